@@ -1,0 +1,182 @@
+/*
+ * mcx.h -- C ABI of the MI355X-native parallel Metropolis-Hastings engine (libmcx.so).
+ *
+ * This is the drop-in boundary for the chain-step hot path of rplzzz/mcpar.  The reference has
+ * no C ABI of its own (its plug-in mechanism is a C++ abstract class linked into the same
+ * executable), so each entry point below cites the C++ member of the reference it replaces; the
+ * reference-compatible C++ classes (include/mcpar/{vlfunc,mcpar,mcout,rosenbrock}.hh) are thin
+ * shims over these functions.  See INTEGRATION.md for the binding a maintainer would add.
+ *
+ * Plain pointers and sizes only.  Unless a parameter says "device", pointers are host memory.
+ * All arithmetic is float32 ("MCX arithmetic v1"); accept decisions are bit-exact
+ * against oracle/mcx_oracle.c for a fixed seed.
+ *
+ * Every function returns MCX_OK (0) or an mcx_status; mcx_last_error() gives the message.
+ * There is no CPU fallback: without a gfx950 device every compute entry point fails with
+ * MCX_ERR_NO_DEVICE.
+ */
+#ifndef MCX_H_
+#define MCX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCX_ABI_VERSION 1
+
+typedef enum mcx_status {
+  MCX_OK = 0,
+  MCX_ERR_INVALID = 1,     /* bad argument (the reference throws a string literal: src/mcpar.cc:268) */
+  MCX_ERR_NO_DEVICE = 2,   /* no HIP device / not gfx950 */
+  MCX_ERR_HIP = 3,         /* a HIP call failed (the reference abort()s on VSL errors: src/mcpar.hh:93) */
+  MCX_ERR_UNSUPPORTED = 4, /* e.g. np > 32 in this round */
+  MCX_ERR_ALLOC = 5,       /* sample store does not fit (reference: exit(2), src/mcpar.cc:34-40) */
+  MCX_ERR_EXCHANGE = 6,    /* exchange hook failed / missing (reference: MPI_Abort, src/mcpar.cc:133-137) */
+  MCX_ERR_VLFUNC = 7       /* host likelihood callback missing */
+} mcx_status;
+
+/* ---- likelihood plug-in: replaces class VLFunc (src/vlfunc.hh:9-12) ---------------------- */
+enum {
+  MCX_VL_ROSENBROCK1 = 1, /* Rosenbrock1::operator()  src/rosenbrock.cc:4-21   (fused on device) */
+  MCX_VL_ROSENBROCK2 = 2, /* Rosenbrock2::operator()  src/rosenbrock.cc:25-41  as written (device, unfused) */
+  MCX_VL_GAUSSIAN = 3,    /* Gaussian::operator()     src/rosenbrock.cc:44-61  any d      (fused) */
+  MCX_VL_DUALGAUSS = 4,   /* DualGaussian::operator() src/rosenbrock.cc:63-78             (fused) */
+  MCX_VL_GAUSSMIX = 5,    /* N-D K-component unit-variance mixture (BASELINE config 5)    (fused) */
+  MCX_VL_HOST = 100       /* any user VLFunc subclass: device -> host callback -> device  */
+};
+
+/* same contract as VLFunc::operator()(int npset, const float *x, float *restrict y): x is
+ * row-major [npset][d], y is [npset]; the return code is ignored like the reference's
+ * (doc/userguide.tex:146-149).  Called on the thread that called mcx_run. */
+typedef int (*mcx_host_fn)(void *ctx, int npset, const float *x, float *y);
+
+typedef struct mcx_vlfunc {
+  int kind;            /* MCX_VL_* */
+  int d;               /* parameters per set; must equal the engine's np */
+  int ncomp;           /* GAUSSMIX: number of components K (<= 64) */
+  const float *params; /* GAUSSIAN: mu[d], sig2[d] (NULL = standard normal); DUALGAUSS: w;
+                          GAUSSMIX: means[K*d], weights[K].  Copied by mcx_run. */
+  mcx_host_fn fn;      /* HOST */
+  void *ctx;           /* HOST */
+} mcx_vlfunc;
+
+/* batched likelihood on host buffers: the VLFunc call itself, runs the device kernel */
+int mcx_vlfunc_eval(const mcx_vlfunc *f, int npset, const float *x, float *y);
+
+/* ---- engine: replaces class MCPar (src/mcpar.hh:10-91) ------------------------------------ */
+typedef struct mcx_engine mcx_engine;
+
+/* MCPar::MCPar(np, nc, mpisiz, mpirank, pl, armin, armax, dfac, ifac, sync) src/mcpar.hh:32-33,
+ * src/mcpar.cc:216-272.  nshards/shard replace mpisiz/mpirank (one shard per GPU/process; this
+ * shard owns global chains [shard*nc, (shard+1)*nc)).  seed replaces the literal 8675309 of
+ * src/mcpar.cc:271.  Runs on the current HIP device of the calling thread. */
+int mcx_create(mcx_engine **out, int np, int nc, int nshards, int shard, float pl, float armin,
+               float armax, float dfac, float ifac, int sync, uint32_t seed);
+/* MCPar::~MCPar  src/mcpar.cc:274-299 */
+int mcx_destroy(mcx_engine *e);
+
+/* MCPar::run(nsamp, nburn, pinit, L, outsamples, incov)  src/mcpar.hh:36-37, src/mcpar.cc:17-214.
+ * pinit[nc*np] and incov[np*np] (or NULL = identity) are copied.  Samples go to the engine's
+ * HBM-resident sample store (mcx_samples_*), which plays the role of MCout's vector. */
+int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L,
+            const float *incov);
+
+/* MCPar::genLocal(pvals, ptrial, cfac)  src/mcpar.hh:40, src/mcpar.cc:302-312.  t is the RNG
+ * step index; host buffers [nc*np], [nc*np], [nc].  Uses the engine's current
+ * Cholesky factor (mcx_set_chol / last run). */
+int mcx_gen_local(mcx_engine *e, uint32_t t, const float *pvals, float *ptrial, float *cfac);
+/* MCPar::genRemote(pvals, musigall, ptrial, cfac)  src/mcpar.hh:41-42, src/mcpar.cc:315-451.
+ * musigall[nshards*nc*np*2] interleaved (mu, sig^2).  mutrial/sigtrial[nc*np] are the side
+ * outputs the reference keeps in members (sigtrial returned squared, :447-448); npass = number
+ * of rejection passes. */
+int mcx_gen_remote(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
+                   float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass);
+/* MCPar::covar_setup(incov, cov)  src/mcpar.hh:38, src/mcpar.cc:454-484: cov[np*np] in/out,
+ * identity if incov == NULL; also installs the factor in the engine. */
+int mcx_covar_setup(mcx_engine *e, const float *incov, float *cov);
+
+/* ---- inter-shard exchange: replaces MPI_Allgather(IN_PLACE, musigall) src/mcpar.cc:127-140 --
+ * phase MCX_XCHG_BEGIN: start an in-place all-gather of musigall (device pointer, nshards slots
+ * of slot_floats floats; this shard's slot is filled) ordered after the work already queued on
+ * `stream` (a hipStream_t).  phase MCX_XCHG_WAIT: make `stream` wait for that gather.  A hook may
+ * do all the work in BEGIN.  Required when nshards > 1. */
+enum { MCX_XCHG_BEGIN = 0, MCX_XCHG_WAIT = 1 };
+typedef int (*mcx_exchange_fn)(void *ctx, int phase, void *musigall_dev, size_t slot_floats,
+                               int shard, int nshards, void *stream);
+int mcx_set_exchange(mcx_engine *e, mcx_exchange_fn fn, void *ctx);
+
+/* called where the reference dumps output (isamp % outstep == 0 && isamp > 0, and after the
+ * last step: src/mcpar.cc:110-119,212) with the number of main-loop steps completed. */
+typedef int (*mcx_output_fn)(void *ctx, int steps_done);
+int mcx_set_output_hook(mcx_engine *e, mcx_output_fn fn, void *ctx);
+
+/* ---- options ------------------------------------------------------------------------------ */
+enum {
+  MCX_OPT_SAMPLES = 1,     /* 0 none, 1 keep every (step, chain) row in HBM (reference semantics,
+                              src/mcpar.cc:177-182) [default 1] */
+  MCX_OPT_ACCEPT_MASK = 2, /* 1: record one byte per (step, chain), burn-in and main [default 0] */
+  MCX_OPT_FUSE = 3,        /* 1: multi-step fused kernel for local steps [default 1]; 0: one
+                              propose/eval/accept kernel triple per step (same bits) */
+  MCX_OPT_MAX_SEGMENT = 4, /* upper bound on steps per fused launch [default 256] */
+  MCX_OPT_PROFILE = 5,     /* 1: bracket every kernel launch with HIP events (slower) */
+  MCX_OPT_STREAM = 6       /* value = hipStream_t to run on (default: engine-owned stream) */
+};
+int mcx_set_option(mcx_engine *e, int opt, int64_t value);
+
+/* ---- results ------------------------------------------------------------------------------ */
+typedef struct mcx_counters {
+  uint64_t naccept_burn, naccept_main; /* accepted proposals (the reference's float naccept, :43-44) */
+  uint64_t nsteps_burn, nsteps_main;
+  uint64_t remote_steps, remote_passes; /* genRemote calls / rejection passes */
+  uint64_t exchanges;
+  uint64_t kernel_launches;
+} mcx_counters;
+int mcx_get_counters(mcx_engine *e, mcx_counters *c);
+
+int mcx_get_state(mcx_engine *e, float *pvals);       /* [nc*np]  MCPar::pvals   */
+int mcx_get_loglike(mcx_engine *e, float *ly);        /* [nc]     MCPar::lylast  */
+int mcx_get_mean(mcx_engine *e, float *mu);           /* [nc*np]  MCPar::mu      */
+int mcx_get_var(mcx_engine *e, float *sig);           /* [nc*np]  MCPar::sig (population variance) */
+int mcx_get_musigall(mcx_engine *e, float *musigall); /* [nshards*nc*np*2] MCPar::musigall */
+int mcx_get_chol(mcx_engine *e, float *cov);          /* [np*np]  MCPar::cov after tuning */
+int mcx_get_accept_counts(mcx_engine *e, uint32_t *counts); /* [nc] per chain, burn + main */
+int mcx_get_accept_mask(mcx_engine *e, uint8_t *mask);      /* [(nburn+nsamp)*nc] of the last run */
+int mcx_get_tuner_trace(mcx_engine *e, float *scales, int maxn, int *n); /* cov[0] after each check */
+
+/* sample store of the last run, in MCout row format: (np+1) columns, step-major then chain
+ * (src/mcout.cc:129-145).  rows = steps*nc. */
+int mcx_samples_steps(mcx_engine *e, int *nsteps);
+int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float *rows);
+/* running maximum-likelihood sample of this shard (MCout::add's maxlval, src/mcout.cc:140-144) */
+int mcx_samples_maxlike(mcx_engine *e, float *lmax, float *params);
+
+/* ---- profiling (MCX_OPT_PROFILE) ---------------------------------------------------------- */
+enum { MCX_K_FUSED_BURN = 0, MCX_K_FUSED_MAIN, MCX_K_PROPOSE, MCX_K_EVAL, MCX_K_ACCEPT,
+       MCX_K_REMOTE, MCX_K_TUNER, MCX_K_MISC, MCX_K_COUNT };
+typedef struct mcx_profile {
+  double ms[MCX_K_COUNT];
+  uint64_t launches[MCX_K_COUNT];
+  uint64_t chain_steps[MCX_K_COUNT];
+} mcx_profile;
+int mcx_get_profile(mcx_engine *e, mcx_profile *p);
+
+/* ---- misc --------------------------------------------------------------------------------- */
+const char *mcx_last_error(void);
+int mcx_abi_version(void);
+int mcx_device_info(char *name, size_t namelen, int *cu_count, size_t *hbm_bytes);
+int mcx_set_device(int device);
+/* device evaluation of the arithmetic primitives for bit-exactness tests:
+ * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
+ * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0) */
+int mcx_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out_bits);
+/* normals of stream `stream`, counter (t, g0+i, a, q) for i < n: out[n*4] */
+int mcx_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uint32_t g0, uint32_t a,
+                      uint32_t q, int n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCX_H_ */

@@ -1,0 +1,94 @@
+"""ctypes loader for libmcx.so.  Fails loudly when the HIP library has not been built."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class McxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mcx status %d: %s" % (code, msg))
+        self.code = code
+
+
+HOSTFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+XCHGFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
+OUTFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+
+
+class VLFunc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("d", C.c_int), ("ncomp", C.c_int),
+                ("params", C.POINTER(C.c_float)), ("fn", HOSTFN), ("ctx", C.c_void_p)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("naccept_burn", "naccept_main", "nsteps_burn", "nsteps_main",
+                                          "remote_steps", "remote_passes", "exchanges", "kernel_launches")]
+
+
+K_NAMES = ("fused_burn", "fused_main", "propose", "eval", "accept", "remote", "tuner", "misc")
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("chain_steps", C.c_uint64 * 8)]
+
+
+def lib_path():
+    return os.path.join(HERE, "libmcx.so")
+
+
+_lib = None
+
+
+def load():
+    """dlopen libmcx.so and declare every entry point of include/mcx.h"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise McxError(-1, "%s not found: build it with `make lib` (hipcc --offload-arch=gfx950); "
+                           "there is no CPU fallback" % p)
+    L = C.CDLL(p)
+    fp, u32p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+    sig = {
+        "mcx_vlfunc_eval": [C.POINTER(VLFunc), C.c_int, fp, fp],
+        "mcx_create": [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                       C.c_float, C.c_float, C.c_float, C.c_int, C.c_uint32],
+        "mcx_destroy": [vp],
+        "mcx_run": [vp, C.c_int, C.c_int, fp, C.POINTER(VLFunc), fp],
+        "mcx_gen_local": [vp, C.c_uint32, fp, fp, fp],
+        "mcx_gen_remote": [vp, C.c_uint32, fp, fp, fp, fp, fp, fp, C.POINTER(C.c_int)],
+        "mcx_covar_setup": [vp, fp, fp],
+        "mcx_set_exchange": [vp, XCHGFN, vp],
+        "mcx_set_output_hook": [vp, OUTFN, vp],
+        "mcx_set_option": [vp, C.c_int, C.c_int64],
+        "mcx_get_counters": [vp, C.POINTER(Counters)],
+        "mcx_get_state": [vp, fp], "mcx_get_loglike": [vp, fp], "mcx_get_mean": [vp, fp],
+        "mcx_get_var": [vp, fp], "mcx_get_musigall": [vp, fp], "mcx_get_chol": [vp, fp],
+        "mcx_get_accept_counts": [vp, u32p],
+        "mcx_get_accept_mask": [vp, C.POINTER(C.c_uint8)],
+        "mcx_get_tuner_trace": [vp, fp, C.c_int, C.POINTER(C.c_int)],
+        "mcx_samples_steps": [vp, C.POINTER(C.c_int)],
+        "mcx_samples_copy": [vp, C.c_int, C.c_int, fp],
+        "mcx_samples_maxlike": [vp, fp, fp],
+        "mcx_get_profile": [vp, C.POINTER(Profile)],
+        "mcx_abi_version": [],
+        "mcx_device_info": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
+        "mcx_set_device": [C.c_int],
+        "mcx_debug_numerics": [C.c_int, C.c_int, u32p, u32p],
+        "mcx_debug_normals": [C.c_uint32] * 6 + [C.c_int, fp],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    L.mcx_last_error.restype = C.c_char_p
+    L.mcx_last_error.argtypes = []
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        raise McxError(code, load().mcx_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,662 @@
+// mcx_device.hpp -- gfx950 kernels of the chain-step hot path.
+//
+// Work decomposition: a chain's parameter vector is split into blocks of 4
+// parameters; one lane owns one block, LPC = next_pow2(ceil(d/4)) adjacent lanes own one chain,
+// 64/LPC chains share a wavefront.  With d % 4 == 0 the reference's own row-major chain-state
+// matrix pvals[nchain][nparam] (src/mcpar.hh:63-65) is then read and written as one fully
+// coalesced 16-byte access per lane, one Philox4x32 block feeds exactly one lane's four normals,
+// and the likelihood / acceptance reductions are xor-butterflies over LPC lanes.
+//
+// Reference functions restated here:
+//   genLocal            src/mcpar.cc:302-312   -> propose_block()
+//   VLFunc builtins     src/rosenbrock.cc      -> Lik<...>
+//   accept/reject       src/mcpar.cc:62-75,162-175 -> accept_decision()
+//   Welford + publish   src/mcpar.cc:184-209   -> welford_block(), publish
+//   genRemote           src/mcpar.cc:315-451   -> k_remote_*
+//   burn-in tuner       src/mcpar.cc:77-96     -> k_tuner
+#pragma once
+#include "mcx_numerics.hpp"
+
+namespace mcx {
+
+constexpr int BLOCK = 256;  // 4 wavefronts per workgroup
+constexpr int MAXD_FUSED = 32;
+
+enum LikKind : int { LIK_ROSEN1 = 1, LIK_ROSEN2 = 2, LIK_GAUSS = 3, LIK_MIX = 5 };
+
+template <int LPC>
+__device__ __forceinline__ float group_sum(float p)
+{
+#pragma unroll
+  for (int s = 1; s < LPC; s <<= 1) p = p + __shfl_xor(p, s);
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Likelihood block partials.  xb = this lane's 4 parameters, nv = how many are real, k0 = index
+// of the first one.  lik = device parameter block.
+// ---------------------------------------------------------------------------------------------
+template <int LIK, int LPC>
+struct Lik;
+
+template <int LPC>
+struct Lik<LIK_ROSEN1, LPC> {  // src/rosenbrock.cc:4-21
+  __device__ __forceinline__ void init(const float *, int, int, int, int) {}
+  __device__ __forceinline__ float eval(const float xb[4], int nv) const
+  {
+    float acc = 0.0f;
+    if (nv >= 2) {
+      const float t1 = 1.0f - xb[0];
+      const float t2 = __builtin_fmaf(-xb[0], xb[0], xb[1]);
+      acc = acc + __builtin_fmaf(100.0f * t2, t2, t1 * t1);
+    }
+    if (nv >= 4) {
+      const float t1 = 1.0f - xb[2];
+      const float t2 = __builtin_fmaf(-xb[2], xb[2], xb[3]);
+      acc = acc + __builtin_fmaf(100.0f * t2, t2, t1 * t1);
+    }
+    return -group_sum<LPC>(acc);
+  }
+};
+
+template <int LPC>
+struct Lik<LIK_GAUSS, LPC> {  // src/rosenbrock.cc:44-61; lik = mu[d], s2inv[d]
+  float mu[4], si[4];
+  __device__ __forceinline__ void init(const float *lik, int d, int k0, int nv, int)
+  {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mu[k] = k < nv ? lik[k0 + k] : 0.0f;
+      si[k] = k < nv ? lik[d + k0 + k] : 0.0f;
+    }
+  }
+  __device__ __forceinline__ float eval(const float xb[4], int nv) const
+  {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nv) {
+        const float a = xb[k] - mu[k];
+        acc = __builtin_fmaf((0.5f * a) * a, si[k], acc);
+      }
+    return -group_sum<LPC>(acc);
+  }
+};
+
+template <int LPC>
+struct Lik<LIK_MIX, LPC> {  // log sum_c w_c exp(-|x-m_c|^2/2); lik = means[K*d], logw[K]
+  const float *means, *logw;
+  int K, d, k0;
+  __device__ __forceinline__ void init(const float *lik, int d_, int k0_, int, int K_)
+  {
+    means = lik; K = K_; d = d_; k0 = k0_;
+    logw = lik + (size_t)K_ * d_;
+  }
+  __device__ __forceinline__ float comp(const float xb[4], int nv, int c) const
+  {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nv) {
+        const float a = xb[k] - means[c * d + k0 + k];
+        acc = __builtin_fmaf(a, a, acc);
+      }
+    return __builtin_fmaf(-0.5f, group_sum<LPC>(acc), logw[c]);
+  }
+  __device__ __forceinline__ float eval(const float xb[4], int nv) const
+  {
+    float emax = comp(xb, nv, 0);
+    for (int c = 1; c < K; ++c) {
+      const float e = comp(xb, nv, c);
+      emax = e > emax ? e : emax;
+    }
+    float s = 0.0f;
+    for (int c = 0; c < K; ++c) s = s + expf_v1(comp(xb, nv, c) - emax);
+    return emax + logf_v1(s);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// block load / store helpers: row-major [n][d], this lane's block at column k0
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_block(const float *__restrict__ base, size_t row, int d,
+                                           int k0, int nv, bool vec4, float v[4])
+{
+  const float *p = base + row * (size_t)d + k0;
+  if (vec4) {
+    if (nv == 4) {
+      const float4 f = *reinterpret_cast<const float4 *>(p);
+      v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+      v[0] = v[1] = v[2] = v[3] = 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = k < nv ? p[k] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ void store_block(float *__restrict__ base, size_t row, int d, int k0,
+                                            int nv, bool vec4, const float v[4])
+{
+  float *p = base + row * (size_t)d + k0;
+  if (vec4) {
+    if (nv == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nv) p[k] = v[k];
+  }
+}
+
+// (mu, sig^2) interleaved pairs: musigall slot layout of src/mcpar.cc:205-208
+__device__ __forceinline__ void store_pairs(float *__restrict__ base, size_t row, int d, int k0,
+                                            int nv, bool vec4, const float a[4], const float b[4])
+{
+  float *p = base + 2 * (row * (size_t)d + k0);
+  if (vec4) {
+    if (nv == 4) {
+      reinterpret_cast<float4 *>(p)[0] = make_float4(a[0], b[0], a[1], b[1]);
+      reinterpret_cast<float4 *>(p)[1] = make_float4(a[2], b[2], a[3], b[3]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nv) { p[2 * k] = a[k]; p[2 * k + 1] = b[k]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// genLocal for one block (src/mcpar.cc:302-312): pt = x + T z, T lower triangular (Cholesky
+// factor, scaled by the tuner).  diag: T is diagonal (identity covariance, any tuner history).
+// Tl = T staged in LDS (full path only).
+// ---------------------------------------------------------------------------------------------
+template <int LPC>
+__device__ __forceinline__ void propose_block(const float x[4], float pt[4], const float tdiag[4],
+                                              const float *Tl, bool diag, int d, int q, int nv,
+                                              uint32_t t, uint32_t g, uint32_t seed)
+{
+  float z[4];
+  normal4_from_words(philox4x32_10(t, g, (uint32_t)q, 0u, seed, ST_LOCAL), z);
+  if (diag) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pt[k] = __builtin_fmaf(tdiag[k], z[k], x[k]);
+  } else {
+    const int lane0 = (int)(threadIdx.x & 63u) & ~(LPC - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pt[k] = x[k];
+#pragma unroll
+    for (int qq = 0; qq < LPC; ++qq) {
+      float zz[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) zz[c] = __shfl(z[c], lane0 + qq);
+      if (qq <= q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < nv) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (4 * qq + c < d) pt[k] = __builtin_fmaf(Tl[(4 * q + k) * d + 4 * qq + c], zz[c], pt[k]);
+          }
+      }
+    }
+  }
+}
+
+// accept test (src/mcpar.cc:66-69, 166-169): u < exp(ly' - ly) * cfac
+__device__ __forceinline__ bool accept_decision(float lytrial, float ly, float cfac, uint32_t word)
+{
+  const float pacpt = expf_v1(lytrial - ly) * cfac;
+  return u24(word) < pacpt;
+}
+
+// Welford update of one block (src/mcpar.cc:199-202)
+__device__ __forceinline__ void welford_block(const float x[4], float mu[4], float ps[4],
+                                              float winv)
+{
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float delta = x[k] - mu[k];
+    mu[k] = __builtin_fmaf(delta, winv, mu[k]);
+    ps[k] = __builtin_fmaf(delta, x[k] - mu[k], ps[k]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused multi-step kernel for local steps: burn-in loop body (src/mcpar.cc:58-75) or main loop
+// body (src/mcpar.cc:152-209) for nsteps consecutive steps, chain state held in registers.
+// ---------------------------------------------------------------------------------------------
+struct SegArgs {
+  float *x, *ly, *mu, *psum2;
+  uint32_t *acc_cnt;
+  unsigned long long *acc_total;  // one atomic per wavefront per launch
+  const float *T;
+  float *samp_x, *samp_ly;  // sample store rows of the segment's first step, or null
+  uint8_t *mask;            // accept mask row of the segment's first step, or null
+  const float *lik;
+  int ncomp;
+  int n, d, nsteps;
+  uint32_t g0, t0, seed;
+  int isamp0;
+  int diag, vec4;
+};
+
+template <int LPC, int LIK, bool MAIN>
+__global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
+{
+  __shared__ float Tl[MAXD_FUSED * MAXD_FUSED];
+  const bool diag = a.diag != 0, vec4 = a.vec4 != 0;
+  const int d = a.d;
+  if (!diag) {
+    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tl[i] = a.T[i];
+    __syncthreads();
+  }
+  const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t chain = gid / LPC;
+  const int q = (int)(gid % LPC);
+  if (chain >= (size_t)a.n) return;
+  const int k0 = 4 * q;
+  const int nv = d - k0 >= 4 ? 4 : (d - k0 > 0 ? d - k0 : 0);
+  const uint32_t g = a.g0 + (uint32_t)chain;
+
+  float x[4], mu[4], ps[4], tdiag[4];
+  load_block(a.x, chain, d, k0, nv, vec4, x);
+  if (MAIN) {
+    load_block(a.mu, chain, d, k0, nv, vec4, mu);
+    load_block(a.psum2, chain, d, k0, nv, vec4, ps);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tdiag[k] = (diag && k < nv) ? a.T[(k0 + k) * d + k0 + k] : 0.0f;
+  float ly = a.ly[chain];
+  Lik<LIK, LPC> L;
+  L.init(a.lik, d, k0, nv, a.ncomp);
+
+  uint32_t cnt = 0, wacc = 0;
+  u32x4 aw = {0, 0, 0, 0};
+  uint32_t ablk = 0xffffffffu;
+  float winv = 1.0f;
+
+  for (int s = 0; s < a.nsteps; ++s) {
+    const uint32_t t = a.t0 + (uint32_t)s;
+    float pt[4];
+    propose_block<LPC>(x, pt, tdiag, Tl, diag, d, q, nv, t, g, a.seed);
+    const float lyt = L.eval(pt, nv);
+    if ((t >> 2) != ablk) {  // one Philox block serves four consecutive steps
+      ablk = t >> 2;
+      aw = philox4x32_10(ablk, g, 0u, 0u, a.seed, ST_ACCEPT);
+    }
+    const bool take = accept_decision(lyt, ly, 1.0f, pick_word(aw, t & 3u));
+    if (take) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = pt[k];
+      ly = lyt;
+      cnt += 1;
+    }
+    wacc += (uint32_t)__popcll(__ballot(take && q == 0));
+    if (a.mask && q == 0) a.mask[(size_t)s * a.n + chain] = take ? 1 : 0;
+    if (MAIN) {
+      const float pwgt = (float)(a.isamp0 + s + 1);  // src/mcpar.cc:186-187
+      winv = 1.0f / pwgt;
+      welford_block(x, mu, ps, winv);
+      if (a.samp_x) {  // src/mcpar.cc:177-182
+        store_block(a.samp_x, (size_t)s * a.n + chain, d, k0, nv, vec4, x);
+        if (q == 0) a.samp_ly[(size_t)s * a.n + chain] = ly;
+      }
+    }
+  }
+
+  store_block(a.x, chain, d, k0, nv, vec4, x);
+  if (q == 0) {
+    a.ly[chain] = ly;
+    a.acc_cnt[chain] += cnt;
+  }
+  if (MAIN) {
+    store_block(a.mu, chain, d, k0, nv, vec4, mu);
+    store_block(a.psum2, chain, d, k0, nv, vec4, ps);
+  }
+  if ((threadIdx.x & 63u) == 0 && wacc) atomicAdd(a.acc_total, (unsigned long long)wacc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unfused per-step kernels (host-callback likelihoods, Rosenbrock2-as-written, remote steps,
+// MCX_OPT_FUSE=0).  Same device functions, hence the same bits as k_fused_steps.
+// ---------------------------------------------------------------------------------------------
+struct StepArgs {
+  float *x, *ly, *mu, *psum2;
+  float *ptrial, *lytrial, *cfac;
+  const float *mutrial, *sigtrial;  // remote adoption (src/mcpar.cc:189-196)
+  uint32_t *acc_cnt;
+  unsigned long long *acc_total;
+  const float *T;
+  float *samp_x, *samp_ly;
+  uint8_t *mask;
+  const float *lik;
+  int ncomp;
+  int n, d;
+  uint32_t g0, t, seed;
+  int isamp;
+  int diag, vec4, remote;
+};
+
+template <int LPC>
+__global__ __launch_bounds__(BLOCK) void k_propose_local(const StepArgs a)
+{
+  __shared__ float Tl[MAXD_FUSED * MAXD_FUSED];
+  const bool diag = a.diag != 0, vec4 = a.vec4 != 0;
+  const int d = a.d;
+  if (!diag) {
+    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tl[i] = a.T[i];
+    __syncthreads();
+  }
+  const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t chain = gid / LPC;
+  const int q = (int)(gid % LPC);
+  if (chain >= (size_t)a.n) return;
+  const int k0 = 4 * q;
+  const int nv = d - k0 >= 4 ? 4 : (d - k0 > 0 ? d - k0 : 0);
+  float x[4], pt[4], tdiag[4];
+  load_block(a.x, chain, d, k0, nv, vec4, x);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tdiag[k] = (diag && k < nv) ? a.T[(k0 + k) * d + k0 + k] : 0.0f;
+  propose_block<LPC>(x, pt, tdiag, Tl, diag, d, q, nv, a.t, a.g0 + (uint32_t)chain, a.seed);
+  store_block(a.ptrial, chain, d, k0, nv, vec4, pt);
+  if (q == 0) a.cfac[chain] = 1.0f;  // src/mcpar.cc:309
+}
+
+// batched likelihood, the VLFunc call: x[n][d] -> y[n]
+template <int LPC, int LIK>
+__global__ __launch_bounds__(BLOCK) void k_eval(const float *__restrict__ x, float *__restrict__ y,
+                                                int n, int d, const float *lik, int ncomp, int vec4)
+{
+  const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t chain = gid / LPC;
+  const int q = (int)(gid % LPC);
+  if (chain >= (size_t)n) return;
+  const int k0 = 4 * q;
+  const int nv = d - k0 >= 4 ? 4 : (d - k0 > 0 ? d - k0 : 0);
+  float xb[4];
+  load_block(x, chain, d, k0, nv, vec4 != 0, xb);
+  Lik<LIK, LPC> L;
+  L.init(lik, d, k0, nv, ncomp);
+  const float v = L.eval(xb, nv);
+  if (q == 0) y[chain] = v;
+}
+
+// Rosenbrock2 exactly as written (src/rosenbrock.cc:25-41): flat index, x[i+1] read across the
+// set boundary, '-' on the second term, last set one term short.
+__global__ __launch_bounds__(BLOCK) void k_eval_rosen2(const float *__restrict__ x,
+                                                       float *__restrict__ y, int n, int d)
+{
+  const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= (size_t)n) return;
+  const size_t ntot = (size_t)n * d;
+  float acc = 0.0f;
+  for (size_t i = j * d; i < (j + 1) * d; ++i)
+    if (i + 1 < ntot) {
+      const float t1 = 1.0f - x[i];
+      const float t2 = __builtin_fmaf(-x[i], x[i], x[i + 1]);
+      acc = acc + __builtin_fmaf(-(100.0f * t2), t2, t1 * t1);
+    }
+  y[j] = -acc;
+}
+
+template <int LPC, bool MAIN>
+__global__ __launch_bounds__(BLOCK) void k_accept(const StepArgs a)
+{
+  const bool vec4 = a.vec4 != 0;
+  const int d = a.d;
+  const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t chain = gid / LPC;
+  const int q = (int)(gid % LPC);
+  if (chain >= (size_t)a.n) return;
+  const int k0 = 4 * q;
+  const int nv = d - k0 >= 4 ? 4 : (d - k0 > 0 ? d - k0 : 0);
+  const uint32_t g = a.g0 + (uint32_t)chain;
+  float x[4];
+  load_block(a.x, chain, d, k0, nv, vec4, x);
+  float ly = a.ly[chain];
+  const float lyt = a.lytrial[chain];
+  const u32x4 aw = philox4x32_10(a.t >> 2, g, 0u, 0u, a.seed, ST_ACCEPT);
+  const bool take = accept_decision(lyt, ly, a.cfac[chain], pick_word(aw, a.t & 3u));
+  if (take) {
+    load_block(a.ptrial, chain, d, k0, nv, vec4, x);
+    ly = lyt;
+    store_block(a.x, chain, d, k0, nv, vec4, x);
+    if (q == 0) {
+      a.ly[chain] = ly;
+      a.acc_cnt[chain] += 1;
+    }
+  }
+  const uint32_t wacc = (uint32_t)__popcll(__ballot(take && q == 0));
+  if (a.mask && q == 0) a.mask[chain] = take ? 1 : 0;
+  if (MAIN) {
+    float mu[4], ps[4];
+    const float pwgt = (float)(a.isamp + 1);
+    const float winv = 1.0f / pwgt;
+    if (a.remote && take) {  // src/mcpar.cc:189-196
+      float sg[4];
+      load_block(a.mutrial, chain, d, k0, nv, vec4, mu);
+      load_block(a.sigtrial, chain, d, k0, nv, vec4, sg);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ps[k] = sg[k] * (pwgt - 1.0f);
+    } else {
+      load_block(a.mu, chain, d, k0, nv, vec4, mu);
+      load_block(a.psum2, chain, d, k0, nv, vec4, ps);
+    }
+    welford_block(x, mu, ps, winv);
+    store_block(a.mu, chain, d, k0, nv, vec4, mu);
+    store_block(a.psum2, chain, d, k0, nv, vec4, ps);
+    if (a.samp_x) {
+      store_block(a.samp_x, chain, d, k0, nv, vec4, x);
+      if (q == 0) a.samp_ly[chain] = ly;
+    }
+  }
+  if ((threadIdx.x & 63u) == 0 && wacc) atomicAdd(a.acc_total, (unsigned long long)wacc);
+}
+
+// start of the main loop: mu = 0, psum2 = FPEPS (src/mcpar.cc:99-104)
+__global__ void k_init_moments(float *mu, float *psum2, size_t ntot)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ntot) { mu[i] = 0.0f; psum2[i] = FPEPS; }
+}
+
+// Publish this shard's (mu, sig^2) pairs into its musigall slot (src/mcpar.cc:202-208).  The
+// reference rewrites the slot every step; the slot is only read by genRemote and by the exchange,
+// so it is written once, right before either of them, from the resident moments.
+__global__ void k_publish(const float *__restrict__ mu, const float *__restrict__ psum2,
+                          float *__restrict__ slot, size_t ntot, float winv)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ntot) reinterpret_cast<float2 *>(slot)[i] = make_float2(mu[i], psum2[i] * winv);
+}
+
+// sig = psum2 / pwgt for the getter (src/mcpar.cc:202)
+__global__ void k_variance(const float *psum2, float *sig, size_t ntot, float winv)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ntot) sig[i] = psum2[i] * winv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Burn-in acceptance-rate tuner (src/mcpar.cc:77-96), on device so that burn-in needs no host
+// round trip.  ctr[0] = accepts of the segment just run, ctr[1] = tuner naccept, ctr[2] = tuner
+// ntrial, ctr[3] = total burn-in accepts.  Integer counters (the reference's float counters stop
+// counting at 2^24: SURVEY §7).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsigned long long add_trials,
+                        int check, float armin, float armax, float dfac, float ifac, float *trace,
+                        int *ntrace)
+{
+  __shared__ float fac;
+  if (threadIdx.x == 0) {
+    const unsigned long long seg = ctr[0];
+    ctr[0] = 0;
+    unsigned long long na = ctr[1] + seg, nt = ctr[2] + add_trials;
+    ctr[3] += seg;
+    float f = 1.0f;
+    if (check) {
+      const float arate = (float)na / (float)nt;
+      if (arate < armin) { na = nt = 0; f = dfac; }
+      else if (arate > armax) { na = nt = 0; f = ifac; }
+    }
+    ctr[1] = na;
+    ctr[2] = nt;
+    fac = f;
+  }
+  __syncthreads();
+  if (check) {
+    const float f = fac;
+    if (f != 1.0f)
+      for (int i = threadIdx.x; i < ncov; i += blockDim.x) T[i] *= f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int k = *ntrace;
+      if (k < 256) trace[k] = T[0];
+      *ntrace = k + 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// genRemote (src/mcpar.cc:315-451).  One lane per chain, chain vector in registers, the N
+// per-chain Gaussians Q_i streamed through wave-uniform (scalar) loads.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ winv, size_t nd)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nd) winv[i] = 1.0f / musigall[2 * i + 1];
+}
+
+template <int DMAX>
+__device__ __forceinline__ float q_arg(const float *__restrict__ ms, const float *__restrict__ wv,
+                                       const float x[DMAX], int d)
+{
+  float arg = 0.0f;
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k)
+    if (k < d) {
+      const float xm = ms[2 * k] - x[k];
+      arg = __builtin_fmaf(xm * xm, wv[k], arg);
+    }
+  return arg;
+}
+
+// numerator of cfac: max_i Q_i(pvals_j) (src/mcpar.cc:421-437); does not depend on the pass
+template <int DMAX>
+__global__ __launch_bounds__(BLOCK) void k_remote_cmax(const float *__restrict__ pvals,
+                                                       const float *__restrict__ musigall,
+                                                       const float *__restrict__ winv,
+                                                       float *__restrict__ cmax, int n, int d, int N)
+{
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  float x[DMAX];
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) x[k] = k < d ? pvals[(size_t)j * d + k] : 0.0f;
+  float cm = 0.0f;
+  for (int qi = 0; qi < N; ++qi) {
+    const float gv = expf_v1(-0.5f * q_arg<DMAX>(musigall + 2 * (size_t)qi * d, winv + (size_t)qi * d, x, d));
+    cm = gv > cm ? gv : cm;
+  }
+  cmax[j] = cm;
+}
+
+struct RemoteArgs {
+  const int *active_in;
+  int nact;
+  int *active_out;
+  int *nact_out;
+  const float *musigall, *winv, *cmax;
+  float *ptrial, *mutrial, *sigtrial, *cfac;
+  int n, d, N, pass;
+  uint32_t g0, t, seed;
+};
+
+template <int DMAX>
+__global__ __launch_bounds__(BLOCK) void k_remote_pass(const RemoteArgs a)
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.nact) return;
+  const int j = a.active_in ? a.active_in[i] : i;
+  const int d = a.d;
+  const uint32_t g = a.g0 + (uint32_t)j;
+  const u32x4 w = philox4x32_10(a.t, g, (uint32_t)a.pass, 0u, a.seed, ST_RSEL);
+  const int sel = (int)(((uint64_t)w.x * (uint64_t)a.N) >> 32);  // src/mcpar.cc:337
+  float x[DMAX];
+#pragma unroll
+  for (int qb = 0; qb < (DMAX + 3) / 4; ++qb) {
+    if (4 * qb < d) {
+      float z[4];
+      normal4_from_words(philox4x32_10(a.t, g, (uint32_t)a.pass, (uint32_t)qb, a.seed, ST_RNORM), z);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * qb + c;
+        if (k < DMAX && k < d) {  // src/mcpar.cc:339-352
+          const float m = a.musigall[2 * ((size_t)sel * d + k)];
+          const float sg = __builtin_sqrtf(a.musigall[2 * ((size_t)sel * d + k) + 1]);
+          x[k] = __builtin_fmaf(sg, z[c], m);
+          a.mutrial[(size_t)j * d + k] = m;
+          a.sigtrial[(size_t)j * d + k] = sg;
+          a.ptrial[(size_t)j * d + k] = x[k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k)
+    if (k >= d) x[k] = 0.0f;
+  float qs = FPEPS, qm = FPEPS;  // src/mcpar.cc:355-365
+  for (int qi = 0; qi < a.N; ++qi) {  // src/mcpar.cc:367-395
+    const float gv = expf_v1(-0.5f * q_arg<DMAX>(a.musigall + 2 * (size_t)qi * d, a.winv + (size_t)qi * d, x, d));
+    qs = qs + gv;
+    qm = gv > qm ? gv : qm;
+  }
+  const float pacpt = qm / qs;  // src/mcpar.cc:397-398
+  if (u24(w.y) < pacpt) {       // src/mcpar.cc:405-441
+    a.cfac[j] = a.cmax[j] / qm;
+  } else {
+    const int slot = atomicAdd(a.nact_out, 1);
+    a.active_out[slot] = j;
+  }
+}
+
+// src/mcpar.cc:447-448
+__global__ void k_square(float *v, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = v[i] * v[i];
+}
+
+// test hooks -----------------------------------------------------------------------------------
+__global__ void k_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t w = in[i];
+  float s, c;
+  uint32_t r = 0;
+  switch (what) {
+  case 0: r = as_u32(logf_v1(as_f32(w))); break;
+  case 1: r = as_u32(expf_v1(as_f32(w))); break;
+  case 2: sincos2pi_v1(w, s, c); r = as_u32(s); break;
+  case 3: sincos2pi_v1(w, s, c); r = as_u32(c); break;
+  case 4: r = as_u32(u24(w)); break;
+  case 5: r = as_u32(uopen(w)); break;
+  case 6: r = philox4x32_10(w, 0, 0, 0, 0, 0).x; break;
+  default: break;
+  }
+  out[i] = r;
+}
+
+__global__ void k_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uint32_t g0, uint32_t a,
+                                uint32_t q, int n, float *out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float z[4];
+  normal4_from_words(philox4x32_10(t, g0 + (uint32_t)i, a, q, seed, stream), z);
+  for (int k = 0; k < 4; ++k) out[4 * i + k] = z[k];
+}
+
+}  // namespace mcx

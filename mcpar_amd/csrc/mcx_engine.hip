@@ -1,0 +1,1017 @@
+// mcx_engine.hip -- host side of libmcx.so: the C ABI of include/mcx.h and the step-loop control
+// code that replaces MCPar::run (src/mcpar.cc:17-214) by a schedule of gfx950 kernel launches.
+//
+// There is no CPU compute path in this file: every entry point that computes anything needs a
+// HIP device and returns MCX_ERR_NO_DEVICE without one.
+#include "../../include/mcx.h"
+#include "mcx_device.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mcx;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? MCX_ERR_NO_DEVICE \
+                                                                        : MCX_ERR_HIP,      \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define MCXCHK(expr)          \
+  do {                        \
+    int s_ = (expr);          \
+    if (s_ != MCX_OK) return s_; \
+  } while (0)
+
+extern "C" const char *mcx_last_error(void) { return g_err.c_str(); }
+extern "C" int mcx_abi_version(void) { return MCX_ABI_VERSION; }
+
+static int need_device()
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n < 1)
+    return fail(MCX_ERR_NO_DEVICE, "no HIP device visible (%s); libmcx has no CPU fallback",
+                e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  return MCX_OK;
+}
+
+extern "C" int mcx_set_device(int device)
+{
+  MCXCHK(need_device());
+  HIPCHK(hipSetDevice(device));
+  return MCX_OK;
+}
+
+extern "C" int mcx_device_info(char *name, size_t namelen, int *cu_count, size_t *hbm_bytes)
+{
+  MCXCHK(need_device());
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, dev));
+  if (name && namelen) snprintf(name, namelen, "%s (%s)", p.name, p.gcnArchName);
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+static inline int lpc_for(int d)
+{
+  const int nb = (d + 3) / 4;
+  int l = 1;
+  while (l < nb) l <<= 1;
+  return l;
+}
+static inline int dmax_for(int d)
+{
+  int m = 2;
+  while (m < d) m <<= 1;
+  return m;
+}
+static inline unsigned nblocks(size_t threads) { return (unsigned)((threads + BLOCK - 1) / BLOCK); }
+
+// Cholesky factor, lower, row-major, strict upper triangle zeroed: the role of spotrf('U') on the
+// column-major view in MCPar::covar_setup (src/mcpar.cc:470-480).  Host side, np <= 32, once per run.
+static int cholesky_lower(int d, float *a)
+{
+  for (int i = 0; i < d; ++i) {
+    for (int j = 0; j <= i; ++j) {
+      float s = a[i * d + j];
+      for (int k = 0; k < j; ++k) s = std::fmaf(-a[i * d + k], a[j * d + k], s);
+      if (i == j) {
+        if (!(s > 0.0f)) return i + 1;
+        a[i * d + i] = std::sqrt(s);
+      } else {
+        a[i * d + j] = s / a[j * d + j];
+      }
+    }
+    for (int j = i + 1; j < d; ++j) a[i * d + j] = 0.0f;
+  }
+  return 0;
+}
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count)
+  {
+    if (count <= n && p) return MCX_OK;
+    release();
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      n = 0;
+      return fail(MCX_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    }
+    n = count;
+    return MCX_OK;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+// device-side likelihood descriptor built from an mcx_vlfunc
+struct LikDev {
+  int kind = 0;  // LikKind, or MCX_VL_HOST
+  int ncomp = 0;
+  DevBuf<float> params;
+  mcx_host_fn fn = nullptr;
+  void *ctx = nullptr;
+  bool fusable() const { return kind == LIK_ROSEN1 || kind == LIK_GAUSS || kind == LIK_MIX; }
+};
+
+static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
+{
+  if (!f) return fail(MCX_ERR_INVALID, "vlfunc is NULL");
+  if (f->d != np) return fail(MCX_ERR_INVALID, "vlfunc.d = %d but engine np = %d", f->d, np);
+  const int d = f->d;
+  std::vector<float> h;
+  L.fn = nullptr;
+  L.ctx = nullptr;
+  L.ncomp = 0;
+  switch (f->kind) {
+  case MCX_VL_ROSENBROCK1:
+    if (d < 2 || (d & 1))  // src/rosenbrock.hh:13-16
+      return fail(MCX_ERR_INVALID, "N for Rosenbrock1 must be even and >= 2");
+    L.kind = LIK_ROSEN1;
+    break;
+  case MCX_VL_ROSENBROCK2:
+    if (d < 2) return fail(MCX_ERR_INVALID, "N for Rosenbrock2 must be >= 2");  // src/rosenbrock.hh:27-30
+    L.kind = LIK_ROSEN2;
+    break;
+  case MCX_VL_GAUSSIAN:
+    L.kind = LIK_GAUSS;
+    h.resize(2 * (size_t)d);
+    for (int k = 0; k < d; ++k) {  // src/rosenbrock.hh:44-47
+      h[k] = f->params ? f->params[k] : 0.0f;
+      h[d + k] = f->params ? 1.0f / f->params[d + k] : 1.0f;
+    }
+    break;
+  case MCX_VL_DUALGAUSS: {
+    if (d != 2) return fail(MCX_ERR_INVALID, "DualGaussian is two-dimensional");
+    if (!f->params) return fail(MCX_ERR_INVALID, "DualGaussian needs params[0] = w");
+    L.kind = LIK_MIX;
+    L.ncomp = 2;
+    const float m[4] = {0.0f, 0.0f, 5.0f, 5.0f};  // src/rosenbrock.cc:71-72
+    h.assign(m, m + 4);
+    h.push_back(logf_v1(f->params[0]));
+    h.push_back(0.0f);
+    break;
+  }
+  case MCX_VL_GAUSSMIX: {
+    const int K = f->ncomp;
+    if (K < 1 || K > 64 || !f->params) return fail(MCX_ERR_INVALID, "GAUSSMIX needs 1 <= K <= 64 and params");
+    L.kind = LIK_MIX;
+    L.ncomp = K;
+    h.assign(f->params, f->params + (size_t)K * d);
+    for (int c = 0; c < K; ++c) h.push_back(logf_v1(f->params[(size_t)K * d + c]));
+    break;
+  }
+  case MCX_VL_HOST:
+    if (!f->fn) return fail(MCX_ERR_VLFUNC, "MCX_VL_HOST without a callback");
+    L.kind = MCX_VL_HOST;
+    L.fn = f->fn;
+    L.ctx = f->ctx;
+    break;
+  default:
+    return fail(MCX_ERR_INVALID, "unknown vlfunc kind %d", f->kind);
+  }
+  MCXCHK(L.params.alloc(h.size()));
+  if (!h.empty()) {
+    HIPCHK(hipMemcpyAsync(L.params.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel dispatch on (LPC, likelihood)
+// ---------------------------------------------------------------------------------------------
+#define DISPATCH_LPC(lpc, CALL)                                   \
+  switch (lpc) {                                                  \
+  case 1: { constexpr int LPC_ = 1; CALL; } break;                \
+  case 2: { constexpr int LPC_ = 2; CALL; } break;                \
+  case 4: { constexpr int LPC_ = 4; CALL; } break;                \
+  case 8: { constexpr int LPC_ = 8; CALL; } break;                \
+  default: return fail(MCX_ERR_UNSUPPORTED, "np > 32 is not supported in this build"); \
+  }
+
+#define DISPATCH_DMAX(dm, CALL)                                   \
+  switch (dm) {                                                   \
+  case 2: { constexpr int DMAX_ = 2; CALL; } break;               \
+  case 4: { constexpr int DMAX_ = 4; CALL; } break;               \
+  case 8: { constexpr int DMAX_ = 8; CALL; } break;               \
+  case 16: { constexpr int DMAX_ = 16; CALL; } break;             \
+  case 32: { constexpr int DMAX_ = 32; CALL; } break;             \
+  default: return fail(MCX_ERR_UNSUPPORTED, "np > 32 is not supported in this build"); \
+  }
+
+template <int LPC>
+static int launch_fused(int lik, bool main, const SegArgs &a, hipStream_t st)
+{
+  const dim3 grid(nblocks((size_t)a.n * LPC)), block(BLOCK);
+#define LF(LK)                                                                       \
+  if (main) hipLaunchKernelGGL((k_fused_steps<LPC, LK, true>), grid, block, 0, st, a); \
+  else hipLaunchKernelGGL((k_fused_steps<LPC, LK, false>), grid, block, 0, st, a);
+  switch (lik) {
+  case LIK_ROSEN1: LF(LIK_ROSEN1) break;
+  case LIK_GAUSS: LF(LIK_GAUSS) break;
+  case LIK_MIX: LF(LIK_MIX) break;
+  default: return fail(MCX_ERR_INVALID, "likelihood %d has no fused kernel", lik);
+  }
+#undef LF
+  HIPCHK(hipGetLastError());
+  return MCX_OK;
+}
+
+template <int LPC>
+static int launch_eval(int lik, const float *x, float *y, int n, int d, const float *params,
+                       int ncomp, int vec4, hipStream_t st)
+{
+  const dim3 grid(nblocks((size_t)n * LPC)), block(BLOCK);
+  switch (lik) {
+  case LIK_ROSEN1:
+    hipLaunchKernelGGL((k_eval<LPC, LIK_ROSEN1>), grid, block, 0, st, x, y, n, d, params, ncomp, vec4);
+    break;
+  case LIK_GAUSS:
+    hipLaunchKernelGGL((k_eval<LPC, LIK_GAUSS>), grid, block, 0, st, x, y, n, d, params, ncomp, vec4);
+    break;
+  case LIK_MIX:
+    hipLaunchKernelGGL((k_eval<LPC, LIK_MIX>), grid, block, 0, st, x, y, n, d, params, ncomp, vec4);
+    break;
+  case LIK_ROSEN2:
+    hipLaunchKernelGGL(k_eval_rosen2, dim3(nblocks((size_t)n)), block, 0, st, x, y, n, d);
+    break;
+  default:
+    return fail(MCX_ERR_INVALID, "likelihood %d has no device kernel", lik);
+  }
+  HIPCHK(hipGetLastError());
+  return MCX_OK;
+}
+
+static int eval_device(const LikDev &L, const float *x, float *y, int n, int d, hipStream_t st)
+{
+  const int lpc = lpc_for(d), vec4 = (d % 4 == 0);
+  DISPATCH_LPC(lpc, MCXCHK((launch_eval<LPC_>(L.kind, x, y, n, d, L.params.p, L.ncomp, vec4, st))));
+  return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the engine
+// ---------------------------------------------------------------------------------------------
+struct EvPair {
+  hipEvent_t a, b;
+  int kind;
+  uint64_t chain_steps;
+};
+
+struct mcx_engine {
+  // problem (src/mcpar.hh:47-59)
+  int nparam, nchain, ntot, ncov, size, rank, tchains;
+  float PLOCAL, TGT_ARATE_MIN, TGT_ARATE_MAX, SCALE_DEC, SCALE_INC;
+  int SYNCSTEP;
+  uint32_t seed, tbase = 0;
+  int lpc, vec4;
+  // device state (src/mcpar.hh:61-88)
+  DevBuf<float> pvals, ptrial, mu, sig, psum2, mutrial, sigtrial, musigall, winvall;
+  DevBuf<float> lylast, lytrial, cfac, cmax, cov, trace;
+  DevBuf<uint32_t> acc_cnt;
+  DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
+  DevBuf<int> active0, active1, nact, ntrace;
+  DevBuf<float> samp_x, samp_ly;
+  DevBuf<uint8_t> mask;
+  // host staging
+  std::vector<float> h_ptrial, h_lytrial;
+  // run bookkeeping
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0;
+  int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
+  bool have_run = false, diag = true, xchg_pending = false;
+  int published_steps = 0;  // main-loop steps reflected in this shard's musigall slot
+  float pwgt_last = 0.0f;
+  LikDev lik;
+  mcx_exchange_fn xfn = nullptr;
+  void *xctx = nullptr;
+  mcx_output_fn ofn = nullptr;
+  void *octx = nullptr;
+  mcx_counters cnt{};
+  std::vector<EvPair> evs;
+  mcx_profile prof{};
+};
+
+struct ProfScope {
+  mcx_engine *e;
+  EvPair p{};
+  bool on;
+  ProfScope(mcx_engine *e_, int kind, uint64_t cs) : e(e_), on(e_->opt_profile != 0)
+  {
+    e->cnt.kernel_launches++;
+    if (!on) return;
+    p.kind = kind;
+    p.chain_steps = cs;
+    (void)hipEventCreate(&p.a);
+    (void)hipEventCreate(&p.b);
+    (void)hipEventRecord(p.a, e->stream);
+  }
+  ~ProfScope()
+  {
+    if (!on) return;
+    (void)hipEventRecord(p.b, e->stream);
+    e->evs.push_back(p);
+  }
+};
+
+static void prof_collect(mcx_engine *e)
+{
+  for (auto &p : e->evs) {
+    float ms = 0.0f;
+    (void)hipEventSynchronize(p.b);
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      e->prof.ms[p.kind] += ms;
+      e->prof.launches[p.kind] += 1;
+      e->prof.chain_steps[p.kind] += p.chain_steps;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  e->evs.clear();
+}
+
+extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int shard, float pl,
+                          float armin, float armax, float dfac, float ifac, int sync, uint32_t seed)
+{
+  if (!out) return fail(MCX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (np < 1 || nc < 1 || nshards < 1 || shard < 0 || shard >= nshards || sync < 1)
+    return fail(MCX_ERR_INVALID, "bad problem size np=%d nc=%d nshards=%d shard=%d sync=%d", np, nc,
+                nshards, shard, sync);
+  if (np > MAXD_FUSED) return fail(MCX_ERR_UNSUPPORTED, "np = %d > %d is not supported in this build", np, MAXD_FUSED);
+  if ((long long)nshards * nc > 0x7fffffffLL / (2LL * np))
+    return fail(MCX_ERR_INVALID, "tchains*np*2 overflows int32 (the reference indexes musigall with int)");
+  MCXCHK(need_device());
+  mcx_engine *e = new mcx_engine();
+  e->nparam = np; e->nchain = nc; e->ntot = np * nc; e->ncov = np * np;
+  e->size = nshards; e->rank = shard; e->tchains = nshards * nc;
+  e->PLOCAL = pl; e->TGT_ARATE_MIN = armin; e->TGT_ARATE_MAX = armax;
+  e->SCALE_DEC = dfac; e->SCALE_INC = ifac; e->SYNCSTEP = sync; e->seed = seed;
+  e->lpc = lpc_for(np);
+  e->vec4 = (np % 4 == 0);
+  const size_t nt = (size_t)e->ntot, n = (size_t)nc;
+  int st = MCX_OK;
+  auto A = [&](int s) { if (st == MCX_OK) st = s; };
+  A(e->pvals.alloc(nt)); A(e->ptrial.alloc(nt)); A(e->mu.alloc(nt)); A(e->sig.alloc(nt));
+  A(e->psum2.alloc(nt)); A(e->mutrial.alloc(nt)); A(e->sigtrial.alloc(nt));
+  A(e->musigall.alloc(2 * (size_t)e->tchains * np)); A(e->winvall.alloc((size_t)e->tchains * np));
+  A(e->lylast.alloc(n)); A(e->lytrial.alloc(n)); A(e->cfac.alloc(n)); A(e->cmax.alloc(n));
+  A(e->cov.alloc((size_t)e->ncov)); A(e->trace.alloc(256)); A(e->acc_cnt.alloc(n)); A(e->ctr.alloc(8));
+  A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(1)); A(e->ntrace.alloc(1));
+  if (st == MCX_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    st = fail(MCX_ERR_HIP, "hipStreamCreate failed");
+  if (st != MCX_OK) { mcx_destroy(e); return st; }
+  e->own_stream = true;
+  (void)hipMemsetAsync(e->musigall.p, 0, 2 * (size_t)e->tchains * np * sizeof(float), e->stream);
+  (void)hipMemsetAsync(e->mu.p, 0, nt * sizeof(float), e->stream);
+  (void)hipMemsetAsync(e->sig.p, 0, nt * sizeof(float), e->stream);
+  (void)hipMemsetAsync(e->psum2.p, 0, nt * sizeof(float), e->stream);
+  (void)hipMemsetAsync(e->acc_cnt.p, 0, n * sizeof(uint32_t), e->stream);
+  // identity factor until covar_setup / run installs one (src/mcpar.cc:460-467)
+  std::vector<float> eye((size_t)e->ncov, 0.0f);
+  for (int i = 0; i < np; ++i) eye[(size_t)i * (np + 1)] = 1.0f;
+  (void)hipMemcpyAsync(e->cov.p, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice, e->stream);
+  if (hipStreamSynchronize(e->stream) != hipSuccess) {
+    mcx_destroy(e);
+    return fail(MCX_ERR_HIP, "engine initialisation failed");
+  }
+  *out = e;
+  return MCX_OK;
+}
+
+extern "C" int mcx_destroy(mcx_engine *e)
+{
+  if (!e) return MCX_OK;
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  prof_collect(e);
+  e->pvals.release(); e->ptrial.release(); e->mu.release(); e->sig.release(); e->psum2.release();
+  e->mutrial.release(); e->sigtrial.release(); e->musigall.release(); e->winvall.release();
+  e->lylast.release(); e->lytrial.release(); e->cfac.release(); e->cmax.release(); e->cov.release();
+  e->trace.release(); e->acc_cnt.release(); e->ctr.release(); e->active0.release();
+  e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
+  e->samp_ly.release(); e->mask.release(); e->lik.params.release();
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return MCX_OK;
+}
+
+extern "C" int mcx_set_exchange(mcx_engine *e, mcx_exchange_fn fn, void *ctx)
+{
+  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  e->xfn = fn;
+  e->xctx = ctx;
+  return MCX_OK;
+}
+
+extern "C" int mcx_set_output_hook(mcx_engine *e, mcx_output_fn fn, void *ctx)
+{
+  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  e->ofn = fn;
+  e->octx = ctx;
+  return MCX_OK;
+}
+
+extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
+{
+  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  switch (opt) {
+  case MCX_OPT_SAMPLES: e->opt_samples = value ? 1 : 0; break;
+  case MCX_OPT_ACCEPT_MASK: e->opt_mask = value ? 1 : 0; break;
+  case MCX_OPT_FUSE: e->opt_fuse = value ? 1 : 0; break;
+  case MCX_OPT_MAX_SEGMENT:
+    if (value < 1) return fail(MCX_ERR_INVALID, "MAX_SEGMENT must be >= 1");
+    e->opt_maxseg = (int)std::min<int64_t>(value, 1 << 20);
+    break;
+  case MCX_OPT_PROFILE: e->opt_profile = value ? 1 : 0; break;
+  case MCX_OPT_STREAM:
+    if (e->own_stream && e->stream) {
+      (void)hipStreamSynchronize(e->stream);
+      (void)hipStreamDestroy(e->stream);
+    }
+    e->stream = (hipStream_t)(uintptr_t)value;
+    e->own_stream = false;
+    break;
+  default: return fail(MCX_ERR_INVALID, "unknown option %d", opt);
+  }
+  return MCX_OK;
+}
+
+// MCPar::covar_setup (src/mcpar.cc:454-484)
+static int covar_install(mcx_engine *e, const float *incov, float *cov_out)
+{
+  const int d = e->nparam;
+  std::vector<float> c((size_t)e->ncov, 0.0f);
+  if (incov) std::copy(incov, incov + e->ncov, c.begin());
+  else
+    for (int i = 0; i < d; ++i) c[(size_t)i * (d + 1)] = 1.0f;
+  if (cholesky_lower(d, c.data()) != 0)
+    return fail(MCX_ERR_INVALID, "covariance matrix is not positive definite");
+  e->diag = true;
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < i; ++j)
+      if (c[(size_t)i * d + j] != 0.0f) e->diag = false;
+  HIPCHK(hipMemcpyAsync(e->cov.p, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (cov_out) std::copy(c.begin(), c.end(), cov_out);
+  return MCX_OK;
+}
+
+extern "C" int mcx_covar_setup(mcx_engine *e, const float *incov, float *cov)
+{
+  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  return covar_install(e, incov, cov);
+}
+
+// VLFunc call on device-resident proposals; HOST kind goes device -> host -> device
+static int eval_trials(mcx_engine *e, const float *x_dev, float *y_dev, uint64_t cs)
+{
+  const int n = e->nchain, d = e->nparam;
+  if (e->lik.kind == MCX_VL_HOST) {
+    e->h_ptrial.resize((size_t)e->ntot);
+    e->h_lytrial.resize((size_t)n);
+    HIPCHK(hipMemcpyAsync(e->h_ptrial.data(), x_dev, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    (void)e->lik.fn(e->lik.ctx, n, e->h_ptrial.data(), e->h_lytrial.data());  // return code ignored like the reference
+    HIPCHK(hipMemcpyAsync(y_dev, e->h_lytrial.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    return MCX_OK;
+  }
+  ProfScope ps(e, MCX_K_EVAL, cs);
+  return eval_device(e->lik, x_dev, y_dev, n, d, e->stream);
+}
+
+static void fill_step(mcx_engine *e, StepArgs &a, uint32_t t, int isamp, bool main, size_t maskrow,
+                      int samprow, int remote)
+{
+  a.x = e->pvals.p; a.ly = e->lylast.p; a.mu = e->mu.p; a.psum2 = e->psum2.p;
+  a.ptrial = e->ptrial.p; a.lytrial = e->lytrial.p; a.cfac = e->cfac.p;
+  a.mutrial = e->mutrial.p; a.sigtrial = e->sigtrial.p;
+  a.acc_cnt = e->acc_cnt.p;
+  a.acc_total = e->ctr.p + (main ? 4 : 0);
+  a.T = e->cov.p;
+  a.samp_x = (main && e->opt_samples) ? e->samp_x.p + (size_t)samprow * e->ntot : nullptr;
+  a.samp_ly = (main && e->opt_samples) ? e->samp_ly.p + (size_t)samprow * e->nchain : nullptr;
+  a.mask = e->opt_mask ? e->mask.p + maskrow * (size_t)e->nchain : nullptr;
+  a.lik = e->lik.params.p; a.ncomp = e->lik.ncomp;
+  a.n = e->nchain; a.d = e->nparam;
+  a.g0 = (uint32_t)(e->rank * e->nchain); a.t = t; a.seed = e->seed;
+  a.isamp = isamp; a.diag = e->diag ? 1 : 0; a.vec4 = e->vec4; a.remote = remote;
+}
+
+static int launch_propose(mcx_engine *e, const StepArgs &a)
+{
+  ProfScope ps(e, MCX_K_PROPOSE, (uint64_t)e->nchain);
+  const dim3 grid(nblocks((size_t)a.n * e->lpc)), block(BLOCK);
+  DISPATCH_LPC(e->lpc, hipLaunchKernelGGL((k_propose_local<LPC_>), grid, block, 0, e->stream, a));
+  HIPCHK(hipGetLastError());
+  return MCX_OK;
+}
+
+static int launch_accept(mcx_engine *e, const StepArgs &a, bool main)
+{
+  ProfScope ps(e, MCX_K_ACCEPT, (uint64_t)e->nchain);
+  const dim3 grid(nblocks((size_t)a.n * e->lpc)), block(BLOCK);
+  if (main) { DISPATCH_LPC(e->lpc, hipLaunchKernelGGL((k_accept<LPC_, true>), grid, block, 0, e->stream, a)); }
+  else { DISPATCH_LPC(e->lpc, hipLaunchKernelGGL((k_accept<LPC_, false>), grid, block, 0, e->stream, a)); }
+  HIPCHK(hipGetLastError());
+  return MCX_OK;
+}
+
+// MCPar::genRemote on device buffers (src/mcpar.cc:315-451)
+static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
+                         float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
+{
+  const int n = e->nchain, d = e->nparam, N = e->tchains, dm = dmax_for(d);
+  hipStream_t st = e->stream;
+  ProfScope ps(e, MCX_K_REMOTE, (uint64_t)n);
+  hipLaunchKernelGGL(k_remote_prep, dim3(nblocks((size_t)N * d)), dim3(BLOCK), 0, st, musigall,
+                     e->winvall.p, (size_t)N * d);
+  DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_cmax<DMAX_>), dim3(nblocks((size_t)n)), dim3(BLOCK), 0,
+                                       st, pvals, musigall, e->winvall.p, e->cmax.p, n, d, N));
+  HIPCHK(hipGetLastError());
+  int nact = n, pass = 0;
+  int *ain = nullptr, *aout = e->active0.p;
+  while (nact > 0) {
+    HIPCHK(hipMemsetAsync(e->nact.p, 0, sizeof(int), st));
+    RemoteArgs a;
+    a.active_in = ain; a.nact = nact; a.active_out = aout; a.nact_out = e->nact.p;
+    a.musigall = musigall; a.winv = e->winvall.p; a.cmax = e->cmax.p;
+    a.ptrial = ptrial; a.mutrial = mutrial; a.sigtrial = sigtrial; a.cfac = cfac;
+    a.n = n; a.d = d; a.N = N; a.pass = pass;
+    a.g0 = (uint32_t)(e->rank * e->nchain); a.t = t; a.seed = e->seed;
+    DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_pass<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK),
+                                         0, st, a));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&nact, e->nact.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ain = aout;
+    aout = (aout == e->active0.p) ? e->active1.p : e->active0.p;
+    ++pass;
+    e->cnt.kernel_launches++;
+  }
+  hipLaunchKernelGGL(k_square, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, sigtrial, (size_t)e->ntot);
+  HIPCHK(hipGetLastError());
+  if (npass_out) *npass_out = pass;
+  return MCX_OK;
+}
+
+static int exchange_wait(mcx_engine *e)
+{
+  if (!e->xchg_pending) return MCX_OK;
+  e->xchg_pending = false;
+  if (e->xfn(e->xctx, MCX_XCHG_WAIT, e->musigall.p, 2 * (size_t)e->ntot, e->rank, e->size, e->stream) != 0)
+    return fail(MCX_ERR_EXCHANGE, "exchange hook failed in WAIT");
+  return MCX_OK;
+}
+
+// write this shard's slot from the resident moments after `steps_done` main-loop steps
+static int publish(mcx_engine *e, int steps_done)
+{
+  if (steps_done <= 0 || e->published_steps == steps_done) return MCX_OK;
+  MCXCHK(exchange_wait(e));  // an in-flight gather still reads the slot
+  ProfScope ps(e, MCX_K_MISC, 0);
+  hipLaunchKernelGGL(k_publish, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, e->stream, e->mu.p,
+                     e->psum2.p, e->musigall.p + 2 * (size_t)e->rank * e->ntot, (size_t)e->ntot,
+                     1.0f / (float)steps_done);
+  HIPCHK(hipGetLastError());
+  e->published_steps = steps_done;
+  return MCX_OK;
+}
+
+static int exchange_begin(mcx_engine *e)
+{
+  MCXCHK(exchange_wait(e));
+  if (e->xfn(e->xctx, MCX_XCHG_BEGIN, e->musigall.p, 2 * (size_t)e->ntot, e->rank, e->size, e->stream) != 0)
+    return fail(MCX_ERR_EXCHANGE, "exchange hook failed in BEGIN");
+  e->xchg_pending = true;
+  e->cnt.exchanges++;
+  return MCX_OK;
+}
+
+// one Philox draw per step for the whole job (the reference draws per rank: src/mcpar.cc:142-146)
+static inline bool step_is_remote(const mcx_engine *e, int isamp, uint32_t t)
+{
+  if (isamp < e->SYNCSTEP) return false;
+  const float rndlocal = u24(philox4x32_10(t, 0u, 0u, 0u, e->seed, ST_COIN).x);
+  return !(rndlocal <= e->PLOCAL);
+}
+
+extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L,
+                       const float *incov)
+{
+  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  if (nsamp < 0 || nburn < 0 || !pinit) return fail(MCX_ERR_INVALID, "bad run arguments");
+  if (e->size > 1 && !e->xfn) return fail(MCX_ERR_EXCHANGE, "nshards > 1 needs mcx_set_exchange()");
+  const int n = e->nchain, d = e->nparam;
+  hipStream_t st = e->stream;
+  MCXCHK(lik_setup(e->lik, L, d, st));
+  MCXCHK(covar_install(e, incov, nullptr));  // src/mcpar.cc:20
+  // sample store: every chain, every main-loop step (src/mcpar.cc:31-40, 177-182), kept in HBM
+  e->samp_steps = 0;
+  if (e->opt_samples && nsamp > 0) {
+    int s1 = e->samp_x.alloc((size_t)nsamp * e->ntot), s2 = e->samp_ly.alloc((size_t)nsamp * n);
+    if (s1 != MCX_OK || s2 != MCX_OK)
+      return fail(MCX_ERR_ALLOC, "Unable to allocate space for output samples (%zu bytes)",
+                  (size_t)nsamp * n * (d + 1) * sizeof(float));
+  }
+  if (e->opt_mask) {
+    MCXCHK(e->mask.alloc((size_t)(nburn + nsamp) * n));
+    HIPCHK(hipMemsetAsync(e->mask.p, 0, (size_t)(nburn + nsamp) * n, st));
+  }
+  e->cnt = mcx_counters{};
+  e->published_steps = 0;
+  HIPCHK(hipMemsetAsync(e->ctr.p, 0, 8 * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(e->ntrace.p, 0, sizeof(int), st));
+  HIPCHK(hipMemsetAsync(e->acc_cnt.p, 0, (size_t)n * sizeof(uint32_t), st));
+  HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
+  HIPCHK(hipStreamSynchronize(st));
+  MCXCHK(eval_trials(e, e->pvals.p, e->lylast.p, 0));  // :53
+  const bool fused = e->opt_fuse && e->lik.fusable();
+  const uint32_t g0 = (uint32_t)(e->rank * n);
+
+  SegArgs sa;
+  sa.x = e->pvals.p; sa.ly = e->lylast.p; sa.mu = e->mu.p; sa.psum2 = e->psum2.p;
+  sa.acc_cnt = e->acc_cnt.p; sa.T = e->cov.p; sa.lik = e->lik.params.p; sa.ncomp = e->lik.ncomp;
+  sa.n = n; sa.d = d; sa.g0 = g0; sa.seed = e->seed; sa.diag = e->diag ? 1 : 0; sa.vec4 = e->vec4;
+
+  // ---- burn-in (src/mcpar.cc:55-97) ----
+  int irate = 50;
+  for (int isamp = 0; isamp < nburn;) {
+    int last = irate + 1 < nburn ? irate + 1 : nburn - 1;  // tuner looks at isamp > irate
+    if (last - isamp + 1 > e->opt_maxseg) last = isamp + e->opt_maxseg - 1;
+    const int steps = last - isamp + 1;
+    const uint32_t t0 = e->tbase + (uint32_t)isamp;
+    if (fused) {
+      sa.acc_total = e->ctr.p; sa.samp_x = sa.samp_ly = nullptr;
+      sa.mask = e->opt_mask ? e->mask.p + (size_t)isamp * n : nullptr;
+      sa.nsteps = steps; sa.t0 = t0; sa.isamp0 = 0;
+      ProfScope ps(e, MCX_K_FUSED_BURN, (uint64_t)steps * n);
+      DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, false, sa, st))));
+    } else {
+      for (int s = 0; s < steps; ++s) {
+        StepArgs a;
+        fill_step(e, a, t0 + (uint32_t)s, 0, false, (size_t)(isamp + s), 0, 0);
+        MCXCHK(launch_propose(e, a));
+        MCXCHK(eval_trials(e, e->ptrial.p, e->lytrial.p, (uint64_t)n));
+        MCXCHK(launch_accept(e, a, false));
+      }
+    }
+    const int check = last > irate ? 1 : 0;
+    {
+      ProfScope ps(e, MCX_K_TUNER, 0);
+      hipLaunchKernelGGL(k_tuner, dim3(1), dim3(BLOCK), 0, st, e->ctr.p, e->cov.p, e->ncov,
+                         (unsigned long long)steps * (unsigned long long)n, check, e->TGT_ARATE_MIN,
+                         e->TGT_ARATE_MAX, e->SCALE_DEC, e->SCALE_INC, e->trace.p, e->ntrace.p);
+      HIPCHK(hipGetLastError());
+    }
+    if (check) irate += 50;
+    isamp = last + 1;
+  }
+  e->cnt.nsteps_burn = (uint64_t)nburn;
+
+  // ---- main loop (src/mcpar.cc:99-210) ----
+  if (nsamp > 0) {
+    hipLaunchKernelGGL(k_init_moments, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->mu.p,
+                       e->psum2.p, (size_t)e->ntot);
+    HIPCHK(hipGetLastError());
+  }
+  const int outstep = nsamp > 50 ? nsamp / 10 : 5;  // :110
+  for (int isamp = 0; isamp < nsamp;) {
+    const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
+    if (isamp % outstep == 0 && isamp > 0 && e->ofn) {  // :115-119
+      HIPCHK(hipStreamSynchronize(st));
+      e->samp_steps = isamp;
+      if (e->ofn(e->octx, isamp) != 0) return fail(MCX_ERR_INVALID, "output hook failed");
+    }
+    if (isamp % e->SYNCSTEP == 0 && e->size > 1) {  // :127-140
+      MCXCHK(publish(e, isamp));
+      MCXCHK(exchange_begin(e));
+    }
+    if (step_is_remote(e, isamp, t)) {  // :152-159
+      MCXCHK(publish(e, isamp));
+      MCXCHK(exchange_wait(e));
+      int npass = 0;
+      MCXCHK(remote_device(e, t, e->pvals.p, e->musigall.p, e->ptrial.p, e->cfac.p, e->mutrial.p,
+                           e->sigtrial.p, &npass));
+      e->cnt.remote_steps++;
+      e->cnt.remote_passes += (uint64_t)npass;
+      MCXCHK(eval_trials(e, e->ptrial.p, e->lytrial.p, (uint64_t)n));  // :160
+      StepArgs a;
+      fill_step(e, a, t, isamp, true, (size_t)(nburn + isamp), isamp, 1);
+      MCXCHK(launch_accept(e, a, true));
+      ++isamp;
+      continue;
+    }
+    // run of local steps up to the next output / exchange / remote step
+    int steps = 1;
+    while (isamp + steps < nsamp && steps < e->opt_maxseg) {
+      const int nx = isamp + steps;
+      if (nx % outstep == 0 && e->ofn) break;
+      if (nx % e->SYNCSTEP == 0 && e->size > 1) break;
+      if (step_is_remote(e, nx, t + (uint32_t)steps)) break;
+      ++steps;
+    }
+    if (fused) {
+      sa.acc_total = e->ctr.p + 4;
+      sa.samp_x = e->opt_samples ? e->samp_x.p + (size_t)isamp * e->ntot : nullptr;
+      sa.samp_ly = e->opt_samples ? e->samp_ly.p + (size_t)isamp * n : nullptr;
+      sa.mask = e->opt_mask ? e->mask.p + (size_t)(nburn + isamp) * n : nullptr;
+      sa.nsteps = steps; sa.t0 = t; sa.isamp0 = isamp;
+      ProfScope ps(e, MCX_K_FUSED_MAIN, (uint64_t)steps * n);
+      DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, true, sa, st))));
+    } else {
+      for (int s = 0; s < steps; ++s) {
+        StepArgs a;
+        fill_step(e, a, t + (uint32_t)s, isamp + s, true, (size_t)(nburn + isamp + s), isamp + s, 0);
+        MCXCHK(launch_propose(e, a));
+        MCXCHK(eval_trials(e, e->ptrial.p, e->lytrial.p, (uint64_t)n));
+        MCXCHK(launch_accept(e, a, true));
+      }
+    }
+    isamp += steps;
+  }
+  MCXCHK(publish(e, nsamp));
+  MCXCHK(exchange_wait(e));
+  e->cnt.nsteps_main = (uint64_t)nsamp;
+  e->pwgt_last = (float)nsamp;
+  if (nsamp > 0) {
+    hipLaunchKernelGGL(k_variance, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->psum2.p,
+                       e->sig.p, (size_t)e->ntot, 1.0f / (float)nsamp);
+    HIPCHK(hipGetLastError());
+  }
+  unsigned long long hctr[8];
+  HIPCHK(hipMemcpyAsync(hctr, e->ctr.p, sizeof hctr, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  e->cnt.naccept_burn = hctr[3];
+  e->cnt.naccept_main = hctr[4];
+  e->samp_steps = e->opt_samples ? nsamp : 0;
+  e->last_nsamp = nsamp;
+  e->last_nburn = nburn;
+  e->have_run = true;
+  e->tbase += (uint32_t)(nburn + nsamp);
+  prof_collect(e);
+  if (e->ofn && e->ofn(e->octx, nsamp) != 0) return fail(MCX_ERR_INVALID, "output hook failed");  // :212
+  return MCX_OK;  // :213
+}
+
+// ---------------------------------------------------------------------------------------------
+// standalone operators on host buffers
+// ---------------------------------------------------------------------------------------------
+extern "C" int mcx_vlfunc_eval(const mcx_vlfunc *f, int npset, const float *x, float *y)
+{
+  if (!f || npset < 0 || (npset > 0 && (!x || !y))) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (f->d < 1 || f->d > MAXD_FUSED) return fail(MCX_ERR_UNSUPPORTED, "d = %d outside 1..%d", f->d, MAXD_FUSED);
+  if (f->kind == MCX_VL_HOST) {
+    if (!f->fn) return fail(MCX_ERR_VLFUNC, "MCX_VL_HOST without a callback");
+    return f->fn(f->ctx, npset, x, y);
+  }
+  MCXCHK(need_device());
+  LikDev L;
+  hipStream_t st = nullptr;
+  int rc = lik_setup(L, f, f->d, st);
+  if (rc != MCX_OK || npset == 0) { L.params.release(); return rc; }
+  DevBuf<float> dx, dy;
+  rc = dx.alloc((size_t)npset * f->d);
+  if (rc == MCX_OK) rc = dy.alloc((size_t)npset);
+  if (rc == MCX_OK) {
+    auto run = [&]() -> int {
+      HIPCHK(hipMemcpy(dx.p, x, (size_t)npset * f->d * sizeof(float), hipMemcpyHostToDevice));
+      MCXCHK(eval_device(L, dx.p, dy.p, npset, f->d, st));
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(y, dy.p, (size_t)npset * sizeof(float), hipMemcpyDeviceToHost));
+      return MCX_OK;
+    };
+    rc = run();
+  }
+  dx.release(); dy.release(); L.params.release();
+  return rc;
+}
+
+extern "C" int mcx_gen_local(mcx_engine *e, uint32_t t, const float *pvals, float *ptrial, float *cfac)
+{
+  if (!e || !pvals || !ptrial || !cfac) return fail(MCX_ERR_INVALID, "bad arguments");
+  hipStream_t st = e->stream;
+  DevBuf<float> x;
+  MCXCHK(x.alloc((size_t)e->ntot));
+  auto run = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(x.p, pvals, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));
+    StepArgs a;
+    fill_step(e, a, t, 0, false, 0, 0, 0);
+    a.x = x.p;
+    a.mask = nullptr;
+    MCXCHK(launch_propose(e, a));
+    HIPCHK(hipMemcpyAsync(ptrial, e->ptrial.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(cfac, e->cfac.p, (size_t)e->nchain * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return MCX_OK;
+  };
+  const int rc = run();
+  x.release();
+  return rc;
+}
+
+extern "C" int mcx_gen_remote(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
+                              float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass)
+{
+  if (!e || !pvals || !musigall || !ptrial || !cfac) return fail(MCX_ERR_INVALID, "bad arguments");
+  hipStream_t st = e->stream;
+  DevBuf<float> x, ms;
+  MCXCHK(x.alloc((size_t)e->ntot));
+  int rc = ms.alloc(2 * (size_t)e->tchains * e->nparam);
+  if (rc != MCX_OK) { x.release(); return rc; }
+  auto run = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(x.p, pvals, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ms.p, musigall, 2 * (size_t)e->tchains * e->nparam * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(e->cfac.p, 0, (size_t)e->nchain * sizeof(float), st));
+    MCXCHK(remote_device(e, t, x.p, ms.p, e->ptrial.p, e->cfac.p, e->mutrial.p, e->sigtrial.p, npass));
+    HIPCHK(hipMemcpyAsync(ptrial, e->ptrial.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(cfac, e->cfac.p, (size_t)e->nchain * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (mutrial) HIPCHK(hipMemcpyAsync(mutrial, e->mutrial.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (sigtrial) HIPCHK(hipMemcpyAsync(sigtrial, e->sigtrial.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return MCX_OK;
+  };
+  rc = run();
+  x.release(); ms.release();
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// getters
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int d2h(mcx_engine *e, T *dst, const T *src, size_t count)
+{
+  if (!e || !dst) return fail(MCX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MCX_OK;
+}
+
+extern "C" int mcx_get_counters(mcx_engine *e, mcx_counters *c)
+{
+  if (!e || !c) return fail(MCX_ERR_INVALID, "bad arguments");
+  *c = e->cnt;
+  return MCX_OK;
+}
+extern "C" int mcx_get_state(mcx_engine *e, float *v) { return d2h(e, v, e ? e->pvals.p : nullptr, e ? (size_t)e->ntot : 0); }
+extern "C" int mcx_get_loglike(mcx_engine *e, float *v) { return d2h(e, v, e ? e->lylast.p : nullptr, e ? (size_t)e->nchain : 0); }
+extern "C" int mcx_get_mean(mcx_engine *e, float *v) { return d2h(e, v, e ? e->mu.p : nullptr, e ? (size_t)e->ntot : 0); }
+extern "C" int mcx_get_var(mcx_engine *e, float *v) { return d2h(e, v, e ? e->sig.p : nullptr, e ? (size_t)e->ntot : 0); }
+extern "C" int mcx_get_musigall(mcx_engine *e, float *v) { return d2h(e, v, e ? e->musigall.p : nullptr, e ? 2 * (size_t)e->tchains * e->nparam : 0); }
+extern "C" int mcx_get_chol(mcx_engine *e, float *v) { return d2h(e, v, e ? e->cov.p : nullptr, e ? (size_t)e->ncov : 0); }
+extern "C" int mcx_get_accept_counts(mcx_engine *e, uint32_t *v) { return d2h(e, v, e ? e->acc_cnt.p : nullptr, e ? (size_t)e->nchain : 0); }
+
+extern "C" int mcx_get_accept_mask(mcx_engine *e, uint8_t *mask)
+{
+  if (!e || !mask) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (!e->have_run || !e->opt_mask || !e->mask.p) return fail(MCX_ERR_INVALID, "no accept mask recorded (MCX_OPT_ACCEPT_MASK)");
+  return d2h(e, mask, e->mask.p, (size_t)(e->last_nburn + e->last_nsamp) * e->nchain);
+}
+
+extern "C" int mcx_get_tuner_trace(mcx_engine *e, float *scales, int maxn, int *n)
+{
+  if (!e || !n) return fail(MCX_ERR_INVALID, "bad arguments");
+  int nt = 0;
+  MCXCHK(d2h(e, &nt, e->ntrace.p, 1));
+  *n = nt;
+  const int k = std::min(std::min(nt, maxn), 256);
+  if (k > 0 && scales) MCXCHK(d2h(e, scales, e->trace.p, (size_t)k));
+  return MCX_OK;
+}
+
+extern "C" int mcx_samples_steps(mcx_engine *e, int *nsteps)
+{
+  if (!e || !nsteps) return fail(MCX_ERR_INVALID, "bad arguments");
+  *nsteps = e->samp_steps;
+  return MCX_OK;
+}
+
+extern "C" int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float *rows)
+{
+  if (!e || !rows || first_step < 0 || nsteps < 0) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (first_step + nsteps > e->samp_steps) return fail(MCX_ERR_INVALID, "steps [%d,%d) not in the sample store (%d steps)", first_step, first_step + nsteps, e->samp_steps);
+  const size_t n = (size_t)e->nchain, d = (size_t)e->nparam, nr = (size_t)nsteps * n;
+  if (nr == 0) return MCX_OK;
+  std::vector<float> hx(nr * d), hl(nr);
+  MCXCHK(d2h(e, hx.data(), e->samp_x.p + (size_t)first_step * n * d, nr * d));
+  MCXCHK(d2h(e, hl.data(), e->samp_ly.p + (size_t)first_step * n, nr));
+  for (size_t r = 0; r < nr; ++r) {  // MCout row: params then log-likelihood (src/mcout.cc:129-137)
+    std::memcpy(rows + r * (d + 1), hx.data() + r * d, d * sizeof(float));
+    rows[r * (d + 1) + d] = hl[r];
+  }
+  return MCX_OK;
+}
+
+extern "C" int mcx_samples_maxlike(mcx_engine *e, float *lmax, float *params)
+{
+  if (!e || !lmax || !params) return fail(MCX_ERR_INVALID, "bad arguments");
+  const size_t n = (size_t)e->nchain, d = (size_t)e->nparam, nr = (size_t)e->samp_steps * n;
+  if (nr == 0) return fail(MCX_ERR_INVALID, "sample store is empty");
+  std::vector<float> hl(nr);
+  MCXCHK(d2h(e, hl.data(), e->samp_ly.p, nr));
+  size_t best = 0;
+  float bv = -INFINITY;
+  bool any = false;
+  for (size_t r = 0; r < nr; ++r)  // first strict maximum, like MCout::add (src/mcout.cc:140)
+    if (hl[r] > bv) { bv = hl[r]; best = r; any = true; }
+  *lmax = bv;
+  if (any) MCXCHK(d2h(e, params, e->samp_x.p + best * d, d));
+  else std::fill(params, params + d, 0.0f);
+  return MCX_OK;
+}
+
+extern "C" int mcx_get_profile(mcx_engine *e, mcx_profile *p)
+{
+  if (!e || !p) return fail(MCX_ERR_INVALID, "bad arguments");
+  prof_collect(e);
+  *p = e->prof;
+  return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// numerics test hooks
+// ---------------------------------------------------------------------------------------------
+extern "C" int mcx_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out_bits)
+{
+  if (n < 0 || (n > 0 && (!in || !out_bits))) return fail(MCX_ERR_INVALID, "bad arguments");
+  MCXCHK(need_device());
+  if (n == 0) return MCX_OK;
+  DevBuf<uint32_t> di, dout;
+  MCXCHK(di.alloc((size_t)n));
+  int rc = dout.alloc((size_t)n);
+  if (rc == MCX_OK) {
+    auto run = [&]() -> int {
+      HIPCHK(hipMemcpy(di.p, in, (size_t)n * 4, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_debug_numerics, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, 0, what, n, di.p, dout.p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(out_bits, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+      return MCX_OK;
+    };
+    rc = run();
+  }
+  di.release(); dout.release();
+  return rc;
+}
+
+extern "C" int mcx_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uint32_t g0, uint32_t a,
+                                 uint32_t q, int n, float *out)
+{
+  if (n < 0 || (n > 0 && !out)) return fail(MCX_ERR_INVALID, "bad arguments");
+  MCXCHK(need_device());
+  if (n == 0) return MCX_OK;
+  DevBuf<float> d;
+  MCXCHK(d.alloc((size_t)n * 4));
+  auto run = [&]() -> int {
+    hipLaunchKernelGGL(k_debug_normals, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, 0, seed, stream, t, g0, a, q, n, d.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, d.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return MCX_OK;
+  };
+  const int rc = run();
+  d.release();
+  return rc;
+}

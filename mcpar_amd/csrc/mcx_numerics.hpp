@@ -1,0 +1,146 @@
+// mcx_numerics.hpp -- "MCX arithmetic v1"  for gfx950 and for the engine's host
+// control code.  fp32 only, round-to-nearest-even, explicit fma; this translation unit must be
+// built with -ffp-contract=off and without fast-math so that the device result of every function
+// is a pure function of its input bits.
+//
+// Replaces the Intel MKL VSL calls of the reference hot path:
+//   vslNewStream(MT2203+rank, 8675309)         src/mcpar.cc:270-271  -> Philox4x32-10 counters
+//   vsRngUniform                               src/mcpar.cc:63,146,163,401 -> u24()
+//   viRngUniform                               src/mcpar.cc:337      -> mulhi(word, N)
+//   vsRngGaussianMV(BOXMULLER2)                src/mcpar.cc:306,348  -> normal4()
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MCX_HD __host__ __device__ __forceinline__
+
+namespace mcx {
+
+// RNG streams: Philox key = (seed, stream); counter = (t, g, a, b).  DESIGN.md §3.2
+enum : uint32_t { ST_LOCAL = 0, ST_ACCEPT = 1, ST_COIN = 2, ST_RSEL = 3, ST_RNORM = 4 };
+
+constexpr float FPEPS = 1.0e-14f;  // src/mcpar.cc:15
+
+struct u32x4 {
+  uint32_t x, y, z, w;
+};
+
+MCX_HD float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+MCX_HD uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+MCX_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                           uint32_t k1)
+{
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+
+MCX_HD float u24(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
+MCX_HD float uopen(uint32_t w) { return __builtin_fmaf((float)w, 0x1p-32f, 0x1p-33f); }
+
+MCX_HD float logf_v1(float x)
+{
+  const uint32_t b = as_u32(x);
+  int e = (int)((b >> 23) & 0xffu) - 126;
+  float m = as_f32((b & 0x007fffffu) | 0x3f000000u);
+  const bool lo = m < 0.70710678f;
+  e = lo ? e - 1 : e;
+  m = lo ? (m + m) - 1.0f : m - 1.0f;
+  const float fe = (float)e;
+  const float z = m * m;
+  float p = 7.0376836292e-2f;
+  p = __builtin_fmaf(p, m, -1.1514610310e-1f);
+  p = __builtin_fmaf(p, m, 1.1676998740e-1f);
+  p = __builtin_fmaf(p, m, -1.2420140846e-1f);
+  p = __builtin_fmaf(p, m, 1.4249322787e-1f);
+  p = __builtin_fmaf(p, m, -1.6668057665e-1f);
+  p = __builtin_fmaf(p, m, 2.0000714765e-1f);
+  p = __builtin_fmaf(p, m, -2.4999993993e-1f);
+  p = __builtin_fmaf(p, m, 3.3333331174e-1f);
+  float y = (p * m) * z;
+  y = __builtin_fmaf(-2.12194440e-4f, fe, y);
+  y = __builtin_fmaf(-0.5f, z, y);
+  float r = m + y;
+  r = __builtin_fmaf(0.693359375f, fe, r);
+  return r;
+}
+
+MCX_HD float expf_v1(float x)
+{
+  if (x > 88.72283f) return __builtin_inff();
+  if (x < -87.33654f) return 0.0f;
+  const float fn = __builtin_floorf(__builtin_fmaf(x, 1.44269504f, 0.5f));
+  float r = __builtin_fmaf(fn, -0.693359375f, x);
+  r = __builtin_fmaf(fn, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  const float z = r * r;
+  float y = __builtin_fmaf(p, z, r);
+  y = y + 1.0f;
+  if (!(x == x)) return y;  // NaN in, NaN out (acceptance test then fails: src/mcpar.cc:66-69)
+  const int n = (int)fn;
+  const int n1 = n >> 1;
+  const int n2 = n - n1;
+  y = y * as_f32((uint32_t)(n1 + 127) << 23);
+  y = y * as_f32((uint32_t)(n2 + 127) << 23);
+  return y;
+}
+
+MCX_HD void sincos2pi_v1(uint32_t w, float &s, float &c)
+{
+  const uint32_t k = ((w + 0x20000000u) >> 30) & 3u;
+  const int32_t rem = (int32_t)(w - (k << 30));
+  const float phi = (float)rem * 1.4629180792671596e-9f;
+  const float z = phi * phi;
+  float ps = -1.9515295891e-4f;
+  ps = __builtin_fmaf(ps, z, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+  const float sp = __builtin_fmaf(phi * z, ps, phi);
+  float pc = 2.443315711809948e-5f;
+  pc = __builtin_fmaf(pc, z, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+  const float cp = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+  const bool swap = (k & 1u) != 0u;
+  const float sv = swap ? cp : sp;
+  const float cv = swap ? sp : cp;
+  // k: 0 (s,c)  1 (c,-s)  2 (-s,-c)  3 (-c,s)
+  s = (k >= 2u) ? -sv : sv;
+  c = (k == 1u || k == 2u) ? -cv : cv;
+}
+
+// Box-Muller on one Philox block: (w.x,w.y) -> z0,z1 ; (w.z,w.w) -> z2,z3
+MCX_HD void normal4_from_words(const u32x4 &w, float z[4])
+{
+  float s, c;
+  float r = __builtin_sqrtf(-2.0f * logf_v1(uopen(w.x)));
+  sincos2pi_v1(w.y, s, c);
+  z[0] = r * c;
+  z[1] = r * s;
+  r = __builtin_sqrtf(-2.0f * logf_v1(uopen(w.z)));
+  sincos2pi_v1(w.w, s, c);
+  z[2] = r * c;
+  z[3] = r * s;
+}
+
+MCX_HD uint32_t pick_word(const u32x4 &w, uint32_t i)
+{
+  return i == 0u ? w.x : (i == 1u ? w.y : (i == 2u ? w.z : w.w));
+}
+
+}  // namespace mcx

@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's MCPar interface (src/mcpar.hh:32-42) over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import (HOSTFN, K_NAMES, OUTFN, XCHGFN, Counters, Profile, VLFunc, check, load)
+
+VL_ROSENBROCK1, VL_ROSENBROCK2, VL_GAUSSIAN, VL_DUALGAUSS, VL_GAUSSMIX, VL_HOST = 1, 2, 3, 4, 5, 100
+OPT_SAMPLES, OPT_ACCEPT_MASK, OPT_FUSE, OPT_MAX_SEGMENT, OPT_PROFILE, OPT_STREAM = 1, 2, 3, 4, 5, 6
+XCHG_BEGIN, XCHG_WAIT = 0, 1
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def make_vlfunc(kind, d, params=None, ncomp=0, host_fn=None):
+    """Build an mcx_vlfunc.  host_fn(x[npset, d]) -> y[npset] wraps a user VLFunc (src/vlfunc.hh:9-12).
+    Returns (struct, keepalive)."""
+    p = None if params is None else np.ascontiguousarray(params, dtype=np.float32)
+    cb = HOSTFN()
+    if host_fn is not None:
+        def tramp(ctx, npset, x, y):
+            xa = np.ctypeslib.as_array(x, shape=(npset, d))
+            ya = np.ctypeslib.as_array(y, shape=(npset,))
+            ya[:] = np.asarray(host_fn(xa), dtype=np.float32)
+            return 0
+        cb = HOSTFN(tramp)
+    v = VLFunc(kind, d, ncomp, _fp(p) if p is not None else None, cb, None)
+    return v, (p, cb)
+
+
+def vlfunc_eval(kind, d, x, params=None, ncomp=0):
+    """VLFunc::operator()(npset, x, y) on the GPU"""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, d)
+    y = np.empty(x.shape[0], dtype=np.float32)
+    v, keep = make_vlfunc(kind, d, params, ncomp)
+    check(load().mcx_vlfunc_eval(C.byref(v), x.shape[0], _fp(x), _fp(y)))
+    return y
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cu = C.c_int(0)
+    mem = C.c_size_t(0)
+    check(load().mcx_device_info(name, 256, C.byref(cu), C.byref(mem)))
+    return name.value.decode(), cu.value, mem.value
+
+
+def debug_numerics(what, words):
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.empty_like(w)
+    u32p = C.POINTER(C.c_uint32)
+    check(load().mcx_debug_numerics(what, w.size, w.ctypes.data_as(u32p), out.ctypes.data_as(u32p)))
+    return out
+
+
+def debug_normals(seed, stream, t, g0, a, q, n):
+    out = np.empty((n, 4), np.float32)
+    check(load().mcx_debug_normals(seed, stream, t, g0, a, q, n, _fp(out)))
+    return out
+
+
+class Engine:
+    """MCPar(np, nc, mpisiz, mpirank, pl, armin, armax, dfac, ifac, sync) -- src/mcpar.hh:32-33 --
+    with shards in place of MPI ranks."""
+
+    def __init__(self, np_, nc, nshards=1, shard=0, pl=0.9, armin=0.2, armax=0.5, dfac=0.2,
+                 ifac=1.5, sync=10, seed=8675309):
+        self.np, self.nc, self.nshards, self.shard = np_, nc, nshards, shard
+        self.h = C.c_void_p()
+        self._keep = []
+        check(load().mcx_create(C.byref(self.h), np_, nc, nshards, shard, pl, armin, armax, dfac,
+                                ifac, sync, seed))
+        self.nburn = self.nsamp = 0
+
+    def close(self):
+        if self.h:
+            load().mcx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt, value):
+        check(load().mcx_set_option(self.h, opt, int(value)))
+
+    def set_exchange(self, pyfn):
+        """pyfn(phase, musigall_dev_ptr, slot_floats, shard, nshards, stream_ptr) -> 0 on success"""
+        def tramp(ctx, phase, ptr, slot, shard, nshards, stream):
+            try:
+                return int(pyfn(phase, ptr, slot, shard, nshards, stream) or 0)
+            except Exception:  # never unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = XCHGFN(tramp)
+        self._keep.append(cb)
+        check(load().mcx_set_exchange(self.h, cb, None))
+
+    def set_output_hook(self, pyfn):
+        def tramp(ctx, steps_done):
+            try:
+                return int(pyfn(steps_done) or 0)
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = OUTFN(tramp)
+        self._keep.append(cb)
+        check(load().mcx_set_output_hook(self.h, cb, None))
+
+    def run(self, nsamp, nburn, pinit, vl, incov=None):
+        """MCPar::run(nsamp, nburn, pinit, L, outsamples, incov) -- src/mcpar.hh:36-37"""
+        pinit = np.ascontiguousarray(pinit, dtype=np.float32).reshape(-1)
+        if pinit.size != self.np * self.nc:
+            raise ValueError("pinit must have nc*np elements")
+        ic = None if incov is None else np.ascontiguousarray(incov, dtype=np.float32)
+        check(load().mcx_run(self.h, nsamp, nburn, _fp(pinit), C.byref(vl),
+                             _fp(ic) if ic is not None else None))
+        self.nburn, self.nsamp = nburn, nsamp
+
+    def gen_local(self, t, pvals):
+        pv = np.ascontiguousarray(pvals, np.float32)
+        pt = np.empty_like(pv)
+        cf = np.empty(self.nc, np.float32)
+        check(load().mcx_gen_local(self.h, t, _fp(pv), _fp(pt), _fp(cf)))
+        return pt, cf
+
+    def gen_remote(self, t, pvals, musigall):
+        pv = np.ascontiguousarray(pvals, np.float32)
+        ms = np.ascontiguousarray(musigall, np.float32)
+        pt, mt, sg = np.empty_like(pv), np.empty_like(pv), np.empty_like(pv)
+        cf = np.empty(self.nc, np.float32)
+        npass = C.c_int(0)
+        check(load().mcx_gen_remote(self.h, t, _fp(pv), _fp(ms), _fp(pt), _fp(cf), _fp(mt), _fp(sg),
+                                    C.byref(npass)))
+        return pt, cf, mt, sg, npass.value
+
+    def covar_setup(self, incov=None):
+        out = np.empty((self.np, self.np), np.float32)
+        ic = None if incov is None else np.ascontiguousarray(incov, np.float32)
+        check(load().mcx_covar_setup(self.h, _fp(ic) if ic is not None else None, _fp(out)))
+        return out
+
+    def _get(self, name, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        check(getattr(load(), name)(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    @property
+    def state(self): return self._getf("mcx_get_state", (self.nc, self.np))
+    @property
+    def loglike(self): return self._getf("mcx_get_loglike", (self.nc,))
+    @property
+    def mean(self): return self._getf("mcx_get_mean", (self.nc, self.np))
+    @property
+    def var(self): return self._getf("mcx_get_var", (self.nc, self.np))
+    @property
+    def musigall(self): return self._getf("mcx_get_musigall", (self.nshards * self.nc, self.np, 2))
+    @property
+    def chol(self): return self._getf("mcx_get_chol", (self.np, self.np))
+
+    def _getf(self, name, shape):
+        out = np.empty(shape, np.float32)
+        check(getattr(load(), name)(self.h, _fp(out)))
+        return out
+
+    @property
+    def accept_counts(self):
+        out = np.empty(self.nc, np.uint32)
+        check(load().mcx_get_accept_counts(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    @property
+    def accept_mask(self):
+        out = np.empty((self.nburn + self.nsamp, self.nc), np.uint8)
+        check(load().mcx_get_accept_mask(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    @property
+    def counters(self):
+        c = Counters()
+        check(load().mcx_get_counters(self.h, C.byref(c)))
+        return {n: int(getattr(c, n)) for n, _ in Counters._fields_}
+
+    @property
+    def tuner_trace(self):
+        buf = np.zeros(256, np.float32)
+        n = C.c_int(0)
+        check(load().mcx_get_tuner_trace(self.h, _fp(buf), 256, C.byref(n)))
+        return buf[:min(n.value, 256)].copy()
+
+    @property
+    def samples(self):
+        """MCout rows (np+1 columns), step-major then chain (src/mcout.cc:129-145)"""
+        ns = C.c_int(0)
+        check(load().mcx_samples_steps(self.h, C.byref(ns)))
+        out = np.empty((ns.value * self.nc, self.np + 1), np.float32)
+        if ns.value:
+            check(load().mcx_samples_copy(self.h, 0, ns.value, _fp(out)))
+        return out
+
+    def samples_range(self, first_step, nsteps):
+        out = np.empty((nsteps * self.nc, self.np + 1), np.float32)
+        if nsteps:
+            check(load().mcx_samples_copy(self.h, first_step, nsteps, _fp(out)))
+        return out
+
+    def maxlike(self):
+        lm = C.c_float(0)
+        p = np.empty(self.np, np.float32)
+        check(load().mcx_samples_maxlike(self.h, C.byref(lm), _fp(p)))
+        return lm.value, p
+
+    @property
+    def profile(self):
+        p = Profile()
+        check(load().mcx_get_profile(self.h, C.byref(p)))
+        return {K_NAMES[i]: dict(ms=p.ms[i], launches=int(p.launches[i]), chain_steps=int(p.chain_steps[i]))
+                for i in range(8)}

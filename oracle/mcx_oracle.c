@@ -19,6 +19,8 @@
 
 #define FPEPS 1.0e-14f /* src/mcpar.cc:15 */
 
+static int g_threads = 1; /* OpenMP team size of every parallel loop (mcxo_set_threads) */
+
 /* RNG stream ids (key[1]); key[0] = seed.  DESIGN.md §3.2 */
 enum { ST_LOCAL = 0, ST_ACCEPT = 1, ST_COIN = 2, ST_RSEL = 3, ST_RNORM = 4 };
 
@@ -254,7 +256,7 @@ int mcxo_vlfunc_eval(const mcxo_vlfunc *f, int npset, const float *x, float *y)
   switch (f->kind) {
   case MCXO_VL_ROSENBROCK1:
     if (d < 2 || (d & 1)) return -1; /* src/rosenbrock.hh:13-16 */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int j = 0; j < npset; ++j) y[j] = rosen1_one(d, x + (size_t)j * d);
     return 0;
   case MCXO_VL_ROSENBROCK2: {
@@ -262,7 +264,7 @@ int mcxo_vlfunc_eval(const mcxo_vlfunc *f, int npset, const float *x, float *y)
      * sign of the second term is '-' (src/rosenbrock.cc:32-38) */
     if (d < 2) return -1;
     const long ntot = (long)npset * d;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int j = 0; j < npset; ++j) {
       float acc = 0.0f;
       for (long i = (long)j * d; i < (long)(j + 1) * d; ++i) {
@@ -283,7 +285,7 @@ int mcxo_vlfunc_eval(const mcxo_vlfunc *f, int npset, const float *x, float *y)
       mu[k] = f->params ? f->params[k] : 0.0f;
       s2inv[k] = f->params ? 1.0f / f->params[d + k] : 1.0f; /* src/rosenbrock.hh:44-47 */
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int j = 0; j < npset; ++j) y[j] = gauss_one(d, x + (size_t)j * d, mu, s2inv);
     return 0;
   }
@@ -291,7 +293,7 @@ int mcxo_vlfunc_eval(const mcxo_vlfunc *f, int npset, const float *x, float *y)
     if (d != 2) return -1;
     const float means[4] = {0.0f, 0.0f, 5.0f, 5.0f}; /* src/rosenbrock.cc:71-72 */
     const float logw[2] = {mcxo_logf(f->params[0]), 0.0f};
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int j = 0; j < npset; ++j) y[j] = mix_one(2, 2, x + (size_t)j * 2, means, logw);
     return 0;
   }
@@ -300,7 +302,7 @@ int mcxo_vlfunc_eval(const mcxo_vlfunc *f, int npset, const float *x, float *y)
     if (K < 1 || K > 64) return -1;
     float logw[64];
     for (int c = 0; c < K; ++c) logw[c] = mcxo_logf(f->params[(size_t)K * d + c]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int j = 0; j < npset; ++j) y[j] = mix_one(d, K, x + (size_t)j * d, f->params, logw);
     return 0;
   }
@@ -383,7 +385,11 @@ void mcxo_destroy(mcxo_engine *e)
 }
 
 void mcxo_set_exchange(mcxo_engine *e, mcxo_exchange_fn fn, void *ctx) { e->xfn = fn; e->xctx = ctx; }
-void mcxo_set_threads(mcxo_engine *e, int nthreads) { e->nthreads = nthreads > 0 ? nthreads : 1; }
+void mcxo_set_threads(mcxo_engine *e, int nthreads)
+{
+  e->nthreads = nthreads > 0 ? nthreads : 1;
+  g_threads = e->nthreads;
+}
 void mcxo_set_record(mcxo_engine *e, int ks, int km) { e->keep_samples = ks; e->keep_mask = km; }
 
 /* src/mcpar.cc:454-484 */
@@ -405,7 +411,7 @@ int mcxo_gen_local(const mcxo_engine *e, uint32_t t, const float *pvals, float *
                    float *cfac)
 {
   const int d = e->nparam, nb = (d + 3) / 4;
-#pragma omp parallel for schedule(static) num_threads(e->nthreads)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int j = 0; j < e->nchain; ++j) {
     float z[256];
     for (int q = 0; q < nb; ++q) mcxo_normal4(e->seed, ST_LOCAL, t, gchain(e, j), (uint32_t)q, 0, z + 4 * q);
@@ -437,7 +443,7 @@ int mcxo_gen_remote(mcxo_engine *e, uint32_t t, const float *pvals, const float 
   const int d = e->nparam, n = e->nchain, N = e->tchains, nb = (d + 3) / 4;
   for (size_t i = 0; i < (size_t)N * d; ++i) e->winvall[i] = 1.0f / musigall[2 * i + 1];
   /* numerator of cfac, max_i Q_i(pvals): independent of the pass (src/mcpar.cc:421-437) */
-#pragma omp parallel for schedule(static) num_threads(e->nthreads)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int j = 0; j < n; ++j) {
     float cm = 0.0f;
     for (int qi = 0; qi < N; ++qi) {
@@ -450,7 +456,7 @@ int mcxo_gen_remote(mcxo_engine *e, uint32_t t, const float *pvals, const float 
   for (int j = 0; j < n; ++j) e->rjct[j] = 1; /* :329-331 */
   int anyrjct, pass = 0;
   do {
-#pragma omp parallel for schedule(static) num_threads(e->nthreads)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int j = 0; j < n; ++j) {
       if (!e->rjct[j]) continue;
       uint32_t ctr[4] = {t, gchain(e, j), (uint32_t)pass, 0}, key[2] = {e->seed, ST_RSEL}, w[4];
@@ -502,7 +508,7 @@ static uint64_t accept_all(mcxo_engine *e, uint32_t t, size_t maskrow)
 {
   const int d = e->nparam, n = e->nchain;
   uint64_t nacc = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nacc) num_threads(e->nthreads)
+#pragma omp parallel for schedule(static) reduction(+ : nacc) num_threads(g_threads)
   for (int j = 0; j < n; ++j) {
     uint32_t ctr[4] = {t >> 2, gchain(e, j), 0, 0}, key[2] = {e->seed, ST_ACCEPT}, w[4];
     mcxo_philox4x32_10(ctr, key, w);
@@ -606,7 +612,7 @@ static void main_step(mcxo_engine *e, int isamp)
   e->pwgt += 1.0f;
   const float pwgt = e->pwgt, winv = 1.0f / pwgt;
   float *slot = e->musigall + 2 * (size_t)e->rank * e->ntot;
-#pragma omp parallel for schedule(static) num_threads(e->nthreads)
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int j = 0; j < n; ++j) {
     for (int k = 0; k < d; ++k) {
       size_t i = (size_t)j * d + k;

@@ -1,0 +1,148 @@
+"""HIP engine (through the C ABI) vs the CPU oracle on identical seeded inputs: bit-exact.
+
+Rows of SURVEY §8a covered: a1 burn-in loop + tuner, a2 main loop, a3 genLocal, a5 accept,
+a6 sample emit, a7 Welford/adoption/publish, a4 genRemote (pl < 1), a9 covar_setup, a11 host VLFunc.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def mix_params(d, K):
+    means = np.zeros((K, d), np.float32)
+    for k in range(K):
+        means[k, :] = 5.0 * k / max(K - 1, 1)
+    w = np.ones(K, np.float32)
+    w[0] = 5.0
+    return np.concatenate([means.ravel(), w])
+
+
+def run_pair(kind, d, n, nburn, nsamp, pl, params=None, ncomp=0, incov=None, fuse=1, sync=10,
+             pinit=None, maxseg=None, host=False):
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    p = O.default_pinit(d, n) if pinit is None else pinit
+    vo, keep_o = O.make_vlfunc(kind, d, params, ncomp)
+    eo = O.Engine(d, n, pl=pl, sync=sync, threads=4)
+    eo.run(nsamp, nburn, p, vo, incov)
+    if host:
+        def fn(x):
+            return O.vl_eval(kind, d, x, params, ncomp)
+        vg, keep_g = M.make_vlfunc(M.VL_HOST, d, host_fn=fn)
+    else:
+        vg, keep_g = M.make_vlfunc(kind, d, params, ncomp)
+    eg = M.Engine(d, n, pl=pl, sync=sync)
+    eg.set_option(E.OPT_ACCEPT_MASK, 1)
+    eg.set_option(E.OPT_FUSE, fuse)
+    if maxseg:
+        eg.set_option(E.OPT_MAX_SEGMENT, maxseg)
+    eg.run(nsamp, nburn, p, vg, incov)
+    return eo, eg
+
+
+def assert_same(eo, eg, what=""):
+    mo, mg = eo.accept_mask, eg.accept_mask
+    bad = np.argwhere(mo != mg)
+    assert bad.size == 0, "%s accept mask differs first at (step, chain) %s" % (what, bad[:3])
+    c = eg.counters
+    assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+    assert c["remote_steps"] == eo.remote_steps and c["remote_passes"] == eo.remote_passes
+    np.testing.assert_array_equal(eg.accept_counts, eo.accept_counts)
+    np.testing.assert_array_equal(eg.tuner_trace.view(np.uint32), eo.tuner_trace.view(np.uint32))
+    for name in ("state", "loglike", "mean", "var", "chol", "musigall", "samples"):
+        a, b = getattr(eg, name), getattr(eo, name)
+        if name == "samples":  # the oracle appends across run() calls like MCout::newsamps; the
+            b = b[b.shape[0] - a.shape[0]:]  # engine's HBM store holds the last run
+        assert a.shape == b.shape, name
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
+            "%s %s differs: max abs %g" % (what, name, np.nanmax(np.abs(a - b)))
+
+
+CASES = [
+    # kind, d, n, nburn, nsamp, pl
+    ("dgauss_c1", O.VL_DUALGAUSS, 2, 4, 500, 8, 0.9),
+    ("rosen1_d2", O.VL_ROSENBROCK1, 2, 100, 120, 30, 1.0),
+    ("rosen1_d4", O.VL_ROSENBROCK1, 4, 333, 120, 30, 1.0),
+    ("rosen1_d8", O.VL_ROSENBROCK1, 8, 4096, 200, 50, 1.0),
+    ("rosen1_d16", O.VL_ROSENBROCK1, 16, 1000, 160, 60, 1.0),
+    ("rosen1_d32", O.VL_ROSENBROCK1, 32, 257, 110, 25, 1.0),
+    ("rosen1_d6_ragged", O.VL_ROSENBROCK1, 6, 77, 110, 25, 1.0),
+    ("rosen1_d12_ragged", O.VL_ROSENBROCK1, 12, 65, 110, 25, 1.0),
+    ("rosen1_d30_ragged", O.VL_ROSENBROCK1, 30, 19, 60, 25, 1.0),
+    ("gauss_d3", O.VL_GAUSSIAN, 3, 50, 120, 40, 1.0),
+    ("gauss_d2_murray", O.VL_GAUSSIAN, 2, 64, 120, 80, 0.8),
+    ("rosen1_d16_murray", O.VL_ROSENBROCK1, 16, 256, 120, 60, 0.8),
+    ("rosen1_d8_murray", O.VL_ROSENBROCK1, 8, 100, 120, 60, 0.7),
+]
+
+
+@pytest.mark.parametrize("name,kind,d,n,nburn,nsamp,pl", CASES, ids=[c[0] for c in CASES])
+def test_run_bit_exact(name, kind, d, n, nburn, nsamp, pl):
+    params = None
+    pinit = None
+    if kind == O.VL_DUALGAUSS:
+        params = [5.0]
+        pinit = np.array([0, 0, 2, 2, 0, 1.5, 0, -2], np.float32)  # src/mcpar-dgauss.cc:33
+    if kind == O.VL_GAUSSIAN:
+        params = np.concatenate([np.linspace(-1, 1, d), np.linspace(0.5, 2, d)]).astype(np.float32)
+    eo, eg = run_pair(kind, d, n, nburn, nsamp, pl, params=params, pinit=pinit)
+    assert_same(eo, eg, name)
+
+
+def test_mixture_c5_shape():
+    d, K = 32, 8
+    eo, eg = run_pair(O.VL_GAUSSMIX, d, 128, 120, 40, 0.8, params=mix_params(d, K), ncomp=K)
+    assert_same(eo, eg, "mix")
+
+
+def test_unfused_equals_fused():
+    eo, eg = run_pair(O.VL_ROSENBROCK1, 16, 300, 120, 40, 0.9, fuse=0)
+    assert_same(eo, eg, "unfused")
+
+
+def test_short_segments():
+    eo, eg = run_pair(O.VL_ROSENBROCK1, 8, 300, 120, 40, 1.0, maxseg=7)
+    assert_same(eo, eg, "maxseg7")
+
+
+def test_host_callback_vlfunc():
+    eo, eg = run_pair(O.VL_ROSENBROCK1, 8, 64, 60, 20, 0.8, host=True)
+    assert_same(eo, eg, "host")
+
+
+def test_rosenbrock2_as_written_unfused():
+    eo, eg = run_pair(O.VL_ROSENBROCK2, 4, 32, 60, 10, 1.0)
+    assert_same(eo, eg, "rosen2")
+
+
+def test_full_covariance():
+    d = 8
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(d, d)).astype(np.float32)
+    cov = (a @ a.T / d + 0.5 * np.eye(d)).astype(np.float32)
+    eo, eg = run_pair(O.VL_ROSENBROCK1, d, 200, 120, 40, 0.9, incov=cov)
+    assert_same(eo, eg, "fullcov")
+    # and d = 16 with 4 lanes per chain
+    d = 16
+    a = rng.normal(size=(d, d)).astype(np.float32)
+    cov = (a @ a.T / d + 0.5 * np.eye(d)).astype(np.float32)
+    eo, eg = run_pair(O.VL_ROSENBROCK1, d, 100, 60, 30, 1.0, incov=cov)
+    assert_same(eo, eg, "fullcov16")
+
+
+def test_second_run_continues_rng():
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    d, n = 8, 64
+    p = O.default_pinit(d, n)
+    vo, _k = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    vg, _k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eo, eg = O.Engine(d, n, pl=1.0), M.Engine(d, n, pl=1.0)
+    eg.set_option(E.OPT_ACCEPT_MASK, 1)
+    for _ in range(2):
+        eo.run(20, 60, p, vo)
+        eg.run(20, 60, p, vg)
+    assert_same(eo, eg, "second run")
