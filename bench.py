@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- chain-steps/sec of the MI355X-native Metropolis-Hastings engine on BASELINE.json's
+metric config: 16-D Rosenbrock (Rosenbrock1(16): SURVEY fact 4), 65 536 chains per GPU, the R-local
+job shape of SURVEY §8d (pl = 1.0, nburn = 500, nsamp = 1000, default tuner constants, seed 8675309,
+pinit[g][i] = 0.5 sin(0.37 (g d + i))), every (chain, step) sample retained in HBM like the
+reference's MCout.
+
+A bench "step" is ONE complete MCPar::run-shaped job (burn-in with tuner + main loop with sample
+emission + the inter-shard exchange every SYNCSTEP steps when N > 1) = n * (nburn + nsamp)
+chain-steps per GPU.  Chains shard across GPUs (weak scaling: 65 536 chains per GPU).
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md chip table
+
+
+def alg_bytes_per_chain_step(d, main, emit):
+    """state round trip 2*4*(3d+1) main / 2*4*(d+1) burn-in, + 4(d+1) per kept sample"""
+    b = 8 * (3 * d + 1) if main else 8 * (d + 1)
+    return b + (4 * (d + 1) if (main and emit) else 0)
+
+
+def pinit_for(d, n, g0):
+    import numpy as np
+    g = np.arange(g0, g0 + n, dtype=np.float64)[:, None]
+    i = np.arange(d, dtype=np.float64)[None, :]
+    return (0.5 * np.sin(0.37 * (g * d + i))).astype(np.float32)
+
+
+class CudaArrayView:
+    """zero-copy torch view of engine-owned device memory (for the RCCL exchange)"""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = dict(shape=(nfloats,), typestr="<f4", data=(int(ptr), False),
+                                             version=2, strides=None)
+
+
+def cpu_baseline(d, n, nburn, nsamp, pl):
+    """The CPU oracle (a port of the reference algorithm, oracle/mcx_oracle.c) on this box's host
+    cores, on a bounded sample of the same workload.  Reported beside the GPU number; never part
+    of the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    vl, _keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    p = pinit_for(d, n, 0)
+    e = O.Engine(d, n, pl=pl, threads=cores)
+    e.set_record(samples=True, mask=False)
+    t0 = time.perf_counter()
+    e.run(nsamp, nburn, p, vl)
+    dt = time.perf_counter() - t0
+    e.close()
+    return dict(value=n * (nburn + nsamp) / dt, unit="chain-steps/s", cores=cores, kind="port",
+                sample="%d chains x %d-D Rosenbrock1, %d burn-in + %d main steps, samples kept in host "
+                       "memory, OpenMP over chains (%.1f s)" % (n, d, nburn, nsamp, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--dim", type=int, default=16)
+    ap.add_argument("--nburn", type=int, default=500)
+    ap.add_argument("--nsamp", type=int, default=1000)
+    ap.add_argument("--pl", type=float, default=1.0)
+    ap.add_argument("--no-samples", action="store_true", help="summary-only mode (not the default metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # noqa: F811  (before libmcx so that both use one HIP runtime)
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import numpy as np
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    nsh = world
+    M.load().mcx_set_device(local_rank)
+    d, n, nburn, nsamp = args.dim, args.chains, args.nburn, args.nsamp
+    emit = not args.no_samples
+    eng = M.Engine(d, n, nshards=nsh, shard=rank, pl=args.pl)
+    eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
+    vl, _keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    p = pinit_for(d, n, rank * n)
+
+    state = {}
+    if world > 1:
+        # engine kernels and the RCCL all-gather are ordered through torch's current stream
+        stream = torch.cuda.current_stream()
+        eng.set_option(E.OPT_STREAM, stream.cuda_stream)
+
+        def exchange(phase, ptr, slot, shard, nshards, st):
+            if phase == E.XCHG_BEGIN:
+                if "all" not in state:
+                    state["all"] = torch.as_tensor(CudaArrayView(ptr, slot * nshards), device="cuda")
+                    state["own"] = state["all"][shard * slot:(shard + 1) * slot]
+                state["work"] = dist.all_gather_into_tensor(state["all"], state["own"], async_op=True)
+            else:
+                w = state.pop("work", None)
+                if w is not None:
+                    w.wait()
+            return 0
+        eng.set_exchange(exchange)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.run(nsamp, nburn, p, vl)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run(nsamp, nburn, p, vl)  # synchronous: returns after the stream has drained
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    cnt = eng.counters
+    chain_steps = float(world) * n * (nburn + nsamp) * args.steps
+    value = chain_steps / dt
+
+    # ---- roofline of the dominant kernel (fused main-loop steps), HIP events on the engine stream
+    roofline = None
+    cpu = None
+    if rank == 0:
+        eng.set_option(E.OPT_PROFILE, 1)
+        _ = eng.profile  # clear
+        base = eng.profile
+        eng.run(nsamp, nburn, p, vl)
+        pr = eng.profile
+        eng.set_option(E.OPT_PROFILE, 0)
+        fm = {k: pr["fused_main"][k] - base["fused_main"][k] for k in ("ms", "launches", "chain_steps")}
+        fb = {k: pr["fused_burn"][k] - base["fused_burn"][k] for k in ("ms", "launches", "chain_steps")}
+        if fm["launches"] > 0 and fm["ms"] > 0:
+            bpc = alg_bytes_per_chain_step(d, True, emit)
+            achieved = fm["chain_steps"] * bpc / (fm["ms"] * 1e-3)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("k_fused_steps_main_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = dict(bound="hbm", kernel="k_fused_steps<LPC=%d,ROSEN1,MAIN>" % max(1, (d + 3) // 4),
+                            achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                            frac=achieved / HBM_PEAK, traffic=traffic,
+                            alg_bytes_per_chain_step=bpc,
+                            avg_launch_ms=fm["ms"] / fm["launches"], launches=fm["launches"],
+                            chain_steps_per_launch=fm["chain_steps"] / fm["launches"],
+                            burn_kernel=dict(alg_bytes_per_chain_step=alg_bytes_per_chain_step(d, False, False),
+                                             avg_launch_ms=fb["ms"] / max(fb["launches"], 1),
+                                             achieved=(fb["chain_steps"] * alg_bytes_per_chain_step(d, False, False)
+                                                       / max(fb["ms"] * 1e-3, 1e-12)) / 1e9))
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(d, n, 500, 500, args.pl)
+
+    if rank == 0:
+        out = {
+            "metric": "chain-steps/sec (all chains), 16-D Rosenbrock",
+            "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "mcpar-rosen2 (C3): Rosenbrock1(%d) x %d chains/GPU, R-local job "
+                                   "(pl=%.2f, nburn=%d, nsamp=%d, sync=10), one bench step = one full run()"
+                                   % (d, n, args.pl, nburn, nsamp),
+                       "chains_per_gpu": n, "nparam": d, "nburn": nburn, "nsamp": nsamp,
+                       "samples": "all kept in HBM" if emit else "none (summary only)",
+                       "parallelism": "chains sharded x%d, RCCL all-gather of (mu, sig^2) every 10 steps" % world
+                       if world > 1 else "single GPU",
+                       "accept_rate_main": cnt["naccept_main"] / float(n * nsamp),
+                       "exchanges_per_run": cnt["exchanges"], "kernel_launches_per_run": cnt["kernel_launches"]},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

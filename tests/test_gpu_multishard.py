@@ -1,0 +1,87 @@
+"""N > 1 product path on ONE GPU: several engines (one per shard) run concurrently in threads and
+exchange their musigall slots through the exchange hook (device-to-device copies standing in for
+the RCCL all-gather); results must equal the oracle's in-process multi-shard run bit for bit."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10):
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipDeviceSynchronize.argtypes = []
+    engs = [M.Engine(d, n, nshards=nshards, shard=s, pl=pl, sync=sync) for s in range(nshards)]
+    vl, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    ptrs = [None] * nshards
+    bar = threading.Barrier(nshards)
+    errs = []
+
+    def make_hook(s):
+        def hook(phase, ptr, slot, shard, ns, stream):
+            if phase != E.XCHG_BEGIN:
+                return 0
+            ptrs[s] = ptr
+            hip.hipDeviceSynchronize()   # every shard's slot is published
+            bar.wait(timeout=60)
+            for r in range(ns):          # pull every peer's slot (all-gather, in place)
+                if r != s:
+                    off = r * slot * 4
+                    rc = hip.hipMemcpy(ptr + off, ptrs[r] + off, slot * 4, 3)
+                    assert rc == 0
+            hip.hipDeviceSynchronize()
+            bar.wait(timeout=60)
+            return 0
+        return hook
+
+    def work(s):
+        try:
+            engs[s].set_option(E.OPT_ACCEPT_MASK, 1)
+            engs[s].set_exchange(make_hook(s))
+            engs[s].run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+            bar.abort()
+
+    th = [threading.Thread(target=work, args=(s,)) for s in range(nshards)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    return engs
+
+
+@pytest.mark.parametrize("nshards,pl", [(2, 0.7), (3, 0.8), (2, 1.0)])
+def test_multishard_equals_oracle(nshards, pl):
+    d, n, nburn, nsamp = 16, 96, 120, 60
+    vo, keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl) for s in range(nshards)]
+    O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl)
+    for s in range(nshards):
+        eo, eg = eos[s], egs[s]
+        assert np.array_equal(eg.accept_mask, eo.accept_mask), "shard %d" % s
+        c = eg.counters
+        assert c["remote_steps"] == eo.remote_steps and c["remote_passes"] == eo.remote_passes
+        assert c["exchanges"] == nsamp // 10
+        for name in ("state", "mean", "var", "samples"):
+            assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
+        if pl < 1.0:
+            assert c["remote_steps"] > 0
+        # own slot is current, peers' slots are as of the last exchange (src/mcpar.cc:127-140,205-208)
+        assert np.array_equal(eg.musigall.view(np.uint32), eo.musigall.view(np.uint32))
+
+
+def test_missing_exchange_hook_is_an_error():
+    import mcpar_amd as M
+    e = M.Engine(4, 8, nshards=2, shard=0)
+    vl, keep = M.make_vlfunc(M.VL_ROSENBROCK1, 4)
+    with pytest.raises(M.McxError) as ei:
+        e.run(5, 5, np.zeros((8, 4), np.float32), vl)
+    assert ei.value.code == 6

@@ -1,0 +1,69 @@
+"""Device arithmetic primitives vs the oracle: bit-exact on dense random and edge inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_map(fn, words):
+    return np.array([fn(int(w)) for w in words])
+
+
+def test_philox_word_stream():
+    import mcpar_amd as M
+    w = np.random.default_rng(0).integers(0, 2 ** 32, 5000, dtype=np.uint64).astype(np.uint32)
+    got = M.debug_numerics(6, w)
+    exp = np.array([O.philox([int(x), 0, 0, 0], [0, 0])[0] for x in w], np.uint32)
+    assert np.array_equal(got, exp)
+
+
+def test_log_exp_sincos_uniform_bits():
+    import mcpar_amd as M
+    L = O.lib()
+    rng = np.random.default_rng(1)
+    # logf on (0,1] values produced exactly like the sampler does, plus arbitrary positive normals
+    w = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32)
+    u = np.array([L.mcxo_uopen(int(x)) for x in w], np.float32)
+    assert np.array_equal(M.debug_numerics(5, w), u.view(np.uint32))
+    xs = np.concatenate([u, rng.uniform(1e-30, 1e30, 2000).astype(np.float32),
+                         np.float32(2.0) ** np.arange(-120, 120, dtype=np.float32)]).astype(np.float32)
+    exp = np.array([L.mcxo_logf(float(x)) for x in xs], np.float32)
+    assert np.array_equal(M.debug_numerics(0, xs.view(np.uint32)), exp.view(np.uint32))
+    # expf incl. clamps, +-0, NaN, inf
+    xe = np.concatenate([rng.uniform(-100, 95, 20000), [0.0, -0.0, 88.72283, 88.7229, -87.33654, -87.3366,
+                                                        np.inf, -np.inf, np.nan, 1e-30, -1e-30]]).astype(np.float32)
+    exp = np.array([L.mcxo_expf(float(x)) for x in xe], np.float32)
+    got = M.debug_numerics(1, xe.view(np.uint32)).view(np.float32)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
+    # sincos on random words and every quadrant boundary
+    ww = np.concatenate([w, np.array([0, 1, 0x1fffffff, 0x20000000, 0x20000001, 0x3fffffff, 0x40000000,
+                                      0x5fffffff, 0x60000000, 0x7fffffff, 0x80000000, 0x9fffffff, 0xa0000000,
+                                      0xbfffffff, 0xc0000000, 0xdfffffff, 0xe0000000, 0xffffffff], np.uint32)])
+    s, c = C.c_float(), C.c_float()
+    es, ec = [], []
+    for x in ww:
+        L.mcxo_sincos2pi(int(x), C.byref(s), C.byref(c))
+        es.append(s.value)
+        ec.append(c.value)
+    assert np.array_equal(M.debug_numerics(2, ww), np.array(es, np.float32).view(np.uint32))
+    assert np.array_equal(M.debug_numerics(3, ww), np.array(ec, np.float32).view(np.uint32))
+    assert np.array_equal(M.debug_numerics(4, ww), np.array([L.mcxo_u24(int(x)) for x in ww], np.float32).view(np.uint32))
+
+
+def test_normals_bit_exact_all_streams():
+    import mcpar_amd as M
+    L = O.lib()
+    z = np.zeros(4, np.float32)
+    for stream, t, g0, a, q in ((0, 0, 0, 0, 0), (0, 1234, 65536 * 7, 3, 0), (4, 99, 17, 250, 7)):
+        got = M.debug_normals(8675309, stream, t, g0, a, q, 3000)
+        exp = np.empty((3000, 4), np.float32)
+        for i in range(3000):
+            L.mcxo_normal4(8675309, stream, t, g0 + i, a, q, O.fptr(z))
+            exp[i] = z
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))

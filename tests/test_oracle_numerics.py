@@ -1,0 +1,79 @@
+"""The oracle's arithmetic primitives: published known answers and accuracy against float64."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as O
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_log_exp_sincos_accuracy():
+    L = O.lib()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.random(4000), 2.0 ** -np.arange(1, 34)]).astype(np.float32)
+    for x in xs:
+        ref = np.log(np.float64(x))
+        assert abs(L.mcxo_logf(float(x)) - ref) <= 2e-7 * max(1.0, abs(ref))
+    assert L.mcxo_logf(1.0) == 0.0
+    for x in rng.uniform(-87, 88, 4000).astype(np.float32):
+        ref = np.exp(np.float64(x))
+        assert abs(L.mcxo_expf(float(x)) - ref) <= 3e-7 * ref
+    assert L.mcxo_expf(0.0) == 1.0
+    assert L.mcxo_expf(-100.0) == 0.0 and L.mcxo_expf(89.0) == float("inf")
+    assert np.isnan(L.mcxo_expf(float("nan")))
+    s, c = C.c_float(), C.c_float()
+    for w in rng.integers(0, 2 ** 32, 4000, dtype=np.uint64):
+        L.mcxo_sincos2pi(int(w), C.byref(s), C.byref(c))
+        a = 2 * np.pi * int(w) / 2 ** 32
+        assert abs(s.value - np.sin(a)) < 3e-7 and abs(c.value - np.cos(a)) < 3e-7
+
+
+def test_exp_is_monotone_on_a_dense_sample():
+    L = O.lib()
+    xs = np.sort(np.random.default_rng(1).uniform(-87.3, 5, 20000).astype(np.float32))
+    ys = np.array([L.mcxo_expf(float(x)) for x in xs])
+    assert np.all(np.diff(ys) >= 0)
+
+
+def test_uniform_ranges():
+    L = O.lib()
+    assert L.mcxo_u24(0) == 0.0 and L.mcxo_u24(0xffffffff) < 1.0
+    assert L.mcxo_uopen(0) > 0.0 and L.mcxo_uopen(0xffffffff) == 1.0
+
+
+def test_normals_are_standard():
+    L = O.lib()
+    z = np.zeros(4, np.float32)
+    out = []
+    for g in range(20000):
+        L.mcxo_normal4(8675309, 0, 3, g, 1, 0, O.fptr(z))
+        out.append(z.copy())
+    out = np.asarray(out, np.float64)
+    assert np.all(np.abs(out.mean(0)) < 0.03)
+    assert np.all(np.abs(out.var(0) - 1) < 0.04)
+    assert np.all(np.abs(np.corrcoef(out.T) - np.eye(4)) < 0.03)
+    flat = out.ravel()
+    assert abs(((flat - flat.mean()) ** 4).mean() / flat.var() ** 2 - 3.0) < 0.1
+
+
+def test_cholesky_identity_and_spd():
+    L = O.lib()
+    a = np.eye(5, dtype=np.float32)
+    assert L.mcxo_cholesky(5, O.fptr(a)) == 0
+    assert np.array_equal(a, np.eye(5, dtype=np.float32))  # default covar_setup -> identity
+    rng = np.random.default_rng(2)
+    m = rng.normal(size=(6, 6))
+    spd = (m @ m.T + 6 * np.eye(6)).astype(np.float32)
+    f = spd.copy()
+    assert L.mcxo_cholesky(6, O.fptr(f)) == 0
+    np.testing.assert_allclose(f @ f.T, spd, rtol=2e-5, atol=2e-5)
+    assert np.all(np.triu(f, 1) == 0)
+    bad = -np.eye(3, dtype=np.float32)
+    assert L.mcxo_cholesky(3, O.fptr(bad)) != 0

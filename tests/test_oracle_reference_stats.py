@@ -1,0 +1,53 @@
+"""Statistical parity of the oracle's step loop with the compiled reference.
+
+The reference ships no tests and mcpar.cc cannot be rebuilt here (needs MKL headers the image
+lacks), so the only reference-side numbers for the step loop are the accept rates the survey
+measured from the unmodified reference (BASELINE.md, table "Measured in the survey container").
+The RNG differs by design (Philox vs MT2203), so the comparison is statistical.
+"""
+import numpy as np
+
+import oracle_lib as O
+
+
+def main_accept_rate(e, nburn):
+    """BASELINE.md's definition: fraction of (step >= 1, chain) pairs of the main loop whose row changed"""
+    return float(e.accept_mask[nburn + 1:].mean())
+
+
+def run(d, n, nburn, nsamp, pl, threads=8):
+    vl, keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    e = O.Engine(d, n, pl=pl, threads=threads)
+    e.set_record(samples=False, mask=True)
+    e.run(nsamp, nburn, O.default_pinit(d, n), vl)
+    return e
+
+
+def test_rosenbrock1_8d_4096_chains():
+    e = run(8, 4096, 200, 50, 1.0)  # 0.470
+    assert abs(main_accept_rate(e, 200) - 0.470) < 0.015
+    assert list(np.round(e.tuner_trace, 6)) == [0.2, 0.04, 0.04]
+
+
+def test_rosenbrock1_16d_65536_chains():
+    e = run(16, 65536, 100, 20, 1.0)  # 0.0468 (tuner fires once, at isamp = 51)
+    assert abs(main_accept_rate(e, 100) - 0.0468) < 0.003
+    assert len(e.tuner_trace) == 1 and abs(e.tuner_trace[0] - 0.2) < 1e-7
+
+
+def test_rosenbrock1_16d_murray():
+    e = run(16, 1024, 500, 100, 0.9)  # 0.291, 29 genRemote passes
+    assert abs(main_accept_rate(e, 500) - 0.291) < 0.02
+    assert 5 <= e.remote_steps <= 20 and 10 <= e.remote_passes <= 90
+
+
+def test_target_moments_rosenbrock_2d():
+    """long run on the 2-D Rosenbrock density: chains must sample the right distribution
+    (E[x0] = 1, Var[x0] = 1/2 for exp(-(1-x)^2 - 100 (y-x^2)^2))"""
+    vl, keep = O.make_vlfunc(O.VL_ROSENBROCK1, 2)
+    e = O.Engine(2, 512, pl=1.0, threads=8)
+    e.set_record(samples=True, mask=False)
+    e.run(3000, 500, O.default_pinit(2, 512), vl)
+    s = e.samples.reshape(3000, 512, 3)[1000:, :, 0]
+    assert abs(s.mean() - 1.0) < 0.1
+    assert abs(s.var() - 0.5) < 0.1
