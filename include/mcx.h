@@ -163,6 +163,11 @@ typedef struct mcx_profile {
 } mcx_profile;
 int mcx_get_profile(mcx_engine *e, mcx_profile *p);
 
+/* ---- helpers for exchange / output hooks written in a host language ------------------------ */
+/* copies ordered after the work queued on `stream` (NULL = the default stream); both block until done */
+int mcx_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int mcx_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 const char *mcx_last_error(void);
 int mcx_abi_version(void);

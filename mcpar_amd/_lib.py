@@ -73,6 +73,8 @@ def load():
         "mcx_samples_copy": [vp, C.c_int, C.c_int, fp],
         "mcx_samples_maxlike": [vp, fp, fp],
         "mcx_get_profile": [vp, C.POINTER(Profile)],
+        "mcx_copy_to_host": [vp, vp, C.c_size_t, vp],
+        "mcx_copy_to_device": [vp, vp, C.c_size_t, vp],
         "mcx_abi_version": [],
         "mcx_device_info": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
         "mcx_set_device": [C.c_int],

@@ -970,6 +970,24 @@ extern "C" int mcx_get_profile(mcx_engine *e, mcx_profile *p)
   return MCX_OK;
 }
 
+extern "C" int mcx_copy_to_host(void *dst_host, const void *src_dev, size_t bytes, void *stream)
+{
+  if (!dst_host || !src_dev) return fail(MCX_ERR_INVALID, "bad arguments");
+  MCXCHK(need_device());
+  HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return MCX_OK;
+}
+
+extern "C" int mcx_copy_to_device(void *dst_dev, const void *src_host, size_t bytes, void *stream)
+{
+  if (!dst_dev || !src_host) return fail(MCX_ERR_INVALID, "bad arguments");
+  MCXCHK(need_device());
+  HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return MCX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // numerics test hooks
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,103 @@
+// mcpar-run -- the BASELINE configurations as a first-class driver (the reference reaches them
+// only through its library API: SURVEY fact 3).
+//   mcpar-run [--func rosen1|rosen2|gauss|dgauss|mix] [--np D] [--nc CHAINS] [--nsamp N]
+//             [--nburn B] [--pl P] [--sync S] [--ncomp K] [--quiet] [--iter]
+// Output: the reference's row format (src/mcout.cc:41-45); --iter prepends the iteration index
+// that src/anly/mcpar-analysis.R:80-120 reconstructs; --quiet prints only the summary (stderr).
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mcpar/mcout.hh"
+#include "mcpar/mcpar.hh"
+#include "mcpar/rosenbrock.hh"
+
+int main(int argc, char *argv[])
+{
+  std::string func = "rosen1";
+  int np = 16, nc = 4096, nsamp = 100, nburn = 500, sync = 10, ncomp = 8;
+  float pl = 1.0f;
+  bool quiet = false, iter = false;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : "0"; };
+    if (a == "--func") func = val();
+    else if (a == "--np") np = atoi(val());
+    else if (a == "--nc") nc = atoi(val());
+    else if (a == "--nsamp") nsamp = atoi(val());
+    else if (a == "--nburn") nburn = atoi(val());
+    else if (a == "--pl") pl = (float)atof(val());
+    else if (a == "--sync") sync = atoi(val());
+    else if (a == "--ncomp") ncomp = atoi(val());
+    else if (a == "--quiet") quiet = true;
+    else if (a == "--iter") iter = true;
+    else { std::cerr << "unknown option " << a << "\n"; return 2; }
+  }
+  MPI_Init(&argc, &argv);
+  int size, rank;
+  MPI_Comm_size(MPI_COMM_WORLD, &size);
+  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+
+  VLFunc *L = 0;
+  std::vector<float> means, w;
+  try {
+    if (func == "rosen1") L = new Rosenbrock1(np);
+    else if (func == "rosen2") L = new Rosenbrock2(np);
+    else if (func == "gauss") L = new Gaussian(np);
+    else if (func == "dgauss") { np = 2; L = new DualGaussian(5.0f); }
+    else if (func == "mix") {  // means 5k/(K-1) * 1, weights (5,1,...,1)
+      means.resize((size_t)ncomp * np);
+      w.assign(ncomp, 1.0f);
+      w[0] = 5.0f;
+      for (int k = 0; k < ncomp; ++k)
+        for (int i = 0; i < np; ++i) means[(size_t)k * np + i] = 5.0f * k / (ncomp > 1 ? ncomp - 1 : 1);
+      L = new GaussianMixture(np, ncomp, means.data(), w.data());
+    } else { std::cerr << "unknown --func " << func << "\n"; return 2; }
+  } catch (const char *msg) {
+    std::cerr << msg << "\n";
+    return 2;
+  }
+
+  std::ostringstream sink;
+  MCout rslts(np, (quiet || iter) ? static_cast<std::ostream *>(&sink) : &std::cout, MPI_COMM_WORLD);
+  std::vector<float> pinit((size_t)nc * np);
+  for (int j = 0; j < nc; ++j)
+    for (int i = 0; i < np; ++i)
+      pinit[(size_t)j * np + i] = (float)(0.5 * std::sin(0.37 * ((double)(rank * nc + j) * np + i)));
+  try {
+    MCPar mcpar(np, nc, size, rank, pl, 0.2f, 0.5f, 0.2f, 1.5f, sync);
+    auto t0 = std::chrono::steady_clock::now();
+    mcpar.run(nsamp, nburn, pinit.data(), *L, rslts);
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (iter && !quiet)
+      for (int r = 0; r < rslts.size(); ++r) {
+        std::cout << r / nc << "  ";
+        const float *p = rslts.getpset(r);
+        for (int j = 0; j < np + 1; ++j) std::cout << p[j] << "  ";
+        std::cout << "\n";
+      }
+    if (rank == 0)
+      std::cerr << "chains " << nc << " x np " << np << "  burn " << nburn << " + samples " << nsamp
+                << ": accept rate (main) " << (double)mcpar.naccept_main() / ((double)nc * nsamp)
+                << ", remote passes " << mcpar.remote_passes() << ", " << (double)nc * (nburn + nsamp) / dt
+                << " chain-steps/s incl. output\n";
+  } catch (const char *msg) {
+    std::cerr << msg << "\n";
+    return 2;
+  }
+  float lmax;
+  const std::vector<float> &pmax = rslts.maxlike(&lmax);
+  if (rank == 0) {
+    std::cerr << "max likelihood value: " << lmax << "\n";
+    for (size_t i = 0; i < pmax.size() && i < 8; ++i) std::cerr << pmax[i] << "  ";
+    std::cerr << "\n";
+  }
+  delete L;
+  MPI_Finalize();
+  return 0;
+}

@@ -369,6 +369,7 @@ mcxo_engine *mcxo_create(int np, int nc, int nshards, int shard, float pl, float
   e->take = zalloc(n);
   e->cov = zalloc(4 * (size_t)e->ncov);
   e->acounts = zalloc(4 * n);
+  for (int i = 0; i < np; ++i) e->cov[i * (np + 1)] = 1.0f; /* identity until covar_setup */
   e->keep_samples = 1; e->keep_mask = 1; e->nthreads = 1;
   return e;
 }

@@ -1,0 +1,93 @@
+"""The reference-shaped C++ surface (include/mcpar/*.hh, libmcpar.so) and the demo drivers:
+same command lines, same stdout/file formats as the reference drivers, values equal
+to the oracle's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRV = os.path.join(ROOT, "mcpar_amd", "drivers")
+
+
+def fmt_rows(rows):
+    """MCout::output: every field followed by two spaces, ostream default (%g, 6 digits)"""
+    return "".join("".join("%g  " % v for v in r) + "\n" for r in rows)
+
+
+def build_drivers():
+    subprocess.check_call(["make", "-C", DRV], stdout=subprocess.DEVNULL)
+
+
+def test_mcpar_dgauss_driver_output(tmp_path):
+    build_drivers()
+    r = subprocess.run([os.path.join(DRV, "mcpar-dgauss")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    vl, keep = O.make_vlfunc(O.VL_DUALGAUSS, 2, [5.0])
+    e = O.Engine(2, 4)  # MCPar(nparam, 4, size, rank) defaults, src/mcpar-dgauss.cc:31
+    e.run(8, 500, np.array([0, 0, 2, 2, 0, 1.5, 0, -2], np.float32), vl)
+    s = e.samples
+    best = int(np.argmax(s[:, 2]))
+    assert np.all(s[best, 2] >= s[:, 2])
+    expect = fmt_rows(s) + "max likelihood value: %g\n" % s[best, 2] + "%g  %g  \n" % (s[best, 0], s[best, 1])
+    assert r.stdout == expect
+    assert len(r.stdout.splitlines()) == 34  # 32 sample rows + 2
+    # per-rank parameter file: tab separated, trailing tab (src/mcpar-dgauss.cc:38-47)
+    txt = (tmp_path / "mcpar-dgauss.000.txt").read_text()
+    assert txt == "".join("%g\t%g\t\n" % (a, b) for a, b in s[:, :2])
+    log = (tmp_path / "mcpar-log.000.txt").read_text()
+    assert log.startswith("Starting burn-in.  Samples = 500\nStarting main sample loop:  nsamp = 8\n"
+                          "Output after each 5 steps.\nBeginning output at step 5\nOutput finished\n")
+
+
+def test_mcpar_rosen1_driver_output(tmp_path):
+    build_drivers()
+    r = subprocess.run([os.path.join(DRV, "mcpar-rosen1"), "120"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    vl, keep = O.make_vlfunc(O.VL_ROSENBROCK1, 2)
+    e = O.Engine(2, 4)
+    e.run(120, 500, np.array([0, 0, 2, 2, 0, 1.5, 0, -2], np.float32), vl)
+    assert r.stdout == "nsamp = 120\n" + fmt_rows(e.samples)
+    log = (tmp_path / "mcpar-log.000.txt").read_text()
+    assert log.count("Beginning output at step") == 9 and "Output after each 12 steps." in log
+
+
+def test_cpp_api_builtin_and_user_vlfunc(tmp_path):
+    build_drivers()
+    exe = str(tmp_path / "facade_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-mfma", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_check.cc"), "-o", exe,
+                           "-L", os.path.join(ROOT, "mcpar_amd"), "-lmcpar", "-lmcx",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mcpar_amd")])
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a, b, tail = r.stdout.split("=====\n")
+    assert a == b  # a user VLFunc subclass (host callback) reproduces the fused device run bit for bit
+    np_, nc, nsamp, nburn = 8, 48, 60, 120
+    vl, keep = O.make_vlfunc(O.VL_ROSENBROCK1, np_)
+    e = O.Engine(np_, nc, pl=0.8)
+    e.run(nsamp, nburn, O.default_pinit(np_, nc), vl)
+    s = e.samples
+    best = int(np.argmax(s[:, np_]))
+    expect = fmt_rows(s) + "size %d maxsize %d ncol %d maxlike %g p0 %g accepts %d\n" % (
+        nc * nsamp, nc * nsamp, np_ + 1, s[best, np_], s[best, 0], e.naccept_main)
+    assert a == expect
+    # VLFunc is called once before burn-in and once per step (src/mcpar.cc:53,60,160)
+    assert "user calls %d" % (1 + nburn + nsamp) in tail
+    assert "guard: N for Rosenbrock1 must be even and >= 2" in tail
+    assert "r2 0 -1" in tail
+
+
+def test_mcpar_run_driver_flags(tmp_path):
+    build_drivers()
+    r = subprocess.run([os.path.join(DRV, "mcpar-run"), "--func", "mix", "--np", "32", "--nc", "256", "--nsamp", "40",
+                        "--nburn", "60", "--pl", "0.85", "--quiet"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "" and "accept rate (main)" in r.stderr and "max likelihood value" in r.stderr
+    r = subprocess.run([os.path.join(DRV, "mcpar-run"), "--func", "rosen1", "--np", "3"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "must be even" in r.stderr

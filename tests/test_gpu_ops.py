@@ -54,4 +54,4 @@ def test_gen_remote(d, n, nshards):
     assert npg == npo and npo >= 1
     for a, b, name in ((pg, po, "ptrial"), (cg, co, "cfac"), (mg, mo, "mutrial"), (sg, so, "sigtrial")):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
-    assert np.all(cg > 0)
+    assert np.all(np.isfinite(cg)) and np.all(cg >= 0)  # 0 when every Q_i underflows at pvals
