@@ -86,7 +86,7 @@ int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_v
 
 /* MCPar::genLocal(pvals, ptrial, cfac)  src/mcpar.hh:40, src/mcpar.cc:302-312.  t is the RNG
  * step index; host buffers [nc*np], [nc*np], [nc].  Uses the engine's current
- * Cholesky factor (mcx_set_chol / last run). */
+ * Cholesky factor (mcx_covar_setup / last run). */
 int mcx_gen_local(mcx_engine *e, uint32_t t, const float *pvals, float *ptrial, float *cfac);
 /* MCPar::genRemote(pvals, musigall, ptrial, cfac)  src/mcpar.hh:41-42, src/mcpar.cc:315-451.
  * musigall[nshards*nc*np*2] interleaved (mu, sig^2).  mutrial/sigtrial[nc*np] are the side

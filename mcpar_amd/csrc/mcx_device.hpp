@@ -55,7 +55,7 @@ struct Lik<LIK_ROSEN1, LPC> {  // src/rosenbrock.cc:4-21
       const float t2 = __builtin_fmaf(-xb[2], xb[2], xb[3]);
       acc = acc + __builtin_fmaf(100.0f * t2, t2, t1 * t1);
     }
-    return -group_sum<LPC>(acc);
+    return 0.0f - group_sum<LPC>(acc);  // 0 - s like the reference's fx = 0; fx -= ...: never -0
   }
 };
 
@@ -79,7 +79,7 @@ struct Lik<LIK_GAUSS, LPC> {  // src/rosenbrock.cc:44-61; lik = mu[d], s2inv[d]
         const float a = xb[k] - mu[k];
         acc = __builtin_fmaf((0.5f * a) * a, si[k], acc);
       }
-    return -group_sum<LPC>(acc);
+    return 0.0f - group_sum<LPC>(acc);  // 0 - s like the reference's fx = 0; fx -= ...: never -0
   }
 };
 
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_rosen2(const float *__restrict__
       const float t2 = __builtin_fmaf(-x[i], x[i], x[i + 1]);
       acc = acc + __builtin_fmaf(-(100.0f * t2), t2, t1 * t1);
     }
-  y[j] = -acc;
+  y[j] = 0.0f - acc;
 }
 
 template <int LPC, bool MAIN>

@@ -205,7 +205,7 @@ static float rosen1_one(int d, const float *x)
     }
     part[q] = acc;
   }
-  return -butterfly_sum(part, nb);
+  return 0.0f - butterfly_sum(part, nb); /* 0 - s like the reference's fx = 0; fx -= ...: never -0 */
 }
 
 /* src/rosenbrock.cc:44-61, any d (reference throws unless d == 2: src/rosenbrock.hh:43) */
@@ -221,7 +221,7 @@ static float gauss_one(int d, const float *x, const float *mu, const float *s2in
     }
     part[q] = acc;
   }
-  return -butterfly_sum(part, nb);
+  return 0.0f - butterfly_sum(part, nb); /* 0 - s like the reference's fx = 0; fx -= ...: never -0 */
 }
 
 /* log sum_k w_k exp(-|x-m_k|^2/2), evaluated as a log-sum-exp.  d=2,K=2,m={0,5},w={w,1}
@@ -275,7 +275,7 @@ int mcxo_vlfunc_eval(const mcxo_vlfunc *f, int npset, const float *x, float *y)
           acc = acc + term;
         }
       }
-      y[j] = -acc;
+      y[j] = 0.0f - acc;
     }
     return 0;
   }

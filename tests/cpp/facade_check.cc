@@ -43,7 +43,7 @@ public:
         for (int q = 0; q < p2; ++q) nxt[q] = part[q] + part[q ^ s];
         for (int q = 0; q < p2; ++q) part[q] = nxt[q];
       }
-      fx[j] = -part[0];
+      fx[j] = 0.0f - part[0];
     }
     return 0;
   }
