@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--pl", type=float, default=1.0)
     ap.add_argument("--no-samples", action="store_true", help="summary-only mode (not the default metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,8 +96,13 @@ def main():
     if world > 1:
         import torch  # noqa: F811  (before libmcx so that both use one HIP runtime)
         import torch.distributed as dist  # noqa: F811
+        if args.one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     import numpy as np
     import mcpar_amd as M
     from mcpar_amd import engine as E
@@ -151,16 +158,37 @@ def main():
     chain_steps = float(world) * n * (nburn + nsamp) * args.steps
     value = chain_steps / dt
 
+    # N > 1: the same job with the reference's own exchange schedule (an all-gather at every sync
+    # point, overlapped with compute) next to the default, which gathers only the snapshots a Murray
+    # step or the end of the run will read (bit-identical results; tests/test_gpu_multishard.py)
+    eager = None
+    if world > 1:
+        eng.set_option(E.OPT_EAGER_EXCHANGE, 1)
+        eng.run(nsamp, nburn, p, vl)
+        sync()
+        t1 = time.perf_counter()
+        ke = max(1, args.steps // 2)
+        for _ in range(ke):
+            eng.run(nsamp, nburn, p, vl)
+        sync()
+        de = time.perf_counter() - t1
+        te = torch.tensor([de], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        eager = dict(value=float(world) * n * (nburn + nsamp) * ke / float(te.item()), unit="chain-steps/s",
+                     steps=ke, exchanges_per_run=eng.counters["exchanges"])
+        eng.set_option(E.OPT_EAGER_EXCHANGE, 0)
+
     # ---- roofline of the dominant kernel (fused main-loop steps), HIP events on the engine stream
     roofline = None
     cpu = None
+    # every rank runs the profiled job (it contains the same collectives); rank 0 reports
+    eng.set_option(E.OPT_PROFILE, 1)
+    base = eng.profile
+    eng.run(nsamp, nburn, p, vl)
+    pr = eng.profile
+    eng.set_option(E.OPT_PROFILE, 0)
+    sync()
     if rank == 0:
-        eng.set_option(E.OPT_PROFILE, 1)
-        _ = eng.profile  # clear
-        base = eng.profile
-        eng.run(nsamp, nburn, p, vl)
-        pr = eng.profile
-        eng.set_option(E.OPT_PROFILE, 0)
         fm = {k: pr["fused_main"][k] - base["fused_main"][k] for k in ("ms", "launches", "chain_steps")}
         fb = {k: pr["fused_burn"][k] - base["fused_burn"][k] for k in ("ms", "launches", "chain_steps")}
         if fm["launches"] > 0 and fm["ms"] > 0:
@@ -197,8 +225,9 @@ def main():
                                    % (d, n, args.pl, nburn, nsamp),
                        "chains_per_gpu": n, "nparam": d, "nburn": nburn, "nsamp": nsamp,
                        "samples": "all kept in HBM" if emit else "none (summary only)",
-                       "parallelism": "chains sharded x%d, RCCL all-gather of (mu, sig^2) every 10 steps" % world
-                       if world > 1 else "single GPU",
+                       "parallelism": "chains sharded x%d, RCCL all-gather of the (mu, sig^2) snapshots that a Murray "
+                                      "step or the end of the run reads" % world if world > 1 else "single GPU",
+                       "eager_exchange": eager,
                        "accept_rate_main": cnt["naccept_main"] / float(n * nsamp),
                        "exchanges_per_run": cnt["exchanges"], "kernel_launches_per_run": cnt["kernel_launches"]},
             "roofline": roofline, "cpu_baseline": cpu,

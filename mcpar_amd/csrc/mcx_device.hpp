@@ -239,6 +239,9 @@ struct SegArgs {
   uint32_t g0, t0, seed;
   int isamp0;
   int diag, vec4;
+  const float *winv;  // winv[i] = 1/(i+1), i = main-loop step index (host-computed, correctly rounded)
+  float *musig_own;   // this shard's musigall slot, written after local step snap_after (or never: -1)
+  int snap_after;
 };
 
 template <int LPC, int LIK, bool MAIN>
@@ -298,6 +301,12 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
       const float pwgt = (float)(a.isamp0 + s + 1);  // src/mcpar.cc:186-187
       winv = 1.0f / pwgt;
       welford_block(x, mu, ps, winv);
+      if (s == a.snap_after) {  // the (mu, sig^2) this shard ships at the next exchange (src/mcpar.cc:202-208)
+        float sg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg[k] = ps[k] * winv;
+        store_pairs(a.musig_own, chain, d, k0, nv, vec4, mu, sg);
+      }
       if (a.samp_x) {  // src/mcpar.cc:177-182
         store_block(a.samp_x, (size_t)s * a.n + chain, d, k0, nv, vec4, x);
         if (q == 0) a.samp_ly[(size_t)s * a.n + chain] = ly;
@@ -313,6 +322,124 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
   if (MAIN) {
     store_block(a.mu, chain, d, k0, nv, vec4, mu);
     store_block(a.psum2, chain, d, k0, nv, vec4, ps);
+  }
+  if ((threadIdx.x & 63u) == 0 && wacc) atomicAdd(a.acc_total, (unsigned long long)wacc);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Hot-path specialisation of k_fused_steps: Rosenbrock1, diagonal Cholesky factor (identity
+// covariance under any tuner history), d % 4 == 0, no accept-mask recording.  Same arithmetic as the
+// generic kernel, restructured for gfx950's issue limits:
+//   * the lane's four parameters are held as two packed pairs E = (x0, x2), O = (x1, x3); Box-Muller,
+//     the proposal, the Rosenbrock terms and the Welford update run on v_pk_{fma,mul,add}_f32;
+//   * the lane-group reductions are DPP row operations instead of LDS-crossbar shuffles;
+//   * 1/pwgt comes from a host-built table through a scalar load instead of a VALU division.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// same pairing as the xor-butterfly of group_sum: after the quad steps every lane of a quad holds
+// the quad's sum, so the mirror steps add the other quad's / other half's sum (addition commutes)
+template <int LPC>
+__device__ __forceinline__ float group_sum_dpp(float p)
+{
+  if (LPC >= 2) p = p + dpp_mov<0xB1>(p);   // quad_perm [1,0,3,2]  == xor 1
+  if (LPC >= 4) p = p + dpp_mov<0x4E>(p);   // quad_perm [2,3,0,1]  == xor 2
+  if (LPC >= 8) p = p + dpp_mov<0x141>(p);  // row_half_mirror      ~  xor 4
+  if (LPC >= 16) p = p + dpp_mov<0x140>(p); // row_mirror           ~  xor 8
+  return p;
+}
+
+template <int LPC, bool MAIN>
+__global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
+{
+  const int d = a.d;
+  const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t chain = gid / LPC;
+  const int q = (int)(gid % LPC);
+  if (chain >= (size_t)a.n) return;
+  const int k0 = 4 * q;
+  const bool live = k0 < d;  // d % 4 == 0: a lane owns 4 parameters or none (d = 12, 20, ...)
+  const uint32_t g = a.g0 + (uint32_t)chain;
+  const size_t off = chain * (size_t)d + k0;
+
+  f32x2 xe = {0, 0}, xo = {0, 0}, me = {0, 0}, mo = {0, 0}, se = {0, 0}, so = {0, 0}, te = {0, 0}, to = {0, 0};
+  if (live) {
+    const float4 f = *reinterpret_cast<const float4 *>(a.x + off);
+    xe = f32x2{f.x, f.z}; xo = f32x2{f.y, f.w};
+    te = f32x2{a.T[(k0 + 0) * d + k0 + 0], a.T[(k0 + 2) * d + k0 + 2]};
+    to = f32x2{a.T[(k0 + 1) * d + k0 + 1], a.T[(k0 + 3) * d + k0 + 3]};
+    if (MAIN) {
+      const float4 m = *reinterpret_cast<const float4 *>(a.mu + off);
+      const float4 p = *reinterpret_cast<const float4 *>(a.psum2 + off);
+      me = f32x2{m.x, m.z}; mo = f32x2{m.y, m.w};
+      se = f32x2{p.x, p.z}; so = f32x2{p.y, p.w};
+    }
+  }
+  float ly = a.ly[chain];
+  uint32_t cnt = 0, wacc = 0;
+  u32x4 aw = {0, 0, 0, 0};
+  uint32_t ablk = 0xffffffffu;
+  float *sx = a.samp_x ? a.samp_x + off : nullptr;
+  float *sl = a.samp_x ? a.samp_ly + chain : nullptr;
+  const size_t sx_stride = (size_t)a.n * d, sl_stride = (size_t)a.n;
+
+  for (int s = 0; s < a.nsteps; ++s) {
+    const uint32_t t = a.t0 + (uint32_t)s;
+    f32x2 ze, zo;
+    normal4_packed(philox4x32_10(t, g, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
+    const f32x2 pe = fma2(te, ze, xe), po = fma2(to, zo, xo);  // src/mcpar.cc:302-312
+    // src/rosenbrock.cc:4-21 on the pairs (x0,x1), (x2,x3)
+    const f32x2 t1 = splat2(1.0f) - pe;
+    const f32x2 t2 = fma2(-pe, pe, po);
+    const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
+    float acc = 0.0f;
+    if (live) acc = (0.0f + term.x) + term.y;
+    const float lyt = 0.0f - group_sum_dpp<LPC>(acc);
+    if ((t >> 2) != ablk) {
+      ablk = t >> 2;
+      aw = philox4x32_10(ablk, g, 0u, 0u, a.seed, ST_ACCEPT);
+    }
+    const bool take = accept_decision(lyt, ly, 1.0f, pick_word(aw, t & 3u));  // src/mcpar.cc:62-75
+    xe = take ? pe : xe;
+    xo = take ? po : xo;
+    ly = take ? lyt : ly;
+    cnt += take ? 1u : 0u;
+    wacc += (uint32_t)__popcll(__ballot(take && q == 0));
+    if (MAIN) {
+      const f32x2 w2 = splat2(a.winv[a.isamp0 + s]);  // src/mcpar.cc:186-187
+      const f32x2 de = xe - me, dO = xo - mo;         // src/mcpar.cc:199-202
+      me = fma2(de, w2, me);
+      mo = fma2(dO, w2, mo);
+      se = fma2(de, xe - me, se);
+      so = fma2(dO, xo - mo, so);
+      if (s == a.snap_after && live) {  // snapshot for the next exchange (src/mcpar.cc:202-208)
+        const f32x2 ve = se * w2, vo = so * w2;
+        float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
+        slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
+        slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
+      }
+      if (sx) {  // src/mcpar.cc:177-182
+        if (live) *reinterpret_cast<float4 *>(sx) = make_float4(xe.x, xo.x, xe.y, xo.y);
+        if (q == 0) *sl = ly;
+        sx += sx_stride;
+        sl += sl_stride;
+      }
+    }
+  }
+
+  if (live) *reinterpret_cast<float4 *>(a.x + off) = make_float4(xe.x, xo.x, xe.y, xo.y);
+  if (q == 0) {
+    a.ly[chain] = ly;
+    a.acc_cnt[chain] += cnt;
+  }
+  if (MAIN && live) {
+    *reinterpret_cast<float4 *>(a.mu + off) = make_float4(me.x, mo.x, me.y, mo.y);
+    *reinterpret_cast<float4 *>(a.psum2 + off) = make_float4(se.x, so.x, se.y, so.y);
   }
   if ((threadIdx.x & 63u) == 0 && wacc) atomicAdd(a.acc_total, (unsigned long long)wacc);
 }

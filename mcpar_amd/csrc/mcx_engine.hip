@@ -244,6 +244,12 @@ template <int LPC>
 static int launch_fused(int lik, bool main, const SegArgs &a, hipStream_t st)
 {
   const dim3 grid(nblocks((size_t)a.n * LPC)), block(BLOCK);
+  if (lik == LIK_ROSEN1 && a.diag && a.vec4 && !a.mask) {  // hot path
+    if (main) hipLaunchKernelGGL((k_fused_fast_rosen1<LPC, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_fused_fast_rosen1<LPC, false>), grid, block, 0, st, a);
+    HIPCHK(hipGetLastError());
+    return MCX_OK;
+  }
 #define LF(LK)                                                                       \
   if (main) hipLaunchKernelGGL((k_fused_steps<LPC, LK, true>), grid, block, 0, st, a); \
   else hipLaunchKernelGGL((k_fused_steps<LPC, LK, false>), grid, block, 0, st, a);
@@ -312,14 +318,14 @@ struct mcx_engine {
   DevBuf<uint32_t> acc_cnt;
   DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
   DevBuf<int> active0, active1, nact, ntrace;
-  DevBuf<float> samp_x, samp_ly;
+  DevBuf<float> samp_x, samp_ly, winv_tab;
   DevBuf<uint8_t> mask;
   // host staging
   std::vector<float> h_ptrial, h_lytrial;
   // run bookkeeping
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0;
+  int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0;
   int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
   bool have_run = false, diag = true, xchg_pending = false;
   int published_steps = 0;  // main-loop steps reflected in this shard's musigall slot
@@ -431,7 +437,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->lylast.release(); e->lytrial.release(); e->cfac.release(); e->cmax.release(); e->cov.release();
   e->trace.release(); e->acc_cnt.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
-  e->samp_ly.release(); e->mask.release(); e->lik.params.release();
+  e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release();
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MCX_OK;
@@ -465,6 +471,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
     e->opt_maxseg = (int)std::min<int64_t>(value, 1 << 20);
     break;
   case MCX_OPT_PROFILE: e->opt_profile = value ? 1 : 0; break;
+  case MCX_OPT_EAGER_EXCHANGE: e->opt_eager = value ? 1 : 0; break;
   case MCX_OPT_STREAM:
     if (e->own_stream && e->stream) {
       (void)hipStreamSynchronize(e->stream);
@@ -659,6 +666,13 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     MCXCHK(e->mask.alloc((size_t)(nburn + nsamp) * n));
     HIPCHK(hipMemsetAsync(e->mask.p, 0, (size_t)(nburn + nsamp) * n, st));
   }
+  if (nsamp > 0) {  // 1/pwgt for every main-loop step (src/mcpar.cc:186-187), correctly rounded on the host
+    std::vector<float> wt((size_t)nsamp);
+    for (int i = 0; i < nsamp; ++i) wt[(size_t)i] = 1.0f / (float)(i + 1);
+    MCXCHK(e->winv_tab.alloc((size_t)nsamp));
+    HIPCHK(hipMemcpyAsync(e->winv_tab.p, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
   e->cnt = mcx_counters{};
   e->published_steps = 0;
   HIPCHK(hipMemsetAsync(e->ctr.p, 0, 8 * sizeof(unsigned long long), st));
@@ -674,6 +688,9 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   sa.x = e->pvals.p; sa.ly = e->lylast.p; sa.mu = e->mu.p; sa.psum2 = e->psum2.p;
   sa.acc_cnt = e->acc_cnt.p; sa.T = e->cov.p; sa.lik = e->lik.params.p; sa.ncomp = e->lik.ncomp;
   sa.n = n; sa.d = d; sa.g0 = g0; sa.seed = e->seed; sa.diag = e->diag ? 1 : 0; sa.vec4 = e->vec4;
+  sa.winv = e->winv_tab.p;
+  sa.musig_own = e->musigall.p + 2 * (size_t)e->rank * e->ntot;
+  sa.snap_after = -1;
 
   // ---- burn-in (src/mcpar.cc:55-97) ----
   int irate = 50;
@@ -717,6 +734,14 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     HIPCHK(hipGetLastError());
   }
   const int outstep = nsamp > 50 ? nsamp / 10 : 5;  // :110
+  // Exchange schedule.  The reference gathers at every sync point (isamp % SYNCSTEP == 0, :127-140),
+  // but the gathered slots are read only by genRemote, and every gather overwrites all of them: a
+  // gather that is followed by another gather before the next Murray step is dead.  Default (lazy):
+  // snapshot this shard's slot at every sync point, gather the latest snapshot right before a Murray
+  // step reads it (and once at the end) -- bit-identical results, fused segments may span sync points.
+  // MCX_OPT_EAGER_EXCHANGE = 1 issues the reference's schedule (overlapped with the next segment).
+  const bool sharded = e->size > 1, eager = e->opt_eager != 0;
+  bool need_gather = false;
   for (int isamp = 0; isamp < nsamp;) {
     const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
     if (isamp % outstep == 0 && isamp > 0 && e->ofn) {  // :115-119
@@ -724,13 +749,18 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       e->samp_steps = isamp;
       if (e->ofn(e->octx, isamp) != 0) return fail(MCX_ERR_INVALID, "output hook failed");
     }
-    if (isamp % e->SYNCSTEP == 0 && e->size > 1) {  // :127-140
+    if (sharded && isamp % e->SYNCSTEP == 0) {  // :127-140
       MCXCHK(publish(e, isamp));
-      MCXCHK(exchange_begin(e));
+      if (eager) MCXCHK(exchange_begin(e));
+      else need_gather = true;
     }
     if (step_is_remote(e, isamp, t)) {  // :152-159
-      MCXCHK(publish(e, isamp));
+      if (need_gather) {  // slot holds the snapshot of the last sync point
+        MCXCHK(exchange_begin(e));
+        need_gather = false;
+      }
       MCXCHK(exchange_wait(e));
+      MCXCHK(publish(e, isamp));  // own slot is always current (:205-208)
       int npass = 0;
       MCXCHK(remote_device(e, t, e->pvals.p, e->musigall.p, e->ptrial.p, e->cfac.p, e->mutrial.p,
                            e->sigtrial.p, &npass));
@@ -743,12 +773,13 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       ++isamp;
       continue;
     }
-    // run of local steps up to the next output / exchange / remote step
+    // run of local steps up to the next output dump / Murray step (/ sync point when eager or unfused)
+    const bool span_sync = fused && sharded && !eager;
     int steps = 1;
     while (isamp + steps < nsamp && steps < e->opt_maxseg) {
       const int nx = isamp + steps;
       if (nx % outstep == 0 && e->ofn) break;
-      if (nx % e->SYNCSTEP == 0 && e->size > 1) break;
+      if (sharded && !span_sync && nx % e->SYNCSTEP == 0) break;
       if (step_is_remote(e, nx, t + (uint32_t)steps)) break;
       ++steps;
     }
@@ -758,6 +789,16 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       sa.samp_ly = e->opt_samples ? e->samp_ly.p + (size_t)isamp * n : nullptr;
       sa.mask = e->opt_mask ? e->mask.p + (size_t)(nburn + isamp) * n : nullptr;
       sa.nsteps = steps; sa.t0 = t; sa.isamp0 = isamp;
+      sa.snap_after = -1;
+      if (span_sync) {  // last sync point strictly inside the segment
+        const int last = ((isamp + steps - 1) / e->SYNCSTEP) * e->SYNCSTEP;
+        if (last > isamp) {
+          MCXCHK(exchange_wait(e));
+          sa.snap_after = last - 1 - isamp;
+          e->published_steps = last;
+          need_gather = true;
+        }
+      }
       ProfScope ps(e, MCX_K_FUSED_MAIN, (uint64_t)steps * n);
       DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, true, sa, st))));
     } else {
@@ -771,8 +812,9 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     }
     isamp += steps;
   }
-  MCXCHK(publish(e, nsamp));
+  if (need_gather) MCXCHK(exchange_begin(e));  // remote slots end as of the last sync point, like the reference's
   MCXCHK(exchange_wait(e));
+  MCXCHK(publish(e, nsamp));
   e->cnt.nsteps_main = (uint64_t)nsamp;
   e->pwgt_last = (float)nsamp;
   if (nsamp > 0) {

@@ -138,6 +138,75 @@ MCX_HD void normal4_from_words(const u32x4 &w, float z[4])
   z[3] = r * s;
 }
 
+// ---- packed (2-wide) forms for gfx950's v_pk_*_f32: the same operations in the same order on two
+// independent values, hence the same bits as the scalar forms above -------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
+__device__ __forceinline__ f32x2 logf_v1x2(f32x2 x)
+{
+  const uint32_t bx = as_u32(x.x), by = as_u32(x.y);
+  int ex = (int)((bx >> 23) & 0xffu) - 126, ey = (int)((by >> 23) & 0xffu) - 126;
+  f32x2 m = {as_f32((bx & 0x007fffffu) | 0x3f000000u), as_f32((by & 0x007fffffu) | 0x3f000000u)};
+  const bool lx = m.x < 0.70710678f, ly = m.y < 0.70710678f;
+  ex = lx ? ex - 1 : ex;
+  ey = ly ? ey - 1 : ey;
+  const f32x2 t = {lx ? m.x + m.x : m.x, ly ? m.y + m.y : m.y};
+  m = t - splat2(1.0f);
+  const f32x2 fe = {(float)ex, (float)ey};
+  const f32x2 z = m * m;
+  f32x2 p = splat2(7.0376836292e-2f);
+  p = fma2(p, m, splat2(-1.1514610310e-1f));
+  p = fma2(p, m, splat2(1.1676998740e-1f));
+  p = fma2(p, m, splat2(-1.2420140846e-1f));
+  p = fma2(p, m, splat2(1.4249322787e-1f));
+  p = fma2(p, m, splat2(-1.6668057665e-1f));
+  p = fma2(p, m, splat2(2.0000714765e-1f));
+  p = fma2(p, m, splat2(-2.4999993993e-1f));
+  p = fma2(p, m, splat2(3.3333331174e-1f));
+  f32x2 y = (p * m) * z;
+  y = fma2(splat2(-2.12194440e-4f), fe, y);
+  y = fma2(splat2(-0.5f), z, y);
+  f32x2 r = m + y;
+  r = fma2(splat2(0.693359375f), fe, r);
+  return r;
+}
+
+__device__ __forceinline__ void sincos2pi_v1x2(uint32_t wa, uint32_t wb, f32x2 &s, f32x2 &c)
+{
+  const uint32_t ka = ((wa + 0x20000000u) >> 30) & 3u, kb = ((wb + 0x20000000u) >> 30) & 3u;
+  const int32_t ra = (int32_t)(wa - (ka << 30)), rb = (int32_t)(wb - (kb << 30));
+  const f32x2 phi = f32x2{(float)ra, (float)rb} * splat2(1.4629180792671596e-9f);
+  const f32x2 z = phi * phi;
+  f32x2 ps = splat2(-1.9515295891e-4f);
+  ps = fma2(ps, z, splat2(8.3321608736e-3f));
+  ps = fma2(ps, z, splat2(-1.6666654611e-1f));
+  const f32x2 sp = fma2(phi * z, ps, phi);
+  f32x2 pc = splat2(2.443315711809948e-5f);
+  pc = fma2(pc, z, splat2(-1.388731625493765e-3f));
+  pc = fma2(pc, z, splat2(4.166664568298827e-2f));
+  const f32x2 cp = fma2(z * z, pc, fma2(splat2(-0.5f), z, splat2(1.0f)));
+  const bool swa = (ka & 1u) != 0u, swb = (kb & 1u) != 0u;
+  const f32x2 sv = {swa ? cp.x : sp.x, swb ? cp.y : sp.y};
+  const f32x2 cv = {swa ? sp.x : cp.x, swb ? sp.y : cp.y};
+  s = f32x2{ka >= 2u ? -sv.x : sv.x, kb >= 2u ? -sv.y : sv.y};
+  c = f32x2{(ka == 1u || ka == 2u) ? -cv.x : cv.x, (kb == 1u || kb == 2u) ? -cv.y : cv.y};
+}
+
+// Box-Muller on one Philox block, both pairs at once.  ze = (z0, z2), zo = (z1, z3)
+__device__ __forceinline__ void normal4_packed(const u32x4 &w, f32x2 &ze, f32x2 &zo)
+{
+  const f32x2 u = fma2(f32x2{(float)w.x, (float)w.z}, splat2(0x1p-32f), splat2(0x1p-33f));
+  const f32x2 a = splat2(-2.0f) * logf_v1x2(u);
+  const f32x2 r = {__builtin_sqrtf(a.x), __builtin_sqrtf(a.y)};
+  f32x2 s, c;
+  sincos2pi_v1x2(w.y, w.w, s, c);
+  ze = r * c;
+  zo = r * s;
+}
+
 MCX_HD uint32_t pick_word(const u32x4 &w, uint32_t i)
 {
   return i == 0u ? w.x : (i == 1u ? w.y : (i == 2u ? w.z : w.w));

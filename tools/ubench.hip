@@ -1,0 +1,93 @@
+// ubench.hip -- VALU issue-cost microbenchmark for gfx950 (build: hipcc --offload-arch=gfx950 -O2).
+// Each kernel runs ITER iterations of 8 independent chains of one instruction per lane; grid fills
+// the chip with W waves per SIMD.  Prints ns per wave-instruction per SIMD and the ratio to v_fma_f32.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define ITER 4096
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+#define KERNEL(name, decl, body, fin_stmt)                                                   \
+  __global__ void name(unsigned *out, unsigned seed)                               \
+  {                                                                                \
+    decl;                                                                          \
+    for (int i = 0; i < ITER; ++i) { body; }                                       \
+    fin_stmt;                                                                      \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = fin;                              \
+  }
+
+#define R8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
+
+#define DF(k) float a##k = seed * 1e-9f + k + threadIdx.x;
+#define DU(k) unsigned a##k = seed + k * 77 + threadIdx.x;
+#define DL(k) unsigned long long a##k = seed + k * 77 + threadIdx.x;
+#define DP(k) float a##k = seed * 1e-9f + k + threadIdx.x, b##k = a##k + 0.5f;
+#define FINF unsigned fin = __float_as_uint(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7)
+#define FINU unsigned fin = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7
+#define FINL unsigned fin = (unsigned)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7)
+#define FINP unsigned fin = __float_as_uint(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7)
+
+#define OP_FMA(k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a##k));
+#define OP_XOR(k) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a##k) : "v"(seed));
+#define OP_MULLO(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a##k) : "v"(seed));
+#define OP_MULHI(k) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a##k) : "v"(seed));
+#define OP_MAD64(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(a##k) : "v"((unsigned)a##k), "v"(seed) : "vcc");
+#define OP_MUL24(k) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a##k) : "v"(seed));
+#define OP_SQRT(k) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a##k));
+#define OP_RCP(k) asm volatile("v_rcp_f32 %0, %0" : "+v"(a##k));
+#define OP_CVT(k) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a##k));
+#define OP_CND(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##k) : "v"(seed));
+#define OP_ADD(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a##k) : "v"(seed));
+#define OP_DPP(k) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a##k));
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define DV(k) f2 a##k = {seed * 1e-9f + k + threadIdx.x, 0.5f + k};
+#define FINV unsigned fin = __float_as_uint(a0.x + a1.x + a2.x + a3.x + a4.y + a5.y + a6.y + a7.y)
+#define OP_PKFMA(k) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(a##k));
+#define OP_PKMUL(k) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(a##k));
+
+KERNEL(k_fma, R8(DF), R8(OP_FMA), FINF)
+KERNEL(k_xor, R8(DU), R8(OP_XOR), FINU)
+KERNEL(k_mul_lo_u32, R8(DU), R8(OP_MULLO), FINU)
+KERNEL(k_mul_hi_u32, R8(DU), R8(OP_MULHI), FINU)
+KERNEL(k_mad_u64_u32, R8(DL), R8(OP_MAD64), FINL)
+KERNEL(k_mul_u32_u24, R8(DU), R8(OP_MUL24), FINU)
+KERNEL(k_sqrt, R8(DF), R8(OP_SQRT), FINF)
+KERNEL(k_rcp, R8(DF), R8(OP_RCP), FINF)
+KERNEL(k_cvt_f32_u32, R8(DU), R8(OP_CVT), FINU)
+KERNEL(k_cndmask, R8(DU), R8(OP_CND), FINU)
+KERNEL(k_add_u32, R8(DU), R8(OP_ADD), FINU)
+KERNEL(k_add_f32_dpp, R8(DF), R8(OP_DPP), FINF)
+KERNEL(k_pk_fma, R8(DV), R8(OP_PKFMA), FINV)
+KERNEL(k_pk_mul, R8(DV), R8(OP_PKMUL), FINV)
+
+typedef void (*kfn)(unsigned *, unsigned);
+struct K { const char *name; kfn f; };
+int main()
+{
+  K ks[] = {{"fma", k_fma},{"xor", k_xor},{"mul_lo_u32", k_mul_lo_u32},{"mul_hi_u32", k_mul_hi_u32},{"mad_u64_u32", k_mad_u64_u32},{"mul_u32_u24", k_mul_u32_u24},{"sqrt", k_sqrt},{"rcp", k_rcp},{"cvt_f32_u32", k_cvt_f32_u32},{"cndmask", k_cndmask},{"add_u32", k_add_u32},{"add_f32_dpp", k_add_f32_dpp},{"pk_fma", k_pk_fma},{"pk_mul", k_pk_mul}};
+  hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
+  const int cus = p.multiProcessorCount;
+  unsigned *out; CHK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * 4));
+  hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+  for (int wps = 1; wps <= 8; wps *= 2) {
+    printf("== %d wave(s) per SIMD (%d CUs, clock %d MHz)\n", wps, cus, p.clockRate / 1000);
+    double base = 0;
+    for (auto &k : ks) {
+      const int blocks = cus * wps;  // 256 threads = 4 waves -> one per SIMD per block
+      hipLaunchKernelGGL(k.f, dim3(blocks), dim3(256), 0, 0, out, 12345u);
+      CHK(hipDeviceSynchronize());
+      float best = 1e30f;
+      for (int r = 0; r < 5; ++r) {
+        CHK(hipEventRecord(a)); hipLaunchKernelGGL(k.f, dim3(blocks), dim3(256), 0, 0, out, 12345u); CHK(hipEventRecord(b));
+        CHK(hipEventSynchronize(b)); float ms; CHK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+      }
+      const double ninst = (double)ITER * 8 * wps;  // wave-instructions per SIMD
+      const double ns = best * 1e6 / ninst;
+      if (base == 0) base = ns;
+      printf("  %-14s %7.3f ns/wave-instr/SIMD  = %5.2f x v_fma  (~%.1f cycles at 2.4 GHz)\n", k.name, ns, ns / base, ns * 2.4);
+    }
+  }
+  return 0;
+}
