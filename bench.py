@@ -58,7 +58,7 @@ def cpu_baseline(d, n, nburn, nsamp, pl):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cores = max(1, min(cores, 16))  # the GPU box's CPU share for one GPU is 16 cores
     vl, _keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
     p = pinit_for(d, n, 0)
     e = O.Engine(d, n, pl=pl, threads=cores)
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--pl", type=float, default=1.0)
     ap.add_argument("--no-samples", action="store_true", help="summary-only mode (not the default metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-segment", type=int, default=0, help="cap on steps per fused launch (0 = engine default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -115,6 +116,8 @@ def main():
     emit = not args.no_samples
     eng = M.Engine(d, n, nshards=nsh, shard=rank, pl=args.pl)
     eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
+    if args.max_segment > 0:
+        eng.set_option(E.OPT_MAX_SEGMENT, args.max_segment)
     vl, _keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     p = pinit_for(d, n, rank * n)
 

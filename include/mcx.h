@@ -178,8 +178,11 @@ int mcx_device_info(char *name, size_t namelen, int *cu_count, size_t *hbm_bytes
 int mcx_set_device(int device);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:
  * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
- * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0) */
+ * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf */
 int mcx_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out_bits);
+/* number of float bit patterns in [lo_bits, hi_bits) where the kernels' lean sqrt (valid for +-0 and
+ * positive normal floats) differs from IEEE sqrtf, and the smallest such pattern */
+int mcx_debug_sqrt_sweep(uint32_t lo_bits, uint32_t hi_bits, uint64_t *nbad, uint32_t *first_bad);
 /* normals of stream `stream`, counter (t, g0+i, a, q) for i < n: out[n*4] */
 int mcx_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uint32_t g0, uint32_t a,
                       uint32_t q, int n, float *out);

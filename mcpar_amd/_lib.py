@@ -80,6 +80,7 @@ def load():
         "mcx_set_device": [C.c_int],
         "mcx_debug_numerics": [C.c_int, C.c_int, u32p, u32p],
         "mcx_debug_normals": [C.c_uint32] * 6 + [C.c_int, fp],
+        "mcx_debug_sqrt_sweep": [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), u32p],
     }
     for name, args in sig.items():
         f = getattr(L, name)

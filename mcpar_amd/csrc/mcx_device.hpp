@@ -354,6 +354,31 @@ __device__ __forceinline__ float group_sum_dpp(float p)
   return p;
 }
 
+// value of lane `owner` of this lane's LPC-group (owner is wave-uniform), by DPP
+template <int LPC>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t owner, int q)
+{
+  if (LPC == 1) return v;
+  const int iv = (int)v;
+  int r = iv;
+  if (LPC == 2) {
+    r = (owner & 1u) ? __builtin_amdgcn_update_dpp(0, iv, 0xF5, 0xF, 0xF, true)   // quad_perm [1,1,3,3]
+                     : __builtin_amdgcn_update_dpp(0, iv, 0xA0, 0xF, 0xF, true);  // quad_perm [0,0,2,2]
+    return (uint32_t)r;
+  }
+  switch (owner & 3u) {
+  case 0: r = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xF, 0xF, true); break;
+  case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, true); break;
+  case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, true); break;
+  default: r = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, true); break;
+  }
+  if (LPC >= 8) {  // the owner's quad holds the value; the other quad of the 8-lane group mirrors it in
+    const int other = __builtin_amdgcn_update_dpp(0, r, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    r = ((int)(owner >> 2) == (q >> 2)) ? r : other;
+  }
+  return (uint32_t)r;
+}
+
 template <int LPC, bool MAIN>
 __global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
 {
@@ -398,13 +423,17 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
     const f32x2 t2 = fma2(-pe, pe, po);
     const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
     float acc = 0.0f;
-    if (live) acc = (0.0f + term.x) + term.y;
+    if (live) acc = term.x + term.y;  // == (0 + term.x) + term.y: the terms are >= +0
     const float lyt = 0.0f - group_sum_dpp<LPC>(acc);
-    if ((t >> 2) != ablk) {
-      ablk = t >> 2;
-      aw = philox4x32_10(ablk, g, 0u, 0u, a.seed, ST_ACCEPT);
+    // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
+    // lanes of a chain split the work: lane q draws block b for b % LPC == q, once per 4*LPC steps.
+    const uint32_t blk = t >> 2;
+    if ((blk & ~(uint32_t)(LPC - 1)) != ablk) {
+      ablk = blk & ~(uint32_t)(LPC - 1);
+      aw = philox4x32_10(ablk + (uint32_t)q, g, 0u, 0u, a.seed, ST_ACCEPT);
     }
-    const bool take = accept_decision(lyt, ly, 1.0f, pick_word(aw, t & 3u));  // src/mcpar.cc:62-75
+    const uint32_t word = group_bcast<LPC>(pick_word(aw, t & 3u), blk & (uint32_t)(LPC - 1), q);
+    const bool take = accept_decision(lyt, ly, 1.0f, word);  // src/mcpar.cc:62-75
     xe = take ? pe : xe;
     xo = take ? po : xo;
     ly = take ? lyt : ly;
@@ -771,9 +800,26 @@ __global__ void k_debug_numerics(int what, int n, const uint32_t *in, uint32_t *
   case 4: r = as_u32(u24(w)); break;
   case 5: r = as_u32(uopen(w)); break;
   case 6: r = philox4x32_10(w, 0, 0, 0, 0, 0).x; break;
+  case 7: r = as_u32(sqrt_rn_pos(as_f32(w))); break;
+  case 8: r = as_u32(__builtin_sqrtf(as_f32(w))); break;
   default: break;
   }
   out[i] = r;
+}
+
+// counts bit patterns in [lo, hi) where sqrt_rn_pos differs from the compiler's IEEE sqrtf
+__global__ void k_debug_sqrt_sweep(uint32_t lo, uint32_t hi, unsigned long long *nbad, uint32_t *first_bad)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long bad = 0;
+  for (uint64_t w = (uint64_t)lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < hi; w += stride) {
+    const float x = as_f32((uint32_t)w);
+    if (as_u32(sqrt_rn_pos(x)) != as_u32(__builtin_sqrtf(x))) {
+      ++bad;
+      atomicMin(first_bad, (uint32_t)w);
+    }
+  }
+  if (bad) atomicAdd(nbad, bad);
 }
 
 __global__ void k_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uint32_t g0, uint32_t a,

@@ -1056,6 +1056,34 @@ extern "C" int mcx_debug_numerics(int what, int n, const uint32_t *in, uint32_t 
   return rc;
 }
 
+extern "C" int mcx_debug_sqrt_sweep(uint32_t lo_bits, uint32_t hi_bits, uint64_t *nbad, uint32_t *first_bad)
+{
+  if (!nbad || !first_bad || hi_bits < lo_bits) return fail(MCX_ERR_INVALID, "bad arguments");
+  MCXCHK(need_device());
+  DevBuf<unsigned long long> dn;
+  DevBuf<uint32_t> df;
+  MCXCHK(dn.alloc(1));
+  int rc = df.alloc(1);
+  if (rc == MCX_OK) {
+    auto run = [&]() -> int {
+      const uint32_t init = 0xffffffffu;
+      HIPCHK(hipMemset(dn.p, 0, sizeof(unsigned long long)));
+      HIPCHK(hipMemcpy(df.p, &init, 4, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_debug_sqrt_sweep, dim3(4096), dim3(BLOCK), 0, 0, lo_bits, hi_bits, dn.p, df.p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipDeviceSynchronize());
+      unsigned long long n = 0;
+      HIPCHK(hipMemcpy(&n, dn.p, sizeof n, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(first_bad, df.p, 4, hipMemcpyDeviceToHost));
+      *nbad = n;
+      return MCX_OK;
+    };
+    rc = run();
+  }
+  dn.release(); df.release();
+  return rc;
+}
+
 extern "C" int mcx_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uint32_t g0, uint32_t a,
                                  uint32_t q, int n, float *out)
 {

@@ -195,12 +195,27 @@ __device__ __forceinline__ void sincos2pi_v1x2(uint32_t wa, uint32_t wb, f32x2 &
   c = f32x2{(ka == 1u || ka == 2u) ? -cv.x : cv.x, (kb == 1u || kb == 2u) ? -cv.y : cv.y};
 }
 
+// Correctly rounded sqrt for x = +-0 or x >= 2^-96: the raw v_sqrt_f32 (<= 1 ulp) plus
+// the one-ulp-down / one-ulp-up residual test -- the sequence hipcc emits for IEEE sqrtf, minus its
+// denormal pre-scaling and its zero/inf class check, neither of which the Box-Muller argument
+// -2 ln(u), u in (0,1], can need (it is 0 or >= 1.19e-7).  Bit-identical to sqrtf on that domain (exhaustively checked:
+// tests/test_gpu_numerics.py::test_sqrt_rn_exhaustive).
+__device__ __forceinline__ float sqrt_rn_pos(float x)
+{
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = as_f32(as_u32(s) - 1u), su = as_f32(as_u32(s) + 1u);
+  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+  float r = (0.0f >= rd) ? sd : s;
+  r = (0.0f < ru) ? su : r;
+  return r;
+}
+
 // Box-Muller on one Philox block, both pairs at once.  ze = (z0, z2), zo = (z1, z3)
 __device__ __forceinline__ void normal4_packed(const u32x4 &w, f32x2 &ze, f32x2 &zo)
 {
   const f32x2 u = fma2(f32x2{(float)w.x, (float)w.z}, splat2(0x1p-32f), splat2(0x1p-33f));
   const f32x2 a = splat2(-2.0f) * logf_v1x2(u);
-  const f32x2 r = {__builtin_sqrtf(a.x), __builtin_sqrtf(a.y)};
+  const f32x2 r = {sqrt_rn_pos(a.x), sqrt_rn_pos(a.y)};
   f32x2 s, c;
   sincos2pi_v1x2(w.y, w.w, s, c);
   ze = r * c;

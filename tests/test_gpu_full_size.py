@@ -97,3 +97,17 @@ def test_murray_4096_chains_bit_exact():
     assert np.array_equal(eg.accept_mask, eo.accept_mask)
     for name in ("state", "mean", "var", "musigall"):
         assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
+
+
+def test_reference_accept_rates_at_full_size():
+    """BASELINE.md's measured reference accept rates (fraction of (step >= 1, chain) rows that changed),
+    same job shapes, on the GPU engine: 8-D x 4096 (200+50) -> 0.470; 16-D x 65 536 (100+20) -> 0.0468.
+    Statistical (the RNG differs from MKL's by design)."""
+    import mcpar_amd as M
+    for d, n, nburn, nsamp, ref, tol in ((8, 4096, 200, 50, 0.470, 0.015), (16, 65536, 100, 20, 0.0468, 0.003)):
+        vg, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+        eg = M.Engine(d, n, pl=1.0)
+        eg.run(nsamp, nburn, O.default_pinit(d, n), vg)
+        s = eg.samples.reshape(nsamp, n, d + 1)
+        changed = np.any(s[1:, :, :d] != s[:-1, :, :d], axis=2)
+        assert abs(changed.mean() - ref) < tol, (d, n, changed.mean())
