@@ -32,7 +32,7 @@ typedef enum mcx_status {
   MCX_ERR_INVALID = 1,     /* bad argument (the reference throws a string literal: src/mcpar.cc:268) */
   MCX_ERR_NO_DEVICE = 2,   /* no HIP device / not gfx950 */
   MCX_ERR_HIP = 3,         /* a HIP call failed (the reference abort()s on VSL errors: src/mcpar.hh:93) */
-  MCX_ERR_UNSUPPORTED = 4, /* e.g. np > 32 in this round */
+  MCX_ERR_UNSUPPORTED = 4, /* np > 256 */
   MCX_ERR_ALLOC = 5,       /* sample store does not fit (reference: exit(2), src/mcpar.cc:34-40) */
   MCX_ERR_EXCHANGE = 6,    /* exchange hook failed / missing (reference: MPI_Abort, src/mcpar.cc:133-137) */
   MCX_ERR_VLFUNC = 7       /* host likelihood callback missing */

@@ -20,7 +20,8 @@
 namespace mcx {
 
 constexpr int BLOCK = 256;  // 4 wavefronts per workgroup
-constexpr int MAXD_FUSED = 32;
+constexpr int MAXD_LDS = 32;  // full-covariance factor is staged in LDS up to this np, read from L2 above
+constexpr int MAXD = 256;     // lanes per chain <= 64
 
 enum LikKind : int { LIK_ROSEN1 = 1, LIK_ROSEN2 = 2, LIK_GAUSS = 3, LIK_MIX = 5 };
 
@@ -247,12 +248,14 @@ struct SegArgs {
 template <int LPC, int LIK, bool MAIN>
 __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
 {
-  __shared__ float Tl[MAXD_FUSED * MAXD_FUSED];
+  __shared__ float Tlds[MAXD_LDS * MAXD_LDS];
   const bool diag = a.diag != 0, vec4 = a.vec4 != 0;
   const int d = a.d;
-  if (!diag) {
-    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tl[i] = a.T[i];
+  const float *Tl = a.T;
+  if (!diag && d <= MAXD_LDS) {
+    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tlds[i] = a.T[i];
     __syncthreads();
+    Tl = Tlds;
   }
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t chain = gid / LPC;
@@ -497,12 +500,14 @@ struct StepArgs {
 template <int LPC>
 __global__ __launch_bounds__(BLOCK) void k_propose_local(const StepArgs a)
 {
-  __shared__ float Tl[MAXD_FUSED * MAXD_FUSED];
+  __shared__ float Tlds[MAXD_LDS * MAXD_LDS];
   const bool diag = a.diag != 0, vec4 = a.vec4 != 0;
   const int d = a.d;
-  if (!diag) {
-    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tl[i] = a.T[i];
+  const float *Tl = a.T;
+  if (!diag && d <= MAXD_LDS) {
+    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tlds[i] = a.T[i];
     __syncthreads();
+    Tl = Tlds;
   }
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t chain = gid / LPC;
@@ -770,6 +775,74 @@ __global__ __launch_bounds__(BLOCK) void k_remote_pass(const RemoteArgs a)
   }
   const float pacpt = qm / qs;  // src/mcpar.cc:397-398
   if (u24(w.y) < pacpt) {       // src/mcpar.cc:405-441
+    a.cfac[j] = a.cmax[j] / qm;
+  } else {
+    const int slot = atomicAdd(a.nact_out, 1);
+    a.active_out[slot] = j;
+  }
+}
+
+// np > 32: the chain vector does not fit the register budget; it is re-read from global memory
+// (L1/L2-resident).  Same arithmetic and order as the register kernels.
+__device__ __forceinline__ float q_arg_mem(const float *__restrict__ ms, const float *__restrict__ wv,
+                                           const float *__restrict__ x, int d)
+{
+  float arg = 0.0f;
+  for (int k = 0; k < d; ++k) {
+    const float xm = ms[2 * k] - x[k];
+    arg = __builtin_fmaf(xm * xm, wv[k], arg);
+  }
+  return arg;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_remote_cmax_big(const float *__restrict__ pvals,
+                                                           const float *__restrict__ musigall,
+                                                           const float *__restrict__ winv,
+                                                           float *__restrict__ cmax, int n, int d, int N)
+{
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const float *x = pvals + (size_t)j * d;
+  float cm = 0.0f;
+  for (int qi = 0; qi < N; ++qi) {
+    const float gv = expf_v1(-0.5f * q_arg_mem(musigall + 2 * (size_t)qi * d, winv + (size_t)qi * d, x, d));
+    cm = gv > cm ? gv : cm;
+  }
+  cmax[j] = cm;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteArgs a)
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.nact) return;
+  const int j = a.active_in ? a.active_in[i] : i;
+  const int d = a.d;
+  const uint32_t g = a.g0 + (uint32_t)j;
+  const u32x4 w = philox4x32_10(a.t, g, (uint32_t)a.pass, 0u, a.seed, ST_RSEL);
+  const int sel = (int)(((uint64_t)w.x * (uint64_t)a.N) >> 32);
+  float *x = a.ptrial + (size_t)j * d;
+  for (int qb = 0; 4 * qb < d; ++qb) {
+    float z[4];
+    normal4_from_words(philox4x32_10(a.t, g, (uint32_t)a.pass, (uint32_t)qb, a.seed, ST_RNORM), z);
+    for (int c = 0; c < 4; ++c) {
+      const int k = 4 * qb + c;
+      if (k < d) {
+        const float m = a.musigall[2 * ((size_t)sel * d + k)];
+        const float sg = __builtin_sqrtf(a.musigall[2 * ((size_t)sel * d + k) + 1]);
+        x[k] = __builtin_fmaf(sg, z[c], m);
+        a.mutrial[(size_t)j * d + k] = m;
+        a.sigtrial[(size_t)j * d + k] = sg;
+      }
+    }
+  }
+  float qs = FPEPS, qm = FPEPS;
+  for (int qi = 0; qi < a.N; ++qi) {
+    const float gv = expf_v1(-0.5f * q_arg_mem(a.musigall + 2 * (size_t)qi * d, a.winv + (size_t)qi * d, x, d));
+    qs = qs + gv;
+    qm = gv > qm ? gv : qm;
+  }
+  const float pacpt = qm / qs;
+  if (u24(w.y) < pacpt) {
     a.cfac[j] = a.cmax[j] / qm;
   } else {
     const int slot = atomicAdd(a.nact_out, 1);

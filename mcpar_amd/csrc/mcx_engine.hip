@@ -227,7 +227,10 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   case 2: { constexpr int LPC_ = 2; CALL; } break;                \
   case 4: { constexpr int LPC_ = 4; CALL; } break;                \
   case 8: { constexpr int LPC_ = 8; CALL; } break;                \
-  default: return fail(MCX_ERR_UNSUPPORTED, "np > 32 is not supported in this build"); \
+  case 16: { constexpr int LPC_ = 16; CALL; } break;              \
+  case 32: { constexpr int LPC_ = 32; CALL; } break;              \
+  case 64: { constexpr int LPC_ = 64; CALL; } break;              \
+  default: return fail(MCX_ERR_UNSUPPORTED, "np > 256 is not supported"); \
   }
 
 #define DISPATCH_DMAX(dm, CALL)                                   \
@@ -237,16 +240,17 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   case 8: { constexpr int DMAX_ = 8; CALL; } break;               \
   case 16: { constexpr int DMAX_ = 16; CALL; } break;             \
   case 32: { constexpr int DMAX_ = 32; CALL; } break;             \
-  default: return fail(MCX_ERR_UNSUPPORTED, "np > 32 is not supported in this build"); \
+  default: return fail(MCX_ERR_UNSUPPORTED, "internal: register Murray kernels cover np <= 32"); \
   }
 
 template <int LPC>
 static int launch_fused(int lik, bool main, const SegArgs &a, hipStream_t st)
 {
   const dim3 grid(nblocks((size_t)a.n * LPC)), block(BLOCK);
-  if (lik == LIK_ROSEN1 && a.diag && a.vec4 && !a.mask) {  // hot path
-    if (main) hipLaunchKernelGGL((k_fused_fast_rosen1<LPC, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_fused_fast_rosen1<LPC, false>), grid, block, 0, st, a);
+  if (LPC <= 8 && lik == LIK_ROSEN1 && a.diag && a.vec4 && !a.mask) {  // hot path
+    constexpr int FL = LPC <= 8 ? LPC : 8;  // (not instantiated above 8 lanes per chain)
+    if (main) hipLaunchKernelGGL((k_fused_fast_rosen1<FL, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_fused_fast_rosen1<FL, false>), grid, block, 0, st, a);
     HIPCHK(hipGetLastError());
     return MCX_OK;
   }
@@ -386,7 +390,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   if (np < 1 || nc < 1 || nshards < 1 || shard < 0 || shard >= nshards || sync < 1)
     return fail(MCX_ERR_INVALID, "bad problem size np=%d nc=%d nshards=%d shard=%d sync=%d", np, nc,
                 nshards, shard, sync);
-  if (np > MAXD_FUSED) return fail(MCX_ERR_UNSUPPORTED, "np = %d > %d is not supported in this build", np, MAXD_FUSED);
+  if (np > MAXD) return fail(MCX_ERR_UNSUPPORTED, "np = %d > %d is not supported", np, MAXD);
   if ((long long)nshards * nc > 0x7fffffffLL / (2LL * np))
     return fail(MCX_ERR_INVALID, "tchains*np*2 overflows int32 (the reference indexes musigall with int)");
   MCXCHK(need_device());
@@ -569,13 +573,18 @@ static int launch_accept(mcx_engine *e, const StepArgs &a, bool main)
 static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
                          float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
 {
-  const int n = e->nchain, d = e->nparam, N = e->tchains, dm = dmax_for(d);
+  const int n = e->nchain, d = e->nparam, N = e->tchains, dm = d <= 32 ? dmax_for(d) : 32;
   hipStream_t st = e->stream;
   ProfScope ps(e, MCX_K_REMOTE, (uint64_t)n);
   hipLaunchKernelGGL(k_remote_prep, dim3(nblocks((size_t)N * d)), dim3(BLOCK), 0, st, musigall,
                      e->winvall.p, (size_t)N * d);
-  DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_cmax<DMAX_>), dim3(nblocks((size_t)n)), dim3(BLOCK), 0,
-                                       st, pvals, musigall, e->winvall.p, e->cmax.p, n, d, N));
+  if (d > 32) {
+    hipLaunchKernelGGL(k_remote_cmax_big, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, pvals, musigall,
+                       e->winvall.p, e->cmax.p, n, d, N);
+  } else {
+    DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_cmax<DMAX_>), dim3(nblocks((size_t)n)), dim3(BLOCK), 0,
+                                         st, pvals, musigall, e->winvall.p, e->cmax.p, n, d, N));
+  }
   HIPCHK(hipGetLastError());
   int nact = n, pass = 0;
   int *ain = nullptr, *aout = e->active0.p;
@@ -587,8 +596,12 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     a.ptrial = ptrial; a.mutrial = mutrial; a.sigtrial = sigtrial; a.cfac = cfac;
     a.n = n; a.d = d; a.N = N; a.pass = pass;
     a.g0 = (uint32_t)(e->rank * e->nchain); a.t = t; a.seed = e->seed;
-    DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_pass<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK),
-                                         0, st, a));
+    if (d > 32) {
+      hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
+    } else {
+      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_pass<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK),
+                                           0, st, a));
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&nact, e->nact.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -843,7 +856,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
 extern "C" int mcx_vlfunc_eval(const mcx_vlfunc *f, int npset, const float *x, float *y)
 {
   if (!f || npset < 0 || (npset > 0 && (!x || !y))) return fail(MCX_ERR_INVALID, "bad arguments");
-  if (f->d < 1 || f->d > MAXD_FUSED) return fail(MCX_ERR_UNSUPPORTED, "d = %d outside 1..%d", f->d, MAXD_FUSED);
+  if (f->d < 1 || f->d > MAXD) return fail(MCX_ERR_UNSUPPORTED, "d = %d outside 1..%d", f->d, MAXD);
   if (f->kind == MCX_VL_HOST) {
     if (!f->fn) return fail(MCX_ERR_VLFUNC, "MCX_VL_HOST without a callback");
     return f->fn(f->ctx, npset, x, y);

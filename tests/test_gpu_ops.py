@@ -8,7 +8,7 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("d,n", [(2, 5), (8, 1000), (16, 4097), (12, 130), (32, 64)])
+@pytest.mark.parametrize("d,n", [(2, 5), (8, 1000), (16, 4097), (12, 130), (32, 64), (50, 37), (256, 11)])
 def test_gen_local(d, n):
     import mcpar_amd as M
     x = np.random.default_rng(d).normal(size=(n, d)).astype(np.float32)
@@ -38,7 +38,7 @@ def test_gen_local_full_covariance_statistics():
         eg.covar_setup(-np.eye(d, dtype=np.float32))
 
 
-@pytest.mark.parametrize("d,n,nshards", [(2, 64, 1), (16, 300, 1), (8, 96, 3), (5, 40, 1), (32, 33, 2)])
+@pytest.mark.parametrize("d,n,nshards", [(2, 64, 1), (16, 300, 1), (8, 96, 3), (5, 40, 1), (32, 33, 2), (33, 40, 1), (80, 24, 2)])
 def test_gen_remote(d, n, nshards):
     import mcpar_amd as M
     rng = np.random.default_rng(10 * d + nshards)

@@ -76,6 +76,12 @@ CASES = [
     ("gauss_d2_murray", O.VL_GAUSSIAN, 2, 64, 120, 80, 0.8),
     ("rosen1_d16_murray", O.VL_ROSENBROCK1, 16, 256, 120, 60, 0.8),
     ("rosen1_d8_murray", O.VL_ROSENBROCK1, 8, 100, 120, 60, 0.7),
+    # np > 32: 16 / 32 / 64 lanes per chain, Murray kernels with the chain vector in memory
+    ("rosen1_d36", O.VL_ROSENBROCK1, 36, 50, 60, 20, 1.0),
+    ("rosen1_d64_murray", O.VL_ROSENBROCK1, 64, 40, 110, 30, 0.8),
+    ("gauss_d45_murray", O.VL_GAUSSIAN, 45, 33, 110, 30, 0.8),
+    ("rosen1_d100", O.VL_ROSENBROCK1, 100, 21, 60, 12, 0.9),
+    ("rosen1_d256", O.VL_ROSENBROCK1, 256, 9, 60, 12, 0.9),
 ]
 
 
@@ -125,6 +131,12 @@ def test_full_covariance():
     cov = (a @ a.T / d + 0.5 * np.eye(d)).astype(np.float32)
     eo, eg = run_pair(O.VL_ROSENBROCK1, d, 200, 120, 40, 0.9, incov=cov)
     assert_same(eo, eg, "fullcov")
+    # np > 32: factor read from L2 instead of LDS
+    d = 40
+    a = rng.normal(size=(d, d)).astype(np.float32)
+    cov = (a @ a.T / d + 0.5 * np.eye(d)).astype(np.float32)
+    eo, eg = run_pair(O.VL_ROSENBROCK1, d, 24, 60, 12, 0.9, incov=cov)
+    assert_same(eo, eg, "fullcov40")
     # and d = 16 with 4 lanes per chain
     d = 16
     a = rng.normal(size=(d, d)).astype(np.float32)

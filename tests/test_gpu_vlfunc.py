@@ -29,15 +29,15 @@ def test_reference_golden_vectors(golden_dir):
         assert np.array_equal(y.view(np.uint32), yo.view(np.uint32)), c["name"]
 
 
-@pytest.mark.parametrize("d", [2, 4, 6, 8, 10, 16, 22, 32])
+@pytest.mark.parametrize("d", [2, 4, 6, 8, 10, 16, 22, 32, 34, 64, 130, 256])
 def test_rosenbrock1_bit_exact(d):
     import mcpar_amd as M
-    x = np.random.default_rng(d).normal(0, 1.5, (70001, d)).astype(np.float32)
+    x = np.random.default_rng(d).normal(0, 1.5, (70001 if d <= 32 else 5001, d)).astype(np.float32)
     assert np.array_equal(M.vlfunc_eval(M.VL_ROSENBROCK1, d, x).view(np.uint32),
                           O.vl_eval(O.VL_ROSENBROCK1, d, x).view(np.uint32))
 
 
-@pytest.mark.parametrize("d", [2, 3, 5, 16, 31])
+@pytest.mark.parametrize("d", [2, 3, 5, 16, 31, 77, 255])
 def test_rosenbrock2_and_gaussian_bit_exact(d):
     import mcpar_amd as M
     rng = np.random.default_rng(100 + d)
