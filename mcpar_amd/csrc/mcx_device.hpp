@@ -703,39 +703,25 @@ __device__ __forceinline__ float q_arg(const float *__restrict__ ms, const float
   return arg;
 }
 
-// numerator of cfac: max_i Q_i(pvals_j) (src/mcpar.cc:421-437); does not depend on the pass
-template <int DMAX>
-__global__ __launch_bounds__(BLOCK) void k_remote_cmax(const float *__restrict__ pvals,
-                                                       const float *__restrict__ musigall,
-                                                       const float *__restrict__ winv,
-                                                       float *__restrict__ cmax, int n, int d, int N)
-{
-  const int j = blockIdx.x * BLOCK + threadIdx.x;
-  if (j >= n) return;
-  float x[DMAX];
-#pragma unroll
-  for (int k = 0; k < DMAX; ++k) x[k] = k < d ? pvals[(size_t)j * d + k] : 0.0f;
-  float cm = 0.0f;
-  for (int qi = 0; qi < N; ++qi) {
-    const float gv = expf_v1(-0.5f * q_arg<DMAX>(musigall + 2 * (size_t)qi * d, winv + (size_t)qi * d, x, d));
-    cm = gv > cm ? gv : cm;
-  }
-  cmax[j] = cm;
-}
+constexpr int QBLOCK = 256;  // block length of the qisum summation order
 
 struct RemoteArgs {
-  const int *active_in;
+  const int *active_in;  // compacted list of still-rejected chains (null = all chains, pass 0)
   int nact;
   int *active_out;
   int *nact_out;
   const float *musigall, *winv, *cmax;
   float *ptrial, *mutrial, *sigtrial, *cfac;
-  int n, d, N, pass;
+  float *racpt;        // [n] rejection threshold of this pass, by chain
+  float *psum, *pmax;  // [nact][S] per-block partial sums / maxima, by position in the active list
+  int n, d, N, pass, S;
   uint32_t g0, t, seed;
 };
 
+// Murray draw for every still-rejected chain (src/mcpar.cc:337-352): pick a component, draw from
+// its diagonal Gaussian, keep (mutrial, sigtrial); one lane per chain.
 template <int DMAX>
-__global__ __launch_bounds__(BLOCK) void k_remote_pass(const RemoteArgs a)
+__global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
 {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.nact) return;
@@ -744,37 +730,81 @@ __global__ __launch_bounds__(BLOCK) void k_remote_pass(const RemoteArgs a)
   const uint32_t g = a.g0 + (uint32_t)j;
   const u32x4 w = philox4x32_10(a.t, g, (uint32_t)a.pass, 0u, a.seed, ST_RSEL);
   const int sel = (int)(((uint64_t)w.x * (uint64_t)a.N) >> 32);  // src/mcpar.cc:337
-  float x[DMAX];
+  for (int qb = 0; 4 * qb < d; ++qb) {
+    float z[4];
+    normal4_from_words(philox4x32_10(a.t, g, (uint32_t)a.pass, (uint32_t)qb, a.seed, ST_RNORM), z);
 #pragma unroll
-  for (int qb = 0; qb < (DMAX + 3) / 4; ++qb) {
-    if (4 * qb < d) {
-      float z[4];
-      normal4_from_words(philox4x32_10(a.t, g, (uint32_t)a.pass, (uint32_t)qb, a.seed, ST_RNORM), z);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = 4 * qb + c;
-        if (k < DMAX && k < d) {  // src/mcpar.cc:339-352
-          const float m = a.musigall[2 * ((size_t)sel * d + k)];
-          const float sg = __builtin_sqrtf(a.musigall[2 * ((size_t)sel * d + k) + 1]);
-          x[k] = __builtin_fmaf(sg, z[c], m);
-          a.mutrial[(size_t)j * d + k] = m;
-          a.sigtrial[(size_t)j * d + k] = sg;
-          a.ptrial[(size_t)j * d + k] = x[k];
-        }
+    for (int c = 0; c < 4; ++c) {
+      const int k = 4 * qb + c;
+      if (k < d) {  // src/mcpar.cc:339-352
+        const float m = a.musigall[2 * ((size_t)sel * d + k)];
+        const float sg = __builtin_sqrtf(a.musigall[2 * ((size_t)sel * d + k) + 1]);
+        a.mutrial[(size_t)j * d + k] = m;
+        a.sigtrial[(size_t)j * d + k] = sg;
+        a.ptrial[(size_t)j * d + k] = __builtin_fmaf(sg, z[c], m);
       }
     }
   }
+  a.racpt[j] = u24(w.y);  // src/mcpar.cc:401
+}
+
+// The all-pairs sweep (src/mcpar.cc:367-395 for ptrial, :421-437 for pvals): lanes = chains (vector
+// in registers), blockIdx.y = one block of QBLOCK consecutive Q_i, streamed through wave-uniform
+// (scalar) loads so that one 128-byte fetch serves 64 chain-Q pairs.  Writes the block's partial
+// sum and maximum; blocks are combined in index order by k_remote_decide (fixed summation order).
+template <int DMAX, bool SUMS>
+__global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict__ xrows,
+                                                        const int *__restrict__ active, int nact,
+                                                        const float *__restrict__ musigall,
+                                                        const float *__restrict__ winv,
+                                                        float *__restrict__ psum,
+                                                        float *__restrict__ pmax, int d, int N, int S)
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= nact) return;
+  const int j = active ? active[i] : i;
+  const int sb = blockIdx.y;
+  float x[DMAX];
 #pragma unroll
-  for (int k = 0; k < DMAX; ++k)
-    if (k >= d) x[k] = 0.0f;
-  float qs = FPEPS, qm = FPEPS;  // src/mcpar.cc:355-365
-  for (int qi = 0; qi < a.N; ++qi) {  // src/mcpar.cc:367-395
-    const float gv = expf_v1(-0.5f * q_arg<DMAX>(a.musigall + 2 * (size_t)qi * d, a.winv + (size_t)qi * d, x, d));
-    qs = qs + gv;
-    qm = gv > qm ? gv : qm;
+  for (int k = 0; k < DMAX; ++k) x[k] = k < d ? xrows[(size_t)j * d + k] : 0.0f;
+  const int q0 = sb * QBLOCK, q1 = (q0 + QBLOCK < N) ? q0 + QBLOCK : N;
+  float part = 0.0f, m = 0.0f;
+  for (int qi = q0; qi < q1; ++qi) {
+    const float gv = expf_v1(-0.5f * q_arg<DMAX>(musigall + 2 * (size_t)qi * d, winv + (size_t)qi * d, x, d));
+    if (SUMS) part = part + gv;
+    m = gv > m ? gv : m;
   }
-  const float pacpt = qm / qs;  // src/mcpar.cc:397-398
-  if (u24(w.y) < pacpt) {       // src/mcpar.cc:405-441
+  if (SUMS) psum[(size_t)i * S + sb] = part;
+  pmax[(size_t)i * S + sb] = m;
+}
+
+// numerator of cfac: max_i Q_i(pvals_j) (src/mcpar.cc:421-437); does not depend on the pass
+__global__ void k_remote_cmax_combine(const float *__restrict__ pmax, float *__restrict__ cmax, int n, int S)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float cm = 0.0f;
+  for (int sb = 0; sb < S; ++sb) {
+    const float v = pmax[(size_t)j * S + sb];
+    cm = v > cm ? v : cm;
+  }
+  cmax[j] = cm;
+}
+
+// rejection test of the pass (src/mcpar.cc:397-441); survivors are compacted for the next pass
+__global__ void k_remote_decide(const RemoteArgs a)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.nact) return;
+  const int j = a.active_in ? a.active_in[i] : i;
+  float qs = FPEPS, qm = FPEPS;  // src/mcpar.cc:355-365
+  for (int sb = 0; sb < a.S; ++sb) {
+    qs = qs + a.psum[(size_t)i * a.S + sb];
+    const float v = a.pmax[(size_t)i * a.S + sb];
+    qm = v > qm ? v : qm;
+  }
+  const float pacpt = qm / qs;
+  if (a.racpt[j] < pacpt) {
     a.cfac[j] = a.cmax[j] / qm;
   } else {
     const int slot = atomicAdd(a.nact_out, 1);
@@ -836,10 +866,14 @@ __global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteArgs a)
     }
   }
   float qs = FPEPS, qm = FPEPS;
-  for (int qi = 0; qi < a.N; ++qi) {
-    const float gv = expf_v1(-0.5f * q_arg_mem(a.musigall + 2 * (size_t)qi * d, a.winv + (size_t)qi * d, x, d));
-    qs = qs + gv;
-    qm = gv > qm ? gv : qm;
+  for (int b0 = 0; b0 < a.N; b0 += QBLOCK) {  // blocked summation order, DESIGN.md §3.5
+    float part = 0.0f;
+    for (int qi = b0; qi < a.N && qi < b0 + QBLOCK; ++qi) {
+      const float gv = expf_v1(-0.5f * q_arg_mem(a.musigall + 2 * (size_t)qi * d, a.winv + (size_t)qi * d, x, d));
+      part = part + gv;
+      qm = gv > qm ? gv : qm;
+    }
+    qs = qs + part;
   }
   const float pacpt = qm / qs;
   if (u24(w.y) < pacpt) {

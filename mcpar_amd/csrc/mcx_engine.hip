@@ -322,7 +322,7 @@ struct mcx_engine {
   DevBuf<uint32_t> acc_cnt;
   DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
   DevBuf<int> active0, active1, nact, ntrace;
-  DevBuf<float> samp_x, samp_ly, winv_tab;
+  DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt;
   DevBuf<uint8_t> mask;
   // host staging
   std::vector<float> h_ptrial, h_lytrial;
@@ -441,7 +441,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->lylast.release(); e->lytrial.release(); e->cfac.release(); e->cmax.release(); e->cov.release();
   e->trace.release(); e->acc_cnt.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
-  e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release();
+  e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release();
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MCX_OK;
@@ -574,16 +574,25 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
                          float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
 {
   const int n = e->nchain, d = e->nparam, N = e->tchains, dm = d <= 32 ? dmax_for(d) : 32;
+  const bool big = d > 32;
+  const int S = (N + QBLOCK - 1) / QBLOCK;
   hipStream_t st = e->stream;
   ProfScope ps(e, MCX_K_REMOTE, (uint64_t)n);
+  if (!big) {
+    MCXCHK(e->psum.alloc((size_t)n * S));
+    MCXCHK(e->pmax.alloc((size_t)n * S));
+    MCXCHK(e->racpt.alloc((size_t)n));
+  }
   hipLaunchKernelGGL(k_remote_prep, dim3(nblocks((size_t)N * d)), dim3(BLOCK), 0, st, musigall,
                      e->winvall.p, (size_t)N * d);
-  if (d > 32) {
+  if (big) {
     hipLaunchKernelGGL(k_remote_cmax_big, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, pvals, musigall,
                        e->winvall.p, e->cmax.p, n, d, N);
   } else {
-    DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_cmax<DMAX_>), dim3(nblocks((size_t)n)), dim3(BLOCK), 0,
-                                         st, pvals, musigall, e->winvall.p, e->cmax.p, n, d, N));
+    DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
+                                         0, st, pvals, (const int *)nullptr, n, musigall, e->winvall.p,
+                                         (float *)nullptr, e->pmax.p, d, N, S));
+    hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S);
   }
   HIPCHK(hipGetLastError());
   int nact = n, pass = 0;
@@ -594,13 +603,17 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     a.active_in = ain; a.nact = nact; a.active_out = aout; a.nact_out = e->nact.p;
     a.musigall = musigall; a.winv = e->winvall.p; a.cmax = e->cmax.p;
     a.ptrial = ptrial; a.mutrial = mutrial; a.sigtrial = sigtrial; a.cfac = cfac;
-    a.n = n; a.d = d; a.N = N; a.pass = pass;
+    a.racpt = e->racpt.p; a.psum = e->psum.p; a.pmax = e->pmax.p;
+    a.n = n; a.d = d; a.N = N; a.pass = pass; a.S = S;
     a.g0 = (uint32_t)(e->rank * e->nchain); a.t = t; a.seed = e->seed;
-    if (d > 32) {
+    if (big) {
       hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
     } else {
-      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_pass<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK),
-                                           0, st, a));
+      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
+      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
+                                           0, st, ptrial, (const int *)ain, nact, musigall, e->winvall.p,
+                                           e->psum.p, e->pmax.p, d, N, S));
+      hipLaunchKernelGGL(k_remote_decide, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&nact, e->nact.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -608,7 +621,7 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     ain = aout;
     aout = (aout == e->active0.p) ? e->active1.p : e->active0.p;
     ++pass;
-    e->cnt.kernel_launches++;
+    e->cnt.kernel_launches += big ? 1 : 3;
   }
   hipLaunchKernelGGL(k_square, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, sigtrial, (size_t)e->ntot);
   HIPCHK(hipGetLastError());

@@ -18,6 +18,7 @@
 #endif
 
 #define FPEPS 1.0e-14f /* src/mcpar.cc:15 */
+#define QBLOCK 256     /* block length of the qisum summation order */
 
 static int g_threads = 1; /* OpenMP team size of every parallel loop (mcxo_set_threads) */
 
@@ -473,12 +474,19 @@ int mcxo_gen_remote(mcxo_engine *e, uint32_t t, const float *pvals, const float 
         sigtrial[ci] = sqrtf(musigall[2 * ((size_t)sel * d + i) + 1]);
         ptrial[ci] = fmaf(sigtrial[ci], z[i], mutrial[ci]);
       }
-      float qs = FPEPS, qm = FPEPS; /* :355-365 */
-      for (int qi = 0; qi < N; ++qi) { /* :367-395 */
-        float gv = mcxo_expf(-0.5f * qarg(d, musigall + 2 * (size_t)qi * d,
-                                          e->winvall + (size_t)qi * d, ptrial + (size_t)j * d));
-        qs = qs + gv;
-        qm = gv > qm ? gv : qm;
+      /* :355-395.  Summation order of qisum: the N terms are added in blocks of
+       * QBLOCK consecutive Q_i, each block summed left to right from 0, block sums added left to
+       * right onto FPEPS -- so that a GPU can sweep the blocks in parallel and still be bit-exact. */
+      float qs = FPEPS, qm = FPEPS;
+      for (int b0 = 0; b0 < N; b0 += QBLOCK) {
+        float part = 0.0f;
+        for (int qi = b0; qi < N && qi < b0 + QBLOCK; ++qi) {
+          float gv = mcxo_expf(-0.5f * qarg(d, musigall + 2 * (size_t)qi * d,
+                                            e->winvall + (size_t)qi * d, ptrial + (size_t)j * d));
+          part = part + gv;
+          qm = gv > qm ? gv : qm;
+        }
+        qs = qs + part;
       }
       e->qisum[j] = qs; e->qimax[j] = qm;
       e->pacpt[j] = qm / qs;        /* :397-398 */
