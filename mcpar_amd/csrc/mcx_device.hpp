@@ -683,22 +683,26 @@ __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsigned lo
 // genRemote (src/mcpar.cc:315-451).  One lane per chain, chain vector in registers, the N
 // per-chain Gaussians Q_i streamed through wave-uniform (scalar) loads.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ winv, size_t nd)
+// qpar[i] = (mu_i, 1/sig2_i): one Q_i is 2d contiguous floats, fetched with wide scalar loads
+__global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ qpar, size_t nd)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nd) winv[i] = 1.0f / musigall[2 * i + 1];
+  if (i < nd) {
+    const float2 ms = reinterpret_cast<const float2 *>(musigall)[i];
+    reinterpret_cast<float2 *>(qpar)[i] = make_float2(ms.x, 1.0f / ms.y);
+  }
 }
 
-template <int DMAX>
-__device__ __forceinline__ float q_arg(const float *__restrict__ ms, const float *__restrict__ wv,
-                                       const float x[DMAX], int d)
+// EXACT: d == DMAX, no per-element guard (lets the compiler fetch a whole Q_i with wide scalar loads)
+template <int DMAX, bool EXACT = false>
+__device__ __forceinline__ float q_arg(const float *__restrict__ qp, const float x[DMAX], int d)
 {
   float arg = 0.0f;
 #pragma unroll
   for (int k = 0; k < DMAX; ++k)
-    if (k < d) {
-      const float xm = ms[2 * k] - x[k];
-      arg = __builtin_fmaf(xm * xm, wv[k], arg);
+    if (EXACT || k < d) {
+      const float xm = qp[2 * k] - x[k];
+      arg = __builtin_fmaf(xm * xm, qp[2 * k + 1], arg);
     }
   return arg;
 }
@@ -710,7 +714,7 @@ struct RemoteArgs {
   int nact;
   int *active_out;
   int *nact_out;
-  const float *musigall, *winv, *cmax;
+  const float *musigall, *winv, *cmax;  // winv = qpar: (mu, 1/sig2) pairs
   float *ptrial, *mutrial, *sigtrial, *cfac;
   float *racpt;        // [n] rejection threshold of this pass, by chain
   float *psum, *pmax;  // [nact][S] per-block partial sums / maxima, by position in the active list
@@ -752,11 +756,10 @@ __global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
 // in registers), blockIdx.y = one block of QBLOCK consecutive Q_i, streamed through wave-uniform
 // (scalar) loads so that one 128-byte fetch serves 64 chain-Q pairs.  Writes the block's partial
 // sum and maximum; blocks are combined in index order by k_remote_decide (fixed summation order).
-template <int DMAX, bool SUMS>
+template <int DMAX, bool SUMS, bool EXACT>
 __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict__ xrows,
                                                         const int *__restrict__ active, int nact,
-                                                        const float *__restrict__ musigall,
-                                                        const float *__restrict__ winv,
+                                                        const float *__restrict__ qpar,
                                                         float *__restrict__ psum,
                                                         float *__restrict__ pmax, int d, int N, int S)
 {
@@ -764,13 +767,14 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
   if (i >= nact) return;
   const int j = active ? active[i] : i;
   const int sb = blockIdx.y;
+  const int DD = EXACT ? DMAX : d;
   float x[DMAX];
 #pragma unroll
-  for (int k = 0; k < DMAX; ++k) x[k] = k < d ? xrows[(size_t)j * d + k] : 0.0f;
+  for (int k = 0; k < DMAX; ++k) x[k] = k < DD ? xrows[(size_t)j * DD + k] : 0.0f;
   const int q0 = sb * QBLOCK, q1 = (q0 + QBLOCK < N) ? q0 + QBLOCK : N;
   float part = 0.0f, m = 0.0f;
   for (int qi = q0; qi < q1; ++qi) {
-    const float gv = expf_v1(-0.5f * q_arg<DMAX>(musigall + 2 * (size_t)qi * d, winv + (size_t)qi * d, x, d));
+    const float gv = expf_v1(-0.5f * q_arg<DMAX, EXACT>(qpar + 2 * (size_t)qi * DD, x, DD));
     if (SUMS) part = part + gv;
     m = gv > m ? gv : m;
   }
@@ -814,20 +818,18 @@ __global__ void k_remote_decide(const RemoteArgs a)
 
 // np > 32: the chain vector does not fit the register budget; it is re-read from global memory
 // (L1/L2-resident).  Same arithmetic and order as the register kernels.
-__device__ __forceinline__ float q_arg_mem(const float *__restrict__ ms, const float *__restrict__ wv,
-                                           const float *__restrict__ x, int d)
+__device__ __forceinline__ float q_arg_mem(const float *__restrict__ qp, const float *__restrict__ x, int d)
 {
   float arg = 0.0f;
   for (int k = 0; k < d; ++k) {
-    const float xm = ms[2 * k] - x[k];
-    arg = __builtin_fmaf(xm * xm, wv[k], arg);
+    const float xm = qp[2 * k] - x[k];
+    arg = __builtin_fmaf(xm * xm, qp[2 * k + 1], arg);
   }
   return arg;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_remote_cmax_big(const float *__restrict__ pvals,
-                                                           const float *__restrict__ musigall,
-                                                           const float *__restrict__ winv,
+                                                           const float *__restrict__ qpar,
                                                            float *__restrict__ cmax, int n, int d, int N)
 {
   const int j = blockIdx.x * BLOCK + threadIdx.x;
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_cmax_big(const float *__restri
   const float *x = pvals + (size_t)j * d;
   float cm = 0.0f;
   for (int qi = 0; qi < N; ++qi) {
-    const float gv = expf_v1(-0.5f * q_arg_mem(musigall + 2 * (size_t)qi * d, winv + (size_t)qi * d, x, d));
+    const float gv = expf_v1(-0.5f * q_arg_mem(qpar + 2 * (size_t)qi * d, x, d));
     cm = gv > cm ? gv : cm;
   }
   cmax[j] = cm;
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteArgs a)
   for (int b0 = 0; b0 < a.N; b0 += QBLOCK) {  // blocked summation order, DESIGN.md §3.5
     float part = 0.0f;
     for (int qi = b0; qi < a.N && qi < b0 + QBLOCK; ++qi) {
-      const float gv = expf_v1(-0.5f * q_arg_mem(a.musigall + 2 * (size_t)qi * d, a.winv + (size_t)qi * d, x, d));
+      const float gv = expf_v1(-0.5f * q_arg_mem(a.winv + 2 * (size_t)qi * d, x, d));
       part = part + gv;
       qm = gv > qm ? gv : qm;
     }

@@ -406,7 +406,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   auto A = [&](int s) { if (st == MCX_OK) st = s; };
   A(e->pvals.alloc(nt)); A(e->ptrial.alloc(nt)); A(e->mu.alloc(nt)); A(e->sig.alloc(nt));
   A(e->psum2.alloc(nt)); A(e->mutrial.alloc(nt)); A(e->sigtrial.alloc(nt));
-  A(e->musigall.alloc(2 * (size_t)e->tchains * np)); A(e->winvall.alloc((size_t)e->tchains * np));
+  A(e->musigall.alloc(2 * (size_t)e->tchains * np)); A(e->winvall.alloc(2 * (size_t)e->tchains * np));
   A(e->lylast.alloc(n)); A(e->lytrial.alloc(n)); A(e->cfac.alloc(n)); A(e->cmax.alloc(n));
   A(e->cov.alloc((size_t)e->ncov)); A(e->trace.alloc(256)); A(e->acc_cnt.alloc(n)); A(e->ctr.alloc(8));
   A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(1)); A(e->ntrace.alloc(1));
@@ -586,12 +586,18 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
   hipLaunchKernelGGL(k_remote_prep, dim3(nblocks((size_t)N * d)), dim3(BLOCK), 0, st, musigall,
                      e->winvall.p, (size_t)N * d);
   if (big) {
-    hipLaunchKernelGGL(k_remote_cmax_big, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, pvals, musigall,
-                       e->winvall.p, e->cmax.p, n, d, N);
+    hipLaunchKernelGGL(k_remote_cmax_big, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, pvals, e->winvall.p,
+                       e->cmax.p, n, d, N);
   } else {
-    DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
-                                         0, st, pvals, (const int *)nullptr, n, musigall, e->winvall.p,
-                                         (float *)nullptr, e->pmax.p, d, N, S));
+    if (d == dm) {
+      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, true>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
+                                           0, st, pvals, (const int *)nullptr, n, e->winvall.p,
+                                           (float *)nullptr, e->pmax.p, d, N, S));
+    } else {
+      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
+                                           0, st, pvals, (const int *)nullptr, n, e->winvall.p,
+                                           (float *)nullptr, e->pmax.p, d, N, S));
+    }
     hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S);
   }
   HIPCHK(hipGetLastError());
@@ -610,9 +616,15 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
       hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
     } else {
       DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
-      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
-                                           0, st, ptrial, (const int *)ain, nact, musigall, e->winvall.p,
-                                           e->psum.p, e->pmax.p, d, N, S));
+      if (d == dm) {
+        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, true>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
+                                             0, st, ptrial, (const int *)ain, nact, e->winvall.p,
+                                             e->psum.p, e->pmax.p, d, N, S));
+      } else {
+        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, false>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
+                                             0, st, ptrial, (const int *)ain, nact, e->winvall.p,
+                                             e->psum.p, e->pmax.p, d, N, S));
+      }
       hipLaunchKernelGGL(k_remote_decide, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
     }
     HIPCHK(hipGetLastError());
