@@ -83,6 +83,9 @@ int mcx_destroy(mcx_engine *e);
  * HBM-resident sample store (mcx_samples_*), which plays the role of MCout's vector. */
 int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L,
             const float *incov);
+/* Stage the initial chain state pinit[nc*np] in HBM ahead of time; a later mcx_run(..., pinit = NULL,
+ * ...) starts from the staged copy (device-to-device) instead of reading host memory. */
+int mcx_stage_pinit(mcx_engine *e, const float *pinit);
 
 /* MCPar::genLocal(pvals, ptrial, cfac)  src/mcpar.hh:40, src/mcpar.cc:302-312.  t is the RNG
  * step index; host buffers [nc*np], [nc*np], [nc].  Uses the engine's current

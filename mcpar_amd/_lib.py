@@ -57,6 +57,7 @@ def load():
                        C.c_float, C.c_float, C.c_float, C.c_int, C.c_uint32],
         "mcx_destroy": [vp],
         "mcx_run": [vp, C.c_int, C.c_int, fp, C.POINTER(VLFunc), fp],
+        "mcx_stage_pinit": [vp, fp],
         "mcx_gen_local": [vp, C.c_uint32, fp, fp, fp],
         "mcx_gen_remote": [vp, C.c_uint32, fp, fp, fp, fp, fp, fp, C.POINTER(C.c_int)],
         "mcx_covar_setup": [vp, fp, fp],

@@ -230,7 +230,7 @@ __device__ __forceinline__ void welford_block(const float x[4], float mu[4], flo
 struct SegArgs {
   float *x, *ly, *mu, *psum2;
   uint32_t *acc_cnt;
-  unsigned long long *acc_total;  // one atomic per wavefront per launch
+  uint32_t *acc_slots;  // [number of wavefronts] accepted proposals, one plain slot per wavefront
   const float *T;
   float *samp_x, *samp_ly;  // sample store rows of the segment's first step, or null
   uint8_t *mask;            // accept mask row of the segment's first step, or null
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
     store_block(a.mu, chain, d, k0, nv, vec4, mu);
     store_block(a.psum2, chain, d, k0, nv, vec4, ps);
   }
-  if ((threadIdx.x & 63u) == 0 && wacc) atomicAdd(a.acc_total, (unsigned long long)wacc);
+  // one slot per wavefront, owned by it: no atomics (4096 same-address atomics cost ~40 us per launch)
+  if ((threadIdx.x & 63u) == 0 && wacc) a.acc_slots[gid >> 6] += wacc;
 }
 
 
@@ -473,7 +474,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
     *reinterpret_cast<float4 *>(a.mu + off) = make_float4(me.x, mo.x, me.y, mo.y);
     *reinterpret_cast<float4 *>(a.psum2 + off) = make_float4(se.x, so.x, se.y, so.y);
   }
-  if ((threadIdx.x & 63u) == 0 && wacc) atomicAdd(a.acc_total, (unsigned long long)wacc);
+  // one slot per wavefront, owned by it: no atomics (4096 same-address atomics cost ~40 us per launch)
+  if ((threadIdx.x & 63u) == 0 && wacc) a.acc_slots[gid >> 6] += wacc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -485,7 +487,7 @@ struct StepArgs {
   float *ptrial, *lytrial, *cfac;
   const float *mutrial, *sigtrial;  // remote adoption (src/mcpar.cc:189-196)
   uint32_t *acc_cnt;
-  unsigned long long *acc_total;
+  uint32_t *acc_slots;
   const float *T;
   float *samp_x, *samp_ly;
   uint8_t *mask;
@@ -612,7 +614,8 @@ __global__ __launch_bounds__(BLOCK) void k_accept(const StepArgs a)
       if (q == 0) a.samp_ly[chain] = ly;
     }
   }
-  if ((threadIdx.x & 63u) == 0 && wacc) atomicAdd(a.acc_total, (unsigned long long)wacc);
+  // one slot per wavefront, owned by it: no atomics (4096 same-address atomics cost ~40 us per launch)
+  if ((threadIdx.x & 63u) == 0 && wacc) a.acc_slots[gid >> 6] += wacc;
 }
 
 // start of the main loop: mu = 0, psum2 = FPEPS (src/mcpar.cc:99-104)
@@ -641,18 +644,43 @@ __global__ void k_variance(const float *psum2, float *sig, size_t ntot, float wi
 
 // ---------------------------------------------------------------------------------------------
 // Burn-in acceptance-rate tuner (src/mcpar.cc:77-96), on device so that burn-in needs no host
-// round trip.  ctr[0] = accepts of the segment just run, ctr[1] = tuner naccept, ctr[2] = tuner
+// round trip.  slots = per-wavefront accepts of the segment just run, ctr[1] = tuner naccept, ctr[2] = tuner
 // ntrial, ctr[3] = total burn-in accepts.  Integer counters (the reference's float counters stop
 // counting at 2^24: SURVEY §7).
 // ---------------------------------------------------------------------------------------------
+// sum (and clear) the per-wavefront accept slots: one block
+__device__ __forceinline__ unsigned long long block_sum_slots(uint32_t *slots, int nslots)
+{
+  __shared__ unsigned long long red[BLOCK / 64];
+  unsigned long long v = 0;
+  for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
+    v += slots[i];
+    slots[i] = 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long t = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
+// accepted proposals of the main loop so far: *dst += sum(slots)
+__global__ void k_reduce_slots(uint32_t *slots, int nslots, unsigned long long *dst)
+{
+  const unsigned long long t = block_sum_slots(slots, nslots);
+  if (threadIdx.x == 0) *dst += t;
+}
+
 __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsigned long long add_trials,
                         int check, float armin, float armax, float dfac, float ifac, float *trace,
-                        int *ntrace)
+                        int *ntrace, uint32_t *slots, int nslots)
 {
   __shared__ float fac;
+  const unsigned long long seg = block_sum_slots(slots, nslots);
   if (threadIdx.x == 0) {
-    const unsigned long long seg = ctr[0];
-    ctr[0] = 0;
     unsigned long long na = ctr[1] + seg, nt = ctr[2] + add_trials;
     ctr[3] += seg;
     float f = 1.0f;

@@ -149,17 +149,20 @@ struct LikDev {
   int kind = 0;  // LikKind, or MCX_VL_HOST
   int ncomp = 0;
   DevBuf<float> params;
+  std::vector<float> host;  // staging for the asynchronous upload (must outlive it)
   mcx_host_fn fn = nullptr;
   void *ctx = nullptr;
   bool fusable() const { return kind == LIK_ROSEN1 || kind == LIK_GAUSS || kind == LIK_MIX; }
 };
 
+// uploads asynchronously on st; the caller synchronises before L.host is touched again
 static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
 {
   if (!f) return fail(MCX_ERR_INVALID, "vlfunc is NULL");
   if (f->d != np) return fail(MCX_ERR_INVALID, "vlfunc.d = %d but engine np = %d", f->d, np);
   const int d = f->d;
-  std::vector<float> h;
+  std::vector<float> &h = L.host;
+  h.clear();
   L.fn = nullptr;
   L.ctx = nullptr;
   L.ncomp = 0;
@@ -211,10 +214,8 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
     return fail(MCX_ERR_INVALID, "unknown vlfunc kind %d", f->kind);
   }
   MCXCHK(L.params.alloc(h.size()));
-  if (!h.empty()) {
+  if (!h.empty())
     HIPCHK(hipMemcpyAsync(L.params.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
-  }
   return MCX_OK;
 }
 
@@ -319,13 +320,15 @@ struct mcx_engine {
   // device state (src/mcpar.hh:61-88)
   DevBuf<float> pvals, ptrial, mu, sig, psum2, mutrial, sigtrial, musigall, winvall;
   DevBuf<float> lylast, lytrial, cfac, cmax, cov, trace;
-  DevBuf<uint32_t> acc_cnt;
+  DevBuf<uint32_t> acc_cnt, acc_slots;
+  int nslots = 0;
   DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
   DevBuf<int> active0, active1, nact, ntrace;
-  DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt;
+  DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev;
+  bool pinit_staged = false;
   DevBuf<uint8_t> mask;
   // host staging
-  std::vector<float> h_ptrial, h_lytrial;
+  std::vector<float> h_ptrial, h_lytrial, h_cov, h_winv;
   // run bookkeeping
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -409,6 +412,8 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   A(e->musigall.alloc(2 * (size_t)e->tchains * np)); A(e->winvall.alloc(2 * (size_t)e->tchains * np));
   A(e->lylast.alloc(n)); A(e->lytrial.alloc(n)); A(e->cfac.alloc(n)); A(e->cmax.alloc(n));
   A(e->cov.alloc((size_t)e->ncov)); A(e->trace.alloc(256)); A(e->acc_cnt.alloc(n)); A(e->ctr.alloc(8));
+  e->nslots = (int)(((size_t)nc * e->lpc + 63) / 64);
+  A(e->acc_slots.alloc((size_t)e->nslots));
   A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(1)); A(e->ntrace.alloc(1));
   if (st == MCX_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipStreamCreate failed");
@@ -439,9 +444,9 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->pvals.release(); e->ptrial.release(); e->mu.release(); e->sig.release(); e->psum2.release();
   e->mutrial.release(); e->sigtrial.release(); e->musigall.release(); e->winvall.release();
   e->lylast.release(); e->lytrial.release(); e->cfac.release(); e->cmax.release(); e->cov.release();
-  e->trace.release(); e->acc_cnt.release(); e->ctr.release(); e->active0.release();
+  e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
-  e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release();
+  e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MCX_OK;
@@ -490,10 +495,11 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
 }
 
 // MCPar::covar_setup (src/mcpar.cc:454-484)
-static int covar_install(mcx_engine *e, const float *incov, float *cov_out)
+static int covar_install(mcx_engine *e, const float *incov, float *cov_out, bool sync = true)
 {
   const int d = e->nparam;
-  std::vector<float> c((size_t)e->ncov, 0.0f);
+  std::vector<float> &c = e->h_cov;
+  c.assign((size_t)e->ncov, 0.0f);
   if (incov) std::copy(incov, incov + e->ncov, c.begin());
   else
     for (int i = 0; i < d; ++i) c[(size_t)i * (d + 1)] = 1.0f;
@@ -504,7 +510,7 @@ static int covar_install(mcx_engine *e, const float *incov, float *cov_out)
     for (int j = 0; j < i; ++j)
       if (c[(size_t)i * d + j] != 0.0f) e->diag = false;
   HIPCHK(hipMemcpyAsync(e->cov.p, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (sync) HIPCHK(hipStreamSynchronize(e->stream));
   if (cov_out) std::copy(c.begin(), c.end(), cov_out);
   return MCX_OK;
 }
@@ -539,7 +545,7 @@ static void fill_step(mcx_engine *e, StepArgs &a, uint32_t t, int isamp, bool ma
   a.ptrial = e->ptrial.p; a.lytrial = e->lytrial.p; a.cfac = e->cfac.p;
   a.mutrial = e->mutrial.p; a.sigtrial = e->sigtrial.p;
   a.acc_cnt = e->acc_cnt.p;
-  a.acc_total = e->ctr.p + (main ? 4 : 0);
+  a.acc_slots = e->acc_slots.p;
   a.T = e->cov.p;
   a.samp_x = (main && e->opt_samples) ? e->samp_x.p + (size_t)samprow * e->ntot : nullptr;
   a.samp_ly = (main && e->opt_samples) ? e->samp_ly.p + (size_t)samprow * e->nchain : nullptr;
@@ -686,12 +692,13 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
                        const float *incov)
 {
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
-  if (nsamp < 0 || nburn < 0 || !pinit) return fail(MCX_ERR_INVALID, "bad run arguments");
+  if (nsamp < 0 || nburn < 0) return fail(MCX_ERR_INVALID, "bad run arguments");
+  if (!pinit && !e->pinit_staged) return fail(MCX_ERR_INVALID, "pinit is NULL and no state was staged (mcx_stage_pinit)");
   if (e->size > 1 && !e->xfn) return fail(MCX_ERR_EXCHANGE, "nshards > 1 needs mcx_set_exchange()");
   const int n = e->nchain, d = e->nparam;
   hipStream_t st = e->stream;
   MCXCHK(lik_setup(e->lik, L, d, st));
-  MCXCHK(covar_install(e, incov, nullptr));  // src/mcpar.cc:20
+  MCXCHK(covar_install(e, incov, nullptr, false));  // src/mcpar.cc:20
   // sample store: every chain, every main-loop step (src/mcpar.cc:31-40, 177-182), kept in HBM
   e->samp_steps = 0;
   if (e->opt_samples && nsamp > 0) {
@@ -704,27 +711,29 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     MCXCHK(e->mask.alloc((size_t)(nburn + nsamp) * n));
     HIPCHK(hipMemsetAsync(e->mask.p, 0, (size_t)(nburn + nsamp) * n, st));
   }
-  if (nsamp > 0) {  // 1/pwgt for every main-loop step (src/mcpar.cc:186-187), correctly rounded on the host
-    std::vector<float> wt((size_t)nsamp);
-    for (int i = 0; i < nsamp; ++i) wt[(size_t)i] = 1.0f / (float)(i + 1);
+  if ((size_t)nsamp > e->h_winv.size()) {  // 1/pwgt for every main-loop step (src/mcpar.cc:186-187),
+    HIPCHK(hipStreamSynchronize(st));      // correctly rounded on the host; rebuilt only when it grows
+    e->h_winv.resize((size_t)nsamp);
+    for (int i = 0; i < nsamp; ++i) e->h_winv[(size_t)i] = 1.0f / (float)(i + 1);
     MCXCHK(e->winv_tab.alloc((size_t)nsamp));
-    HIPCHK(hipMemcpyAsync(e->winv_tab.p, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpyAsync(e->winv_tab.p, e->h_winv.data(), e->h_winv.size() * sizeof(float), hipMemcpyHostToDevice, st));
   }
   e->cnt = mcx_counters{};
   e->published_steps = 0;
   HIPCHK(hipMemsetAsync(e->ctr.p, 0, 8 * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(e->acc_slots.p, 0, (size_t)e->nslots * sizeof(uint32_t), st));
   HIPCHK(hipMemsetAsync(e->ntrace.p, 0, sizeof(int), st));
   HIPCHK(hipMemsetAsync(e->acc_cnt.p, 0, (size_t)n * sizeof(uint32_t), st));
-  HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
-  HIPCHK(hipStreamSynchronize(st));
+  // pinit is pageable caller memory: the runtime stages it before hipMemcpyAsync returns
+  if (pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
+  else HIPCHK(hipMemcpyAsync(e->pvals.p, e->pinit_dev.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToDevice, st));
   MCXCHK(eval_trials(e, e->pvals.p, e->lylast.p, 0));  // :53
   const bool fused = e->opt_fuse && e->lik.fusable();
   const uint32_t g0 = (uint32_t)(e->rank * n);
 
   SegArgs sa;
   sa.x = e->pvals.p; sa.ly = e->lylast.p; sa.mu = e->mu.p; sa.psum2 = e->psum2.p;
-  sa.acc_cnt = e->acc_cnt.p; sa.T = e->cov.p; sa.lik = e->lik.params.p; sa.ncomp = e->lik.ncomp;
+  sa.acc_cnt = e->acc_cnt.p; sa.acc_slots = e->acc_slots.p; sa.T = e->cov.p; sa.lik = e->lik.params.p; sa.ncomp = e->lik.ncomp;
   sa.n = n; sa.d = d; sa.g0 = g0; sa.seed = e->seed; sa.diag = e->diag ? 1 : 0; sa.vec4 = e->vec4;
   sa.winv = e->winv_tab.p;
   sa.musig_own = e->musigall.p + 2 * (size_t)e->rank * e->ntot;
@@ -738,7 +747,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     const int steps = last - isamp + 1;
     const uint32_t t0 = e->tbase + (uint32_t)isamp;
     if (fused) {
-      sa.acc_total = e->ctr.p; sa.samp_x = sa.samp_ly = nullptr;
+      sa.samp_x = sa.samp_ly = nullptr;
       sa.mask = e->opt_mask ? e->mask.p + (size_t)isamp * n : nullptr;
       sa.nsteps = steps; sa.t0 = t0; sa.isamp0 = 0;
       ProfScope ps(e, MCX_K_FUSED_BURN, (uint64_t)steps * n);
@@ -757,7 +766,8 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       ProfScope ps(e, MCX_K_TUNER, 0);
       hipLaunchKernelGGL(k_tuner, dim3(1), dim3(BLOCK), 0, st, e->ctr.p, e->cov.p, e->ncov,
                          (unsigned long long)steps * (unsigned long long)n, check, e->TGT_ARATE_MIN,
-                         e->TGT_ARATE_MAX, e->SCALE_DEC, e->SCALE_INC, e->trace.p, e->ntrace.p);
+                         e->TGT_ARATE_MAX, e->SCALE_DEC, e->SCALE_INC, e->trace.p, e->ntrace.p, e->acc_slots.p,
+                         e->nslots);
       HIPCHK(hipGetLastError());
     }
     if (check) irate += 50;
@@ -822,7 +832,6 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       ++steps;
     }
     if (fused) {
-      sa.acc_total = e->ctr.p + 4;
       sa.samp_x = e->opt_samples ? e->samp_x.p + (size_t)isamp * e->ntot : nullptr;
       sa.samp_ly = e->opt_samples ? e->samp_ly.p + (size_t)isamp * n : nullptr;
       sa.mask = e->opt_mask ? e->mask.p + (size_t)(nburn + isamp) * n : nullptr;
@@ -860,6 +869,8 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
                        e->sig.p, (size_t)e->ntot, 1.0f / (float)nsamp);
     HIPCHK(hipGetLastError());
   }
+  hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, e->ctr.p + 4);
+  HIPCHK(hipGetLastError());
   unsigned long long hctr[8];
   HIPCHK(hipMemcpyAsync(hctr, e->ctr.p, sizeof hctr, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -873,6 +884,16 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   prof_collect(e);
   if (e->ofn && e->ofn(e->octx, nsamp) != 0) return fail(MCX_ERR_INVALID, "output hook failed");  // :212
   return MCX_OK;  // :213
+}
+
+extern "C" int mcx_stage_pinit(mcx_engine *e, const float *pinit)
+{
+  if (!e || !pinit) return fail(MCX_ERR_INVALID, "bad arguments");
+  MCXCHK(e->pinit_dev.alloc((size_t)e->ntot));
+  HIPCHK(hipMemcpyAsync(e->pinit_dev.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->pinit_staged = true;
+  return MCX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -890,7 +911,11 @@ extern "C" int mcx_vlfunc_eval(const mcx_vlfunc *f, int npset, const float *x, f
   LikDev L;
   hipStream_t st = nullptr;
   int rc = lik_setup(L, f, f->d, st);
-  if (rc != MCX_OK || npset == 0) { L.params.release(); return rc; }
+  if (rc != MCX_OK || npset == 0) {
+    (void)hipDeviceSynchronize();  // the parameter upload reads L.host
+    L.params.release();
+    return rc;
+  }
   DevBuf<float> dx, dy;
   rc = dx.alloc((size_t)npset * f->d);
   if (rc == MCX_OK) rc = dy.alloc((size_t)npset);

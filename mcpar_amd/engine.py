@@ -113,13 +113,21 @@ class Engine:
         self._keep.append(cb)
         check(load().mcx_set_output_hook(self.h, cb, None))
 
-    def run(self, nsamp, nburn, pinit, vl, incov=None):
-        """MCPar::run(nsamp, nburn, pinit, L, outsamples, incov) -- src/mcpar.hh:36-37"""
+    def stage_pinit(self, pinit):
+        """put the initial chain state in HBM ahead of time; run(..., pinit=None, ...) starts from it"""
         pinit = np.ascontiguousarray(pinit, dtype=np.float32).reshape(-1)
         if pinit.size != self.np * self.nc:
             raise ValueError("pinit must have nc*np elements")
+        check(load().mcx_stage_pinit(self.h, _fp(pinit)))
+
+    def run(self, nsamp, nburn, pinit, vl, incov=None):
+        """MCPar::run(nsamp, nburn, pinit, L, outsamples, incov) -- src/mcpar.hh:36-37"""
+        if pinit is not None:
+            pinit = np.ascontiguousarray(pinit, dtype=np.float32).reshape(-1)
+            if pinit.size != self.np * self.nc:
+                raise ValueError("pinit must have nc*np elements")
         ic = None if incov is None else np.ascontiguousarray(incov, dtype=np.float32)
-        check(load().mcx_run(self.h, nsamp, nburn, _fp(pinit), C.byref(vl),
+        check(load().mcx_run(self.h, nsamp, nburn, _fp(pinit) if pinit is not None else None, C.byref(vl),
                              _fp(ic) if ic is not None else None))
         self.nburn, self.nsamp = nburn, nsamp
 

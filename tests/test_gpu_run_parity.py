@@ -158,3 +158,18 @@ def test_second_run_continues_rng():
         eo.run(20, 60, p, vo)
         eg.run(20, 60, p, vg)
     assert_same(eo, eg, "second run")
+
+
+def test_staged_pinit_equals_host_pinit():
+    import mcpar_amd as M
+    d, n = 16, 200
+    p = O.default_pinit(d, n)
+    vg, _k = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    a, b = M.Engine(d, n, pl=0.9), M.Engine(d, n, pl=0.9)
+    a.run(30, 60, p, vg)
+    with pytest.raises(M.McxError):
+        b.run(30, 60, None, vg)  # nothing staged yet
+    b.stage_pinit(p)
+    b.run(30, 60, None, vg)
+    assert np.array_equal(a.state.view(np.uint32), b.state.view(np.uint32))
+    assert np.array_equal(a.samples.view(np.uint32), b.samples.view(np.uint32))
