@@ -126,6 +126,8 @@ enum {
   MCX_OPT_MAX_SEGMENT = 4, /* upper bound on steps per fused launch [default 256] */
   MCX_OPT_PROFILE = 5,     /* 1: bracket every kernel launch with HIP events (slower) */
   MCX_OPT_STREAM = 6,      /* value = hipStream_t to run on (default: engine-owned stream) */
+  MCX_OPT_SAMPLE_STRIDE = 8, /* k >= 1: keep only main-loop steps with isamp % k == 0 in the sample store
+                              (thinning; the reference keeps every step, k = 1) [default 1] */
   MCX_OPT_EAGER_EXCHANGE = 7 /* 0 [default]: gather the latest sync-point snapshot only when a Murray step (or
                               the end of the run) will read it -- bit-identical to 1: gather at every sync
                               point like the reference (src/mcpar.cc:127-140), overlapped with compute */

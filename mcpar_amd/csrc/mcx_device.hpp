@@ -232,7 +232,9 @@ struct SegArgs {
   uint32_t *acc_cnt;
   uint32_t *acc_slots;  // [number of wavefronts] accepted proposals, one plain slot per wavefront
   const float *T;
-  float *samp_x, *samp_ly;  // sample store rows of the segment's first step, or null
+  float *samp_x, *samp_ly;  // sample store rows of the segment's first step (stride 1) / of the run's
+                            // step 0 (stride > 1), or null
+  int samp_stride;          // keep main-loop steps with isamp % samp_stride == 0
   uint8_t *mask;            // accept mask row of the segment's first step, or null
   const float *lik;
   int ncomp;
@@ -311,8 +313,17 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
         store_pairs(a.musig_own, chain, d, k0, nv, vec4, mu, sg);
       }
       if (a.samp_x) {  // src/mcpar.cc:177-182
-        store_block(a.samp_x, (size_t)s * a.n + chain, d, k0, nv, vec4, x);
-        if (q == 0) a.samp_ly[(size_t)s * a.n + chain] = ly;
+        size_t row = (size_t)s;
+        bool keep = true;
+        if (a.samp_stride > 1) {
+          const int is = a.isamp0 + s;
+          keep = is % a.samp_stride == 0;
+          row = (size_t)(is / a.samp_stride);
+        }
+        if (keep) {
+          store_block(a.samp_x, row * a.n + chain, d, k0, nv, vec4, x);
+          if (q == 0) a.samp_ly[row * a.n + chain] = ly;
+        }
       }
     }
   }
@@ -457,10 +468,16 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
         slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
       }
       if (sx) {  // src/mcpar.cc:177-182
-        if (live) *reinterpret_cast<float4 *>(sx) = make_float4(xe.x, xo.x, xe.y, xo.y);
-        if (q == 0) *sl = ly;
-        sx += sx_stride;
-        sl += sl_stride;
+        if (a.samp_stride <= 1) {
+          if (live) *reinterpret_cast<float4 *>(sx) = make_float4(xe.x, xo.x, xe.y, xo.y);
+          if (q == 0) *sl = ly;
+          sx += sx_stride;
+          sl += sl_stride;
+        } else if ((a.isamp0 + s) % a.samp_stride == 0) {  // thinned store: row = isamp / stride
+          const size_t row = (size_t)((a.isamp0 + s) / a.samp_stride);
+          if (live) *reinterpret_cast<float4 *>(sx + row * sx_stride) = make_float4(xe.x, xo.x, xe.y, xo.y);
+          if (q == 0) sl[row * sl_stride] = ly;
+        }
       }
     }
   }
@@ -919,6 +936,18 @@ __global__ void k_square(float *v, size_t n)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = v[i] * v[i];
+}
+
+// MCout row format (src/mcout.cc:129-137): (np parameters, log-likelihood) per (step, chain)
+__global__ void k_rows_interleave(const float *__restrict__ sx, const float *__restrict__ sl,
+                                  float *__restrict__ rows, size_t nrows, int d)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ncol = (size_t)d + 1;
+  if (i >= nrows * ncol) return;
+  const size_t r = i / ncol;
+  const int c = (int)(i - r * ncol);
+  rows[i] = c < d ? sx[r * d + c] : sl[r];
 }
 
 // test hooks -----------------------------------------------------------------------------------

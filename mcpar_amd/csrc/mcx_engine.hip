@@ -332,6 +332,7 @@ struct mcx_engine {
   // run bookkeeping
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  int opt_stride = 1;
   int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0;
   int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
   bool have_run = false, diag = true, xchg_pending = false;
@@ -473,6 +474,10 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
   switch (opt) {
   case MCX_OPT_SAMPLES: e->opt_samples = value ? 1 : 0; break;
+  case MCX_OPT_SAMPLE_STRIDE:
+    if (value < 1) return fail(MCX_ERR_INVALID, "SAMPLE_STRIDE must be >= 1");
+    e->opt_stride = (int)std::min<int64_t>(value, 1 << 30);
+    break;
   case MCX_OPT_ACCEPT_MASK: e->opt_mask = value ? 1 : 0; break;
   case MCX_OPT_FUSE: e->opt_fuse = value ? 1 : 0; break;
   case MCX_OPT_MAX_SEGMENT:
@@ -547,8 +552,9 @@ static void fill_step(mcx_engine *e, StepArgs &a, uint32_t t, int isamp, bool ma
   a.acc_cnt = e->acc_cnt.p;
   a.acc_slots = e->acc_slots.p;
   a.T = e->cov.p;
-  a.samp_x = (main && e->opt_samples) ? e->samp_x.p + (size_t)samprow * e->ntot : nullptr;
-  a.samp_ly = (main && e->opt_samples) ? e->samp_ly.p + (size_t)samprow * e->nchain : nullptr;
+  const bool keep = main && e->opt_samples && samprow % e->opt_stride == 0;
+  a.samp_x = keep ? e->samp_x.p + (size_t)(samprow / e->opt_stride) * e->ntot : nullptr;
+  a.samp_ly = keep ? e->samp_ly.p + (size_t)(samprow / e->opt_stride) * e->nchain : nullptr;
   a.mask = e->opt_mask ? e->mask.p + maskrow * (size_t)e->nchain : nullptr;
   a.lik = e->lik.params.p; a.ncomp = e->lik.ncomp;
   a.n = e->nchain; a.d = e->nparam;
@@ -701,11 +707,12 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   MCXCHK(covar_install(e, incov, nullptr, false));  // src/mcpar.cc:20
   // sample store: every chain, every main-loop step (src/mcpar.cc:31-40, 177-182), kept in HBM
   e->samp_steps = 0;
+  const int nkeep = (nsamp + e->opt_stride - 1) / e->opt_stride;  // kept steps: isamp % stride == 0
   if (e->opt_samples && nsamp > 0) {
-    int s1 = e->samp_x.alloc((size_t)nsamp * e->ntot), s2 = e->samp_ly.alloc((size_t)nsamp * n);
+    int s1 = e->samp_x.alloc((size_t)nkeep * e->ntot), s2 = e->samp_ly.alloc((size_t)nkeep * n);
     if (s1 != MCX_OK || s2 != MCX_OK)
       return fail(MCX_ERR_ALLOC, "Unable to allocate space for output samples (%zu bytes)",
-                  (size_t)nsamp * n * (d + 1) * sizeof(float));
+                  (size_t)nkeep * n * (d + 1) * sizeof(float));
   }
   if (e->opt_mask) {
     MCXCHK(e->mask.alloc((size_t)(nburn + nsamp) * n));
@@ -736,6 +743,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   sa.acc_cnt = e->acc_cnt.p; sa.acc_slots = e->acc_slots.p; sa.T = e->cov.p; sa.lik = e->lik.params.p; sa.ncomp = e->lik.ncomp;
   sa.n = n; sa.d = d; sa.g0 = g0; sa.seed = e->seed; sa.diag = e->diag ? 1 : 0; sa.vec4 = e->vec4;
   sa.winv = e->winv_tab.p;
+  sa.samp_stride = e->opt_stride;
   sa.musig_own = e->musigall.p + 2 * (size_t)e->rank * e->ntot;
   sa.snap_after = -1;
 
@@ -794,7 +802,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
     if (isamp % outstep == 0 && isamp > 0 && e->ofn) {  // :115-119
       HIPCHK(hipStreamSynchronize(st));
-      e->samp_steps = isamp;
+      e->samp_steps = e->opt_samples ? (isamp + e->opt_stride - 1) / e->opt_stride : 0;
       if (e->ofn(e->octx, isamp) != 0) return fail(MCX_ERR_INVALID, "output hook failed");
     }
     if (sharded && isamp % e->SYNCSTEP == 0) {  // :127-140
@@ -832,8 +840,9 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       ++steps;
     }
     if (fused) {
-      sa.samp_x = e->opt_samples ? e->samp_x.p + (size_t)isamp * e->ntot : nullptr;
-      sa.samp_ly = e->opt_samples ? e->samp_ly.p + (size_t)isamp * n : nullptr;
+      const size_t row0 = e->opt_stride == 1 ? (size_t)isamp : 0;  // thinned: the kernel indexes from step 0
+      sa.samp_x = e->opt_samples ? e->samp_x.p + row0 * e->ntot : nullptr;
+      sa.samp_ly = e->opt_samples ? e->samp_ly.p + row0 * n : nullptr;
       sa.mask = e->opt_mask ? e->mask.p + (size_t)(nburn + isamp) * n : nullptr;
       sa.nsteps = steps; sa.t0 = t; sa.isamp0 = isamp;
       sa.snap_after = -1;
@@ -876,7 +885,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   HIPCHK(hipStreamSynchronize(st));
   e->cnt.naccept_burn = hctr[3];
   e->cnt.naccept_main = hctr[4];
-  e->samp_steps = e->opt_samples ? nsamp : 0;
+  e->samp_steps = e->opt_samples ? nkeep : 0;
   e->last_nsamp = nsamp;
   e->last_nburn = nburn;
   e->have_run = true;
@@ -1033,20 +1042,56 @@ extern "C" int mcx_samples_steps(mcx_engine *e, int *nsteps)
   return MCX_OK;
 }
 
+// Rows are interleaved into MCout's (np+1)-column layout on the device, moved through two pinned
+// staging buffers (the D2H of chunk k+1 overlaps the host copy of chunk k) and land in the caller's
+// pageable buffer.  Off the hot path: this is the MCout::add / collect side of the boundary.
 extern "C" int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float *rows)
 {
   if (!e || !rows || first_step < 0 || nsteps < 0) return fail(MCX_ERR_INVALID, "bad arguments");
   if (first_step + nsteps > e->samp_steps) return fail(MCX_ERR_INVALID, "steps [%d,%d) not in the sample store (%d steps)", first_step, first_step + nsteps, e->samp_steps);
-  const size_t n = (size_t)e->nchain, d = (size_t)e->nparam, nr = (size_t)nsteps * n;
+  const size_t n = (size_t)e->nchain, d = (size_t)e->nparam, ncol = d + 1, nr = (size_t)nsteps * n;
   if (nr == 0) return MCX_OK;
-  std::vector<float> hx(nr * d), hl(nr);
-  MCXCHK(d2h(e, hx.data(), e->samp_x.p + (size_t)first_step * n * d, nr * d));
-  MCXCHK(d2h(e, hl.data(), e->samp_ly.p + (size_t)first_step * n, nr));
-  for (size_t r = 0; r < nr; ++r) {  // MCout row: params then log-likelihood (src/mcout.cc:129-137)
-    std::memcpy(rows + r * (d + 1), hx.data() + r * d, d * sizeof(float));
-    rows[r * (d + 1) + d] = hl[r];
+  const size_t chunk_rows = std::max<size_t>(1, std::min<size_t>(nr, ((size_t)32 << 20) / (ncol * sizeof(float))));
+  DevBuf<float> stage[2];
+  float *pin[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  auto run = [&]() -> int {
+    for (int b = 0; b < 2; ++b) {
+      MCXCHK(stage[b].alloc(chunk_rows * ncol));
+      HIPCHK(hipHostMalloc((void **)&pin[b], chunk_rows * ncol * sizeof(float), hipHostMallocDefault));
+      HIPCHK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+    }
+    const float *sx = e->samp_x.p + (size_t)first_step * n * d, *sl = e->samp_ly.p + (size_t)first_step * n;
+    size_t issued = 0, copied = 0;
+    int ib = 0, cb = 0;
+    size_t rows_in[2] = {0, 0};
+    while (copied < nr) {
+      while (issued < nr && issued - copied < 2 * chunk_rows) {  // keep both buffers in flight
+        const size_t r = std::min(chunk_rows, nr - issued);
+        hipLaunchKernelGGL(k_rows_interleave, dim3(nblocks(r * ncol)), dim3(BLOCK), 0, e->stream, sx + issued * d,
+                           sl + issued, stage[ib].p, r, (int)d);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(pin[ib], stage[ib].p, r * ncol * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipEventRecord(done[ib], e->stream));
+        rows_in[ib] = r;
+        issued += r;
+        ib ^= 1;
+      }
+      HIPCHK(hipEventSynchronize(done[cb]));
+      std::memcpy(rows + copied * ncol, pin[cb], rows_in[cb] * ncol * sizeof(float));
+      copied += rows_in[cb];
+      cb ^= 1;
+    }
+    return MCX_OK;
+  };
+  const int rc = run();
+  (void)hipStreamSynchronize(e->stream);
+  for (int b = 0; b < 2; ++b) {
+    stage[b].release();
+    if (pin[b]) (void)hipHostFree(pin[b]);
+    if (done[b]) (void)hipEventDestroy(done[b]);
   }
-  return MCX_OK;
+  return rc;
 }
 
 extern "C" int mcx_samples_maxlike(mcx_engine *e, float *lmax, float *params)

@@ -173,3 +173,28 @@ def test_staged_pinit_equals_host_pinit():
     b.run(30, 60, None, vg)
     assert np.array_equal(a.state.view(np.uint32), b.state.view(np.uint32))
     assert np.array_equal(a.samples.view(np.uint32), b.samples.view(np.uint32))
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_sample_stride_thins_the_store(fuse):
+    """MCX_OPT_SAMPLE_STRIDE = k keeps main-loop steps 0, k, 2k, ... (same chain, same bits)"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    d, n, nburn, nsamp, k = 16, 130, 60, 47, 3
+    p = O.default_pinit(d, n)
+    vo, _k1 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=0.85)
+    eo.run(nsamp, nburn, p, vo)
+    vg, _k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eg = M.Engine(d, n, pl=0.85)
+    eg.set_option(E.OPT_SAMPLE_STRIDE, k)
+    eg.set_option(E.OPT_FUSE, fuse)
+    eg.run(nsamp, nburn, p, vg)
+    want = eo.samples.reshape(nsamp, n, d + 1)[::k].reshape(-1, d + 1)
+    got = eg.samples
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(eg.state.view(np.uint32), eo.state.view(np.uint32))
+    # partial ranges of the store
+    part = eg.samples_range(2, 5)
+    assert np.array_equal(part, want[2 * n:7 * n])
