@@ -25,11 +25,26 @@ constexpr int MAXD = 256;     // lanes per chain <= 64
 
 enum LikKind : int { LIK_ROSEN1 = 1, LIK_ROSEN2 = 2, LIK_GAUSS = 3, LIK_MIX = 5 };
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the LPC lanes of a chain, every lane gets the result.  Pairing = xor-butterfly over the
+// block index.  Up to 16 lanes it is done with DPP row operations: after the two
+// quad steps every lane of a quad holds the quad's sum, so the mirror steps add the other quad's /
+// other half-row's sum -- the same pairs as xor 4 / xor 8 (addition commutes).  Wider groups finish
+// with LDS-crossbar shuffles.
 template <int LPC>
 __device__ __forceinline__ float group_sum(float p)
 {
+  if (LPC >= 2) p = p + dpp_mov<0xB1>(p);    // quad_perm [1,0,3,2]  == xor 1
+  if (LPC >= 4) p = p + dpp_mov<0x4E>(p);    // quad_perm [2,3,0,1]  == xor 2
+  if (LPC >= 8) p = p + dpp_mov<0x141>(p);   // row_half_mirror      ~  xor 4
+  if (LPC >= 16) p = p + dpp_mov<0x140>(p);  // row_mirror           ~  xor 8
 #pragma unroll
-  for (int s = 1; s < LPC; s <<= 1) p = p + __shfl_xor(p, s);
+  for (int s = 16; s < LPC; s <<= 1) p = p + __shfl_xor(p, s);
   return p;
 }
 
@@ -106,6 +121,20 @@ struct Lik<LIK_MIX, LPC> {  // log sum_c w_c exp(-|x-m_c|^2/2); lik = means[K*d]
   }
   __device__ __forceinline__ float eval(const float xb[4], int nv) const
   {
+    if (K <= 8) {  // keep the component exponents in registers (same values, one evaluation each)
+      float e[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) e[c] = c < K ? comp(xb, nv, c) : 0.0f;
+      float emax = e[0];
+#pragma unroll
+      for (int c = 1; c < 8; ++c)
+        if (c < K) emax = e[c] > emax ? e[c] : emax;
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < K) s = s + expf_v1(e[c] - emax);
+      return emax + logf_v1(s);
+    }
     float emax = comp(xb, nv, 0);
     for (int c = 1; c < K; ++c) {
       const float e = comp(xb, nv, c);
@@ -351,24 +380,6 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
 //   * the lane-group reductions are DPP row operations instead of LDS-crossbar shuffles;
 //   * 1/pwgt comes from a host-built table through a scalar load instead of a VALU division.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-
-// same pairing as the xor-butterfly of group_sum: after the quad steps every lane of a quad holds
-// the quad's sum, so the mirror steps add the other quad's / other half's sum (addition commutes)
-template <int LPC>
-__device__ __forceinline__ float group_sum_dpp(float p)
-{
-  if (LPC >= 2) p = p + dpp_mov<0xB1>(p);   // quad_perm [1,0,3,2]  == xor 1
-  if (LPC >= 4) p = p + dpp_mov<0x4E>(p);   // quad_perm [2,3,0,1]  == xor 2
-  if (LPC >= 8) p = p + dpp_mov<0x141>(p);  // row_half_mirror      ~  xor 4
-  if (LPC >= 16) p = p + dpp_mov<0x140>(p); // row_mirror           ~  xor 8
-  return p;
-}
-
 // value of lane `owner` of this lane's LPC-group (owner is wave-uniform), by DPP
 template <int LPC>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t owner, int q)
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
     const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
     float acc = 0.0f;
     if (live) acc = term.x + term.y;  // == (0 + term.x) + term.y: the terms are >= +0
-    const float lyt = 0.0f - group_sum_dpp<LPC>(acc);
+    const float lyt = 0.0f - group_sum<LPC>(acc);
     // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
     // lanes of a chain split the work: lane q draws block b for b % LPC == q, once per 4*LPC steps.
     const uint32_t blk = t >> 2;
