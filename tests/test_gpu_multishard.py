@@ -12,7 +12,7 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0):
+def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1):
     import mcpar_amd as M
     from mcpar_amd import engine as E
     hip = C.CDLL("libamdhip64.so")
@@ -43,7 +43,7 @@ def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0):
 
     def work(s):
         try:
-            engs[s].set_option(E.OPT_ACCEPT_MASK, 1)
+            engs[s].set_option(E.OPT_ACCEPT_MASK, mask)
             engs[s].set_option(E.OPT_EAGER_EXCHANGE, eager)
             engs[s].set_exchange(make_hook(s))
             engs[s].run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
@@ -92,3 +92,20 @@ def test_missing_exchange_hook_is_an_error():
     with pytest.raises(M.McxError) as ei:
         e.run(5, 5, np.zeros((8, 4), np.float32), vl)
     assert ei.value.code == 6
+
+
+@pytest.mark.parametrize("eager", [0, 1], ids=["lazy", "eager"])
+@pytest.mark.parametrize("pl", [0.8, 1.0])
+def test_multishard_hot_path_kernel(pl, eager):
+    """without accept-mask recording the hot-path kernel runs (incl. its in-kernel exchange snapshot)"""
+    d, n, nshards, nburn, nsamp = 16, 160, 2, 120, 75
+    vo, keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl) for s in range(nshards)]
+    O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, eager=eager, mask=0)
+    for s in range(nshards):
+        eo, eg = eos[s], egs[s]
+        c = eg.counters
+        assert c["naccept_main"] == eo.naccept_main and c["remote_passes"] == eo.remote_passes
+        for name in ("state", "mean", "var", "samples", "musigall"):
+            assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name

@@ -198,3 +198,25 @@ def test_sample_stride_thins_the_store(fuse):
     # partial ranges of the store
     part = eg.samples_range(2, 5)
     assert np.array_equal(part, want[2 * n:7 * n])
+
+
+@pytest.mark.parametrize("kind,d", [(O.VL_ROSENBROCK1, 16), (O.VL_GAUSSIAN, 8), (O.VL_GAUSSIAN, 32), (O.VL_GAUSSIAN, 12)])
+def test_fast_kernel_without_mask_recording(kind, d):
+    """the hot-path kernel is used only when no accept mask is recorded: compare everything else"""
+    import mcpar_amd as M
+    n, nburn, nsamp = 333, 120, 40
+    p = O.default_pinit(d, n)
+    params = None
+    if kind == O.VL_GAUSSIAN:
+        params = np.concatenate([np.linspace(-1, 1, d), np.linspace(0.5, 2, d)]).astype(np.float32)
+    vo, _k1 = O.make_vlfunc(kind, d, params)
+    eo = O.Engine(d, n, pl=0.9)
+    eo.run(nsamp, nburn, p, vo)
+    vg, _k2 = M.make_vlfunc(kind, d, params)
+    eg = M.Engine(d, n, pl=0.9)
+    eg.run(nsamp, nburn, p, vg)
+    c = eg.counters
+    assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+    np.testing.assert_array_equal(eg.accept_counts, eo.accept_counts)
+    for name in ("state", "loglike", "mean", "var", "musigall", "samples", "chol"):
+        assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
