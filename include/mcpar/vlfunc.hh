@@ -26,4 +26,25 @@ public:
   virtual bool device_descriptor(int /*np*/, mcx_vlfunc * /*out*/) const { return false; }
 };
 
+// A likelihood supplied as a GPU kernel from the user's own code object (MCX_VL_DEVICE):
+//   extern "C" __global__ void f(int npset, const float *x, float *y);
+// kernel = the hipFunction_t from hipModuleGetFunction.  Keeps the whole step on the device.
+class DeviceVLFunc : public VLFunc {
+  const int n;
+  void *kernel;
+public:
+  DeviceVLFunc(int np, void *hip_function) : n(np), kernel(hip_function) {}
+  bool device_descriptor(int, mcx_vlfunc *o) const
+  {
+    *o = mcx_vlfunc{MCX_VL_DEVICE, n, 0, 0, 0, kernel};
+    return true;
+  }
+  int operator()(int npset, const float *x, float *restrict y)
+  {
+    mcx_vlfunc f;
+    device_descriptor(n, &f);
+    return mcx_vlfunc_eval(&f, npset, x, y) == MCX_OK ? 0 : 1;
+  }
+};
+
 #endif

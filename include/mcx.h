@@ -45,7 +45,8 @@ enum {
   MCX_VL_GAUSSIAN = 3,    /* Gaussian::operator()     src/rosenbrock.cc:44-61  any d      (fused) */
   MCX_VL_DUALGAUSS = 4,   /* DualGaussian::operator() src/rosenbrock.cc:63-78             (fused) */
   MCX_VL_GAUSSMIX = 5,    /* N-D K-component unit-variance mixture (BASELINE config 5)    (fused) */
-  MCX_VL_HOST = 100       /* any user VLFunc subclass: device -> host callback -> device  */
+  MCX_VL_HOST = 100,      /* any user VLFunc subclass: device -> host callback -> device  */
+  MCX_VL_DEVICE = 101     /* user likelihood as a GPU kernel: stays on the device (see mcx_vlfunc.ctx) */
 };
 
 /* same contract as VLFunc::operator()(int npset, const float *x, float *restrict y): x is
@@ -60,7 +61,11 @@ typedef struct mcx_vlfunc {
   const float *params; /* GAUSSIAN: mu[d], sig2[d] (NULL = standard normal); DUALGAUSS: w;
                           GAUSSMIX: means[K*d], weights[K].  Copied by mcx_run. */
   mcx_host_fn fn;      /* HOST */
-  void *ctx;           /* HOST */
+  void *ctx;           /* HOST: passed to fn.  DEVICE: a hipFunction_t (from the caller's own code object,
+                          hipModuleGetFunction) of a kernel with the VLFunc contract on device memory,
+                            extern "C" __global__ void f(int npset, const float *x, float *y);
+                          launched with 256-thread blocks, ceil(npset / 256) blocks, on the engine's
+                          stream; thread i evaluates parameter set i (or any mapping covering all sets). */
 } mcx_vlfunc;
 
 /* batched likelihood on host buffers: the VLFunc call itself, runs the device kernel */

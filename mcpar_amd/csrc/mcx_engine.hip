@@ -210,6 +210,11 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
     L.fn = f->fn;
     L.ctx = f->ctx;
     break;
+  case MCX_VL_DEVICE:
+    if (!f->ctx) return fail(MCX_ERR_VLFUNC, "MCX_VL_DEVICE without a kernel (hipFunction_t in ctx)");
+    L.kind = MCX_VL_DEVICE;
+    L.ctx = f->ctx;
+    break;
   default:
     return fail(MCX_ERR_INVALID, "unknown vlfunc kind %d", f->kind);
   }
@@ -545,6 +550,14 @@ static int eval_trials(mcx_engine *e, const float *x_dev, float *y_dev, uint64_t
     return MCX_OK;
   }
   ProfScope ps(e, MCX_K_EVAL, cs);
+  if (e->lik.kind == MCX_VL_DEVICE) {  // the user's own kernel, VLFunc contract on device memory
+    int npset = n;
+    const float *xa = x_dev;
+    float *ya = y_dev;
+    void *args[] = {&npset, &xa, &ya};
+    HIPCHK(hipModuleLaunchKernel((hipFunction_t)e->lik.ctx, nblocks((size_t)n), 1, 1, BLOCK, 1, 1, 0, e->stream, args, nullptr));
+    return MCX_OK;
+  }
   return eval_device(e->lik, x_dev, y_dev, n, d, e->stream);
 }
 
@@ -925,6 +938,26 @@ extern "C" int mcx_vlfunc_eval(const mcx_vlfunc *f, int npset, const float *x, f
   LikDev L;
   hipStream_t st = nullptr;
   int rc = lik_setup(L, f, f->d, st);
+  if (rc == MCX_OK && L.kind == MCX_VL_DEVICE) {
+    DevBuf<float> ux, uy;
+    rc = ux.alloc((size_t)std::max(npset, 1) * f->d);
+    if (rc == MCX_OK) rc = uy.alloc((size_t)std::max(npset, 1));
+    if (rc == MCX_OK && npset > 0) {
+      auto run = [&]() -> int {
+        HIPCHK(hipMemcpy(ux.p, x, (size_t)npset * f->d * sizeof(float), hipMemcpyHostToDevice));
+        const float *xa = ux.p;
+        float *ya = uy.p;
+        void *args[] = {&npset, &xa, &ya};
+        HIPCHK(hipModuleLaunchKernel((hipFunction_t)L.ctx, nblocks((size_t)npset), 1, 1, BLOCK, 1, 1, 0, st, args, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(y, uy.p, (size_t)npset * sizeof(float), hipMemcpyDeviceToHost));
+        return MCX_OK;
+      };
+      rc = run();
+    }
+    ux.release(); uy.release();
+    return rc;
+  }
   if (rc != MCX_OK || npset == 0) {
     (void)hipDeviceSynchronize();  // the parameter upload reads L.host
     L.params.release();

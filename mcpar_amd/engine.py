@@ -6,6 +6,7 @@ import numpy as np
 from ._lib import (HOSTFN, K_NAMES, OUTFN, XCHGFN, Counters, Profile, VLFunc, check, load)
 
 VL_ROSENBROCK1, VL_ROSENBROCK2, VL_GAUSSIAN, VL_DUALGAUSS, VL_GAUSSMIX, VL_HOST = 1, 2, 3, 4, 5, 100
+VL_DEVICE = 101
 OPT_SAMPLES, OPT_ACCEPT_MASK, OPT_FUSE, OPT_MAX_SEGMENT, OPT_PROFILE, OPT_STREAM, OPT_EAGER_EXCHANGE = 1, 2, 3, 4, 5, 6, 7
 OPT_SAMPLE_STRIDE = 8
 XCHG_BEGIN, XCHG_WAIT = 0, 1
@@ -15,8 +16,9 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def make_vlfunc(kind, d, params=None, ncomp=0, host_fn=None):
-    """Build an mcx_vlfunc.  host_fn(x[npset, d]) -> y[npset] wraps a user VLFunc (src/vlfunc.hh:9-12).
+def make_vlfunc(kind, d, params=None, ncomp=0, host_fn=None, device_fn=None):
+    """Build an mcx_vlfunc.  host_fn(x[npset, d]) -> y[npset] wraps a user VLFunc (src/vlfunc.hh:9-12);
+    device_fn is a hipFunction_t (int) of a user kernel f(int npset, const float *x, float *y).
     Returns (struct, keepalive)."""
     p = None if params is None else np.ascontiguousarray(params, dtype=np.float32)
     cb = HOSTFN()
@@ -27,7 +29,8 @@ def make_vlfunc(kind, d, params=None, ncomp=0, host_fn=None):
             ya[:] = np.asarray(host_fn(xa), dtype=np.float32)
             return 0
         cb = HOSTFN(tramp)
-    v = VLFunc(kind, d, ncomp, _fp(p) if p is not None else None, cb, None)
+    v = VLFunc(kind, d, ncomp, _fp(p) if p is not None else None, cb,
+               C.c_void_p(device_fn) if device_fn is not None else None)
     return v, (p, cb)
 
 
