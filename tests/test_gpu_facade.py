@@ -91,3 +91,34 @@ def test_mcpar_run_driver_flags(tmp_path):
     r = subprocess.run([os.path.join(DRV, "mcpar-run"), "--func", "rosen1", "--np", "3"], cwd=tmp_path,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "must be even" in r.stderr
+
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.skipif(not os.path.exists(MPIEXEC), reason="no MPI launcher in this image")
+def test_two_mpi_ranks_through_the_facade(tmp_path):
+    """the reference's process model: mpiexec -n 2, one rank per shard (both on this one GPU), the
+    MPI_Allgather of src/mcpar.cc:127-140 staged through the exchange hook; stdout = MCout::output's
+    rank-major dumps (src/mcout.cc:62-69) and must equal the oracle's two-shard run"""
+    r = subprocess.run(["make", "-C", DRV, "mpi"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("MPI build not available: " + r.stderr[-300:])
+    np_, nc, nsamp, nburn, pl = 8, 32, 40, 60, 0.8
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([MPIEXEC, "-n", "2", os.path.join(DRV, "mcpar-run-mpi"), "--func", "rosen1", "--np", str(np_),
+                        "--nc", str(nc), "--nsamp", str(nsamp), "--nburn", str(nburn), "--pl", str(pl)],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vl, keep = O.make_vlfunc(O.VL_ROSENBROCK1, np_)
+    engs = [O.Engine(np_, nc, nshards=2, shard=s, pl=pl) for s in range(2)]
+    O.run_all(engs, nsamp, nburn, [O.default_pinit(np_, nc, g0=s * nc) for s in range(2)], vl)
+    assert engs[0].remote_steps > 0
+    outstep = nsamp // 10 if nsamp > 50 else 5
+    bounds = [s for s in range(outstep, nsamp, outstep)] + [nsamp]
+    expect, lo = "", 0
+    for hi in bounds:  # each dump: rank 0's new rows, then rank 1's
+        for e in engs:
+            expect += fmt_rows(e.samples[lo * nc:hi * nc])
+        lo = hi
+    assert r.stdout == expect
