@@ -129,6 +129,7 @@ struct DevBuf {
     if (count == 0) count = 1;
     hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
     if (e != hipSuccess) {
+      (void)hipGetLastError();  // clear the sticky error: later launch checks must not see it
       p = nullptr;
       n = 0;
       return fail(MCX_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
