@@ -166,6 +166,31 @@ int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float *rows);
 /* running maximum-likelihood sample of this shard (MCout::add's maxlval, src/mcout.cc:140-144) */
 int mcx_samples_maxlike(mcx_engine *e, float *lmax, float *params);
 
+/* ---- the schedule of one run (host logic only, no device needed) --------------------------
+ * mcx_run cuts MCPar::run's two loops (src/mcpar.cc:55-97, 99-210) into device launches between the
+ * events it knows in advance: tuner checks, output dumps, exchanges and -- because the local/remote
+ * coin is counter-based -- Murray steps.  mcx_plan returns exactly the item list mcx_run executes. */
+enum {
+  MCX_PLAN_BURN_SEGMENT = 1, /* first, nsteps: consecutive burn-in steps in one launch */
+  MCX_PLAN_TUNER = 2,        /* first = last step of the segment, nsteps, aux = 1 if the tuner decides here */
+  MCX_PLAN_INIT_MOMENTS = 3,
+  MCX_PLAN_OUTPUT = 4,       /* first = main-loop steps completed (output hook) */
+  MCX_PLAN_PUBLISH = 5,      /* first = steps completed: write this shard's (mu, sig^2) slot */
+  MCX_PLAN_GATHER_BEGIN = 6, /* exchange hook, MCX_XCHG_BEGIN */
+  MCX_PLAN_GATHER_WAIT = 7,  /* exchange hook, MCX_XCHG_WAIT */
+  MCX_PLAN_REMOTE_STEP = 8,  /* first = isamp of a Murray (genRemote) step */
+  MCX_PLAN_MAIN_SEGMENT = 9  /* first, nsteps: consecutive local main-loop steps in one launch;
+                                aux = local step after which the kernel snapshots the slot, or -1 */
+};
+typedef struct mcx_plan_item {
+  int kind, first, nsteps, aux;
+} mcx_plan_item;
+/* tbase = steps consumed by earlier runs of the engine (0 for a fresh one).  items may be NULL to
+ * query the count. */
+int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed, uint32_t tbase, int nshards,
+             int eager, int fused, int max_segment, int has_output_hook, mcx_plan_item *items,
+             int max_items, int *nitems);
+
 /* ---- profiling (MCX_OPT_PROFILE) ---------------------------------------------------------- */
 enum { MCX_K_FUSED_BURN = 0, MCX_K_FUSED_MAIN, MCX_K_PROPOSE, MCX_K_EVAL, MCX_K_ACCEPT,
        MCX_K_REMOTE, MCX_K_TUNER, MCX_K_MISC, MCX_K_COUNT };

@@ -29,6 +29,10 @@ class Counters(C.Structure):
 K_NAMES = ("fused_burn", "fused_main", "propose", "eval", "accept", "remote", "tuner", "misc")
 
 
+class PlanItem(C.Structure):
+    _fields_ = [("kind", C.c_int), ("first", C.c_int), ("nsteps", C.c_int), ("aux", C.c_int)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("chain_steps", C.c_uint64 * 8)]
 
@@ -76,6 +80,8 @@ def load():
         "mcx_get_profile": [vp, C.POINTER(Profile)],
         "mcx_copy_to_host": [vp, vp, C.c_size_t, vp],
         "mcx_copy_to_device": [vp, vp, C.c_size_t, vp],
+        "mcx_plan": [C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                     C.c_int, C.c_int, C.POINTER(PlanItem), C.c_int, C.POINTER(C.c_int)],
         "mcx_abi_version": [],
         "mcx_device_info": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
         "mcx_set_device": [C.c_int],

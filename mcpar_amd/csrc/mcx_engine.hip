@@ -705,12 +705,108 @@ static int exchange_begin(mcx_engine *e)
   return MCX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Schedule of one run(): pure host logic (no device), exported as mcx_plan() so that it can be
+// tested without a GPU.  It is what mcx_run executes.
+// ---------------------------------------------------------------------------------------------
+struct PlanCfg {
+  int nsamp, nburn, sync;
+  float pl;
+  uint32_t seed, tbase;
+  bool sharded, eager, fused, output_hook;
+  int maxseg;
+};
+
 // one Philox draw per step for the whole job (the reference draws per rank: src/mcpar.cc:142-146)
-static inline bool step_is_remote(const mcx_engine *e, int isamp, uint32_t t)
+static inline bool coin_is_remote(const PlanCfg &c, int isamp)
 {
-  if (isamp < e->SYNCSTEP) return false;
-  const float rndlocal = u24(philox4x32_10(t, 0u, 0u, 0u, e->seed, ST_COIN).x);
-  return !(rndlocal <= e->PLOCAL);
+  if (isamp < c.sync) return false;  // :143-144
+  const uint32_t t = c.tbase + (uint32_t)c.nburn + (uint32_t)isamp;
+  const float rndlocal = u24(philox4x32_10(t, 0u, 0u, 0u, c.seed, ST_COIN).x);
+  return !(rndlocal <= c.pl);  // :152
+}
+
+static std::vector<mcx_plan_item> build_plan(const PlanCfg &c)
+{
+  std::vector<mcx_plan_item> p;
+  auto add = [&](int kind, int first, int nsteps, int aux) { p.push_back(mcx_plan_item{kind, first, nsteps, aux}); };
+  // burn-in (src/mcpar.cc:55-97): the tuner looks at the counters when isamp > irate, irate = 50, 100, ...
+  int irate = 50;
+  for (int isamp = 0; isamp < c.nburn;) {
+    int last = irate + 1 < c.nburn ? irate + 1 : c.nburn - 1;
+    if (last - isamp + 1 > c.maxseg) last = isamp + c.maxseg - 1;
+    const int steps = last - isamp + 1, check = last > irate ? 1 : 0;
+    add(MCX_PLAN_BURN_SEGMENT, isamp, steps, 0);
+    add(MCX_PLAN_TUNER, last, steps, check);
+    if (check) irate += 50;
+    isamp = last + 1;
+  }
+  if (c.nsamp > 0) add(MCX_PLAN_INIT_MOMENTS, 0, 0, 0);  // :99-104
+  const int outstep = c.nsamp > 50 ? c.nsamp / 10 : 5;  // :110
+  // Exchange schedule.  The reference gathers at every sync point (isamp % SYNCSTEP == 0, :127-140),
+  // but the gathered slots are read only by genRemote, and every gather overwrites all of them: a
+  // gather that is followed by another gather before the next Murray step is dead.  Default (lazy):
+  // snapshot this shard's slot at every sync point, gather the latest snapshot right before a Murray
+  // step reads it (and once at the end) -- bit-identical results, fused segments may span sync points.
+  // eager = the reference's schedule (each gather overlapped with the next segment).
+  bool need_gather = false;
+  for (int isamp = 0; isamp < c.nsamp;) {
+    if (isamp % outstep == 0 && isamp > 0 && c.output_hook) add(MCX_PLAN_OUTPUT, isamp, 0, 0);  // :115-119
+    if (c.sharded && isamp % c.sync == 0) {  // :127-140
+      add(MCX_PLAN_PUBLISH, isamp, 0, 0);
+      if (c.eager) add(MCX_PLAN_GATHER_BEGIN, isamp, 0, 0);
+      else need_gather = true;
+    }
+    if (coin_is_remote(c, isamp)) {  // :152-159
+      if (need_gather) {  // the slot holds the snapshot of the last sync point
+        add(MCX_PLAN_GATHER_BEGIN, isamp, 0, 0);
+        need_gather = false;
+      }
+      if (c.sharded) add(MCX_PLAN_GATHER_WAIT, isamp, 0, 0);
+      add(MCX_PLAN_PUBLISH, isamp, 0, 0);  // own slot is always current (:205-208)
+      add(MCX_PLAN_REMOTE_STEP, isamp, 1, 0);
+      ++isamp;
+      continue;
+    }
+    // run of local steps up to the next output dump / Murray step (/ sync point when eager or unfused)
+    const bool span_sync = c.fused && c.sharded && !c.eager;
+    int steps = 1;
+    while (isamp + steps < c.nsamp && steps < c.maxseg) {
+      const int nx = isamp + steps;
+      if (nx % outstep == 0 && c.output_hook) break;
+      if (c.sharded && !span_sync && nx % c.sync == 0) break;
+      if (coin_is_remote(c, nx)) break;
+      ++steps;
+    }
+    int snap_after = -1;
+    if (span_sync) {  // last sync point strictly inside the segment: the kernel snapshots the slot there
+      const int last = ((isamp + steps - 1) / c.sync) * c.sync;
+      if (last > isamp) {
+        snap_after = last - 1 - isamp;
+        need_gather = true;
+      }
+    }
+    add(MCX_PLAN_MAIN_SEGMENT, isamp, steps, snap_after);
+    isamp += steps;
+  }
+  if (need_gather) add(MCX_PLAN_GATHER_BEGIN, c.nsamp, 0, 0);  // remote slots end as of the last sync point
+  if (c.sharded) add(MCX_PLAN_GATHER_WAIT, c.nsamp, 0, 0);
+  add(MCX_PLAN_PUBLISH, c.nsamp, 0, 0);
+  return p;
+}
+
+extern "C" int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed, uint32_t tbase, int nshards,
+                        int eager, int fused, int max_segment, int has_output_hook, mcx_plan_item *items,
+                        int max_items, int *nitems)
+{
+  if (nsamp < 0 || nburn < 0 || sync < 1 || nshards < 1 || max_segment < 1 || !nitems)
+    return fail(MCX_ERR_INVALID, "bad arguments");
+  const PlanCfg c = {nsamp, nburn, sync, pl, seed, tbase, nshards > 1, eager != 0, fused != 0, has_output_hook != 0, max_segment};
+  const std::vector<mcx_plan_item> p = build_plan(c);
+  *nitems = (int)p.size();
+  if (items)
+    for (int i = 0; i < (int)p.size() && i < max_items; ++i) items[i] = p[(size_t)i];
+  return MCX_OK;
 }
 
 extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L,
@@ -766,76 +862,55 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   sa.musig_own = e->musigall.p + 2 * (size_t)e->rank * e->ntot;
   sa.snap_after = -1;
 
-  // ---- burn-in (src/mcpar.cc:55-97) ----
-  int irate = 50;
-  for (int isamp = 0; isamp < nburn;) {
-    int last = irate + 1 < nburn ? irate + 1 : nburn - 1;  // tuner looks at isamp > irate
-    if (last - isamp + 1 > e->opt_maxseg) last = isamp + e->opt_maxseg - 1;
-    const int steps = last - isamp + 1;
-    const uint32_t t0 = e->tbase + (uint32_t)isamp;
-    if (fused) {
-      sa.samp_x = sa.samp_ly = nullptr;
-      sa.mask = e->opt_mask ? e->mask.p + (size_t)isamp * n : nullptr;
-      sa.nsteps = steps; sa.t0 = t0; sa.isamp0 = 0;
-      ProfScope ps(e, MCX_K_FUSED_BURN, (uint64_t)steps * n);
-      DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, false, sa, st))));
-    } else {
-      for (int s = 0; s < steps; ++s) {
-        StepArgs a;
-        fill_step(e, a, t0 + (uint32_t)s, 0, false, (size_t)(isamp + s), 0, 0);
-        MCXCHK(launch_propose(e, a));
-        MCXCHK(eval_trials(e, e->ptrial.p, e->lytrial.p, (uint64_t)n));
-        MCXCHK(launch_accept(e, a, false));
+  const PlanCfg cfg = {nsamp, nburn, e->SYNCSTEP, e->PLOCAL, e->seed, e->tbase, e->size > 1, e->opt_eager != 0,
+                       fused, e->ofn != nullptr, e->opt_maxseg};
+  const std::vector<mcx_plan_item> plan = build_plan(cfg);
+  for (const mcx_plan_item &it : plan) {
+    const int isamp = it.first, steps = it.nsteps;
+    switch (it.kind) {
+    case MCX_PLAN_BURN_SEGMENT: {  // src/mcpar.cc:58-75
+      const uint32_t t0 = e->tbase + (uint32_t)isamp;
+      if (fused) {
+        sa.samp_x = sa.samp_ly = nullptr;
+        sa.mask = e->opt_mask ? e->mask.p + (size_t)isamp * n : nullptr;
+        sa.nsteps = steps; sa.t0 = t0; sa.isamp0 = 0; sa.snap_after = -1;
+        ProfScope ps(e, MCX_K_FUSED_BURN, (uint64_t)steps * n);
+        DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, false, sa, st))));
+      } else {
+        for (int s = 0; s < steps; ++s) {
+          StepArgs a;
+          fill_step(e, a, t0 + (uint32_t)s, 0, false, (size_t)(isamp + s), 0, 0);
+          MCXCHK(launch_propose(e, a));
+          MCXCHK(eval_trials(e, e->ptrial.p, e->lytrial.p, (uint64_t)n));
+          MCXCHK(launch_accept(e, a, false));
+        }
       }
+      break;
     }
-    const int check = last > irate ? 1 : 0;
-    {
+    case MCX_PLAN_TUNER: {  // src/mcpar.cc:77-96
       ProfScope ps(e, MCX_K_TUNER, 0);
       hipLaunchKernelGGL(k_tuner, dim3(1), dim3(BLOCK), 0, st, e->ctr.p, e->cov.p, e->ncov,
-                         (unsigned long long)steps * (unsigned long long)n, check, e->TGT_ARATE_MIN,
+                         (unsigned long long)steps * (unsigned long long)n, it.aux, e->TGT_ARATE_MIN,
                          e->TGT_ARATE_MAX, e->SCALE_DEC, e->SCALE_INC, e->trace.p, e->ntrace.p, e->acc_slots.p,
                          e->nslots);
       HIPCHK(hipGetLastError());
+      break;
     }
-    if (check) irate += 50;
-    isamp = last + 1;
-  }
-  e->cnt.nsteps_burn = (uint64_t)nburn;
-
-  // ---- main loop (src/mcpar.cc:99-210) ----
-  if (nsamp > 0) {
-    hipLaunchKernelGGL(k_init_moments, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->mu.p,
-                       e->psum2.p, (size_t)e->ntot);
-    HIPCHK(hipGetLastError());
-  }
-  const int outstep = nsamp > 50 ? nsamp / 10 : 5;  // :110
-  // Exchange schedule.  The reference gathers at every sync point (isamp % SYNCSTEP == 0, :127-140),
-  // but the gathered slots are read only by genRemote, and every gather overwrites all of them: a
-  // gather that is followed by another gather before the next Murray step is dead.  Default (lazy):
-  // snapshot this shard's slot at every sync point, gather the latest snapshot right before a Murray
-  // step reads it (and once at the end) -- bit-identical results, fused segments may span sync points.
-  // MCX_OPT_EAGER_EXCHANGE = 1 issues the reference's schedule (overlapped with the next segment).
-  const bool sharded = e->size > 1, eager = e->opt_eager != 0;
-  bool need_gather = false;
-  for (int isamp = 0; isamp < nsamp;) {
-    const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
-    if (isamp % outstep == 0 && isamp > 0 && e->ofn) {  // :115-119
+    case MCX_PLAN_INIT_MOMENTS:  // src/mcpar.cc:99-104
+      hipLaunchKernelGGL(k_init_moments, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->mu.p,
+                         e->psum2.p, (size_t)e->ntot);
+      HIPCHK(hipGetLastError());
+      break;
+    case MCX_PLAN_OUTPUT:  // src/mcpar.cc:115-119
       HIPCHK(hipStreamSynchronize(st));
       e->samp_steps = e->opt_samples ? (isamp + e->opt_stride - 1) / e->opt_stride : 0;
       if (e->ofn(e->octx, isamp) != 0) return fail(MCX_ERR_INVALID, "output hook failed");
-    }
-    if (sharded && isamp % e->SYNCSTEP == 0) {  // :127-140
-      MCXCHK(publish(e, isamp));
-      if (eager) MCXCHK(exchange_begin(e));
-      else need_gather = true;
-    }
-    if (step_is_remote(e, isamp, t)) {  // :152-159
-      if (need_gather) {  // slot holds the snapshot of the last sync point
-        MCXCHK(exchange_begin(e));
-        need_gather = false;
-      }
-      MCXCHK(exchange_wait(e));
-      MCXCHK(publish(e, isamp));  // own slot is always current (:205-208)
+      break;
+    case MCX_PLAN_PUBLISH: MCXCHK(publish(e, isamp)); break;
+    case MCX_PLAN_GATHER_BEGIN: MCXCHK(exchange_begin(e)); break;  // src/mcpar.cc:127-140
+    case MCX_PLAN_GATHER_WAIT: MCXCHK(exchange_wait(e)); break;
+    case MCX_PLAN_REMOTE_STEP: {  // src/mcpar.cc:152-175 with genRemote
+      const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
       int npass = 0;
       MCXCHK(remote_device(e, t, e->pvals.p, e->musigall.p, e->ptrial.p, e->cfac.p, e->mutrial.p,
                            e->sigtrial.p, &npass));
@@ -845,51 +920,38 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       StepArgs a;
       fill_step(e, a, t, isamp, true, (size_t)(nburn + isamp), isamp, 1);
       MCXCHK(launch_accept(e, a, true));
-      ++isamp;
-      continue;
+      break;
     }
-    // run of local steps up to the next output dump / Murray step (/ sync point when eager or unfused)
-    const bool span_sync = fused && sharded && !eager;
-    int steps = 1;
-    while (isamp + steps < nsamp && steps < e->opt_maxseg) {
-      const int nx = isamp + steps;
-      if (nx % outstep == 0 && e->ofn) break;
-      if (sharded && !span_sync && nx % e->SYNCSTEP == 0) break;
-      if (step_is_remote(e, nx, t + (uint32_t)steps)) break;
-      ++steps;
-    }
-    if (fused) {
-      const size_t row0 = e->opt_stride == 1 ? (size_t)isamp : 0;  // thinned: the kernel indexes from step 0
-      sa.samp_x = e->opt_samples ? e->samp_x.p + row0 * e->ntot : nullptr;
-      sa.samp_ly = e->opt_samples ? e->samp_ly.p + row0 * n : nullptr;
-      sa.mask = e->opt_mask ? e->mask.p + (size_t)(nburn + isamp) * n : nullptr;
-      sa.nsteps = steps; sa.t0 = t; sa.isamp0 = isamp;
-      sa.snap_after = -1;
-      if (span_sync) {  // last sync point strictly inside the segment
-        const int last = ((isamp + steps - 1) / e->SYNCSTEP) * e->SYNCSTEP;
-        if (last > isamp) {
+    case MCX_PLAN_MAIN_SEGMENT: {  // src/mcpar.cc:152-209 with genLocal
+      const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
+      if (fused) {
+        const size_t row0 = e->opt_stride == 1 ? (size_t)isamp : 0;  // thinned: the kernel indexes from step 0
+        sa.samp_x = e->opt_samples ? e->samp_x.p + row0 * e->ntot : nullptr;
+        sa.samp_ly = e->opt_samples ? e->samp_ly.p + row0 * n : nullptr;
+        sa.mask = e->opt_mask ? e->mask.p + (size_t)(nburn + isamp) * n : nullptr;
+        sa.nsteps = steps; sa.t0 = t; sa.isamp0 = isamp;
+        sa.snap_after = it.aux;
+        if (it.aux >= 0) {  // the kernel rewrites this shard's slot: no gather may still be reading it
           MCXCHK(exchange_wait(e));
-          sa.snap_after = last - 1 - isamp;
-          e->published_steps = last;
-          need_gather = true;
+          e->published_steps = isamp + it.aux + 1;
+        }
+        ProfScope ps(e, MCX_K_FUSED_MAIN, (uint64_t)steps * n);
+        DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, true, sa, st))));
+      } else {
+        for (int s = 0; s < steps; ++s) {
+          StepArgs a;
+          fill_step(e, a, t + (uint32_t)s, isamp + s, true, (size_t)(nburn + isamp + s), isamp + s, 0);
+          MCXCHK(launch_propose(e, a));
+          MCXCHK(eval_trials(e, e->ptrial.p, e->lytrial.p, (uint64_t)n));
+          MCXCHK(launch_accept(e, a, true));
         }
       }
-      ProfScope ps(e, MCX_K_FUSED_MAIN, (uint64_t)steps * n);
-      DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, true, sa, st))));
-    } else {
-      for (int s = 0; s < steps; ++s) {
-        StepArgs a;
-        fill_step(e, a, t + (uint32_t)s, isamp + s, true, (size_t)(nburn + isamp + s), isamp + s, 0);
-        MCXCHK(launch_propose(e, a));
-        MCXCHK(eval_trials(e, e->ptrial.p, e->lytrial.p, (uint64_t)n));
-        MCXCHK(launch_accept(e, a, true));
-      }
+      break;
     }
-    isamp += steps;
+    default: return fail(MCX_ERR_INVALID, "internal: unknown plan item %d", it.kind);
+    }
   }
-  if (need_gather) MCXCHK(exchange_begin(e));  // remote slots end as of the last sync point, like the reference's
-  MCXCHK(exchange_wait(e));
-  MCXCHK(publish(e, nsamp));
+  e->cnt.nsteps_burn = (uint64_t)nburn;
   e->cnt.nsteps_main = (uint64_t)nsamp;
   e->pwgt_last = (float)nsamp;
   if (nsamp > 0) {

@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (HOSTFN, K_NAMES, OUTFN, XCHGFN, Counters, Profile, VLFunc, check, load)
+from ._lib import (HOSTFN, K_NAMES, OUTFN, XCHGFN, Counters, PlanItem, Profile, VLFunc, check, load)
 
 VL_ROSENBROCK1, VL_ROSENBROCK2, VL_GAUSSIAN, VL_DUALGAUSS, VL_GAUSSMIX, VL_HOST = 1, 2, 3, 4, 5, 100
 VL_DEVICE = 101
@@ -41,6 +41,22 @@ def vlfunc_eval(kind, d, x, params=None, ncomp=0):
     v, keep = make_vlfunc(kind, d, params, ncomp)
     check(load().mcx_vlfunc_eval(C.byref(v), x.shape[0], _fp(x), _fp(y)))
     return y
+
+
+PLAN_NAMES = {1: "burn_segment", 2: "tuner", 3: "init_moments", 4: "output", 5: "publish", 6: "gather_begin",
+              7: "gather_wait", 8: "remote_step", 9: "main_segment"}
+
+
+def plan(nsamp, nburn, sync=10, pl=0.9, seed=8675309, tbase=0, nshards=1, eager=0, fused=1, max_segment=256,
+         has_output_hook=0):
+    """the launch schedule mcx_run executes for these settings (host logic only, needs no GPU)"""
+    n = C.c_int(0)
+    check(load().mcx_plan(nsamp, nburn, sync, pl, seed, tbase, nshards, eager, fused, max_segment, has_output_hook,
+                          None, 0, C.byref(n)))
+    items = (PlanItem * max(1, n.value))()
+    check(load().mcx_plan(nsamp, nburn, sync, pl, seed, tbase, nshards, eager, fused, max_segment, has_output_hook,
+                          items, n.value, C.byref(n)))
+    return [(PLAN_NAMES[it.kind], it.first, it.nsteps, it.aux) for it in items[:n.value]]
 
 
 def device_info():
