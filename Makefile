@@ -21,3 +21,11 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib oracle clean
+
+drivers: lib
+	$(MAKE) -C mcpar_amd/drivers
+
+test-cpu: lib oracle
+	python -m pytest tests -x -q -m "not gpu"
+
+.PHONY: drivers test-cpu
