@@ -213,7 +213,7 @@ def main():
                     traffic = json.load(open(tpath)).get("k_fused_steps_main_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = dict(bound="hbm", kernel="k_fused_fast_rosen1<LPC=%d,MAIN>" % max(1, (d + 3) // 4),
+            roofline = dict(bound="hbm", kernel="k_fused_fast<LPC=%d,MAIN>" % max(1, (d + 3) // 4),
                             achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                             frac=achieved / HBM_PEAK, traffic=traffic,
                             alg_bytes_per_chain_step=bpc,

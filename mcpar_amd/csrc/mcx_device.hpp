@@ -410,9 +410,19 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t owner, int 
 }
 
 template <int LPC, bool MAIN, int LIK = LIK_ROSEN1>
-__global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
+__global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
 {
-  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS, "fast path: Rosenbrock1 or diagonal Gaussian");
+  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX,
+                "fast path: Rosenbrock1, diagonal Gaussian, or a mixture of <= 8 unit Gaussians");
+  // mixture: component means and log-weights staged in LDS (every lane group reads the same rows)
+  __shared__ __attribute__((aligned(16))) float lds_means[LIK == LIK_MIX ? 8 * MAXD_LDS : 4];
+  __shared__ float lds_logw[8];
+  if (LIK == LIK_MIX) {
+    const int kd = a.ncomp * a.d;
+    for (int i = threadIdx.x; i < kd; i += BLOCK) lds_means[i] = a.lik[i];
+    if (threadIdx.x < (unsigned)a.ncomp) lds_logw[threadIdx.x] = a.lik[kd + threadIdx.x];
+    __syncthreads();
+  }
   const int d = a.d;
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t chain = gid / LPC;
@@ -462,7 +472,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
       const f32x2 t2 = fma2(-pe, pe, po);
       const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
       if (live) acc = term.x + term.y;  // == (0 + term.x) + term.y: the terms are >= +0
-    } else {
+    } else if (LIK == LIK_GAUSS) {
       // src/rosenbrock.cc:44-61: acc = fma((0.5 a) a, 1/sigma^2, acc) for k = 0..3 in order
       const f32x2 ae = pe - gme, ao = po - gmo;
       const f32x2 he = (splat2(0.5f) * ae) * ae, ho = (splat2(0.5f) * ao) * ao;
@@ -473,7 +483,44 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast_rosen1(const SegArgs a)
         acc = __builtin_fmaf(ho.y, gs3, acc);
       }
     }
-    const float lyt = 0.0f - group_sum<LPC>(acc);
+    float lyt;
+    if (LIK == LIK_MIX) {
+      // log sum_c w_c exp(-|x - m_c|^2 / 2) as a log-sum-exp (DualGaussian: src/rosenbrock.cc:63-78)
+      const int K = a.ncomp;
+      float e[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        e[c] = 0.0f;
+        if (c < K) {
+          float s2 = 0.0f;
+          if (live) {
+            const float4 m = *reinterpret_cast<const float4 *>(&lds_means[c * d + k0]);
+            const f32x2 ae = pe - f32x2{m.x, m.z}, ao = po - f32x2{m.y, m.w};
+            s2 = __builtin_fmaf(ae.x, ae.x, 0.0f);
+            s2 = __builtin_fmaf(ao.x, ao.x, s2);
+            s2 = __builtin_fmaf(ae.y, ae.y, s2);
+            s2 = __builtin_fmaf(ao.y, ao.y, s2);
+          }
+          e[c] = __builtin_fmaf(-0.5f, group_sum<LPC>(s2), lds_logw[c]);
+        }
+      }
+      float emax = e[0];
+#pragma unroll
+      for (int c = 1; c < 8; ++c)
+        if (c < K) emax = e[c] > emax ? e[c] : emax;
+      float ssum = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; c += 2) {  // exp two components at a time, add them in component order
+        if (c < K) {
+          const f32x2 ex = expf_v1x2(f32x2{e[c] - emax, e[c + 1] - emax});
+          ssum = ssum + ex.x;
+          if (c + 1 < K) ssum = ssum + ex.y;
+        }
+      }
+      lyt = emax + logf_v1(ssum);
+    } else {
+      lyt = 0.0f - group_sum<LPC>(acc);
+    }
     // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
     // lanes of a chain split the work: lane q draws block b for b % LPC == q, once per 4*LPC steps.
     const uint32_t blk = t >> 2;

@@ -254,14 +254,18 @@ template <int LPC>
 static int launch_fused(int lik, bool main, const SegArgs &a, hipStream_t st)
 {
   const dim3 grid(nblocks((size_t)a.n * LPC)), block(BLOCK);
-  if (LPC <= 8 && (lik == LIK_ROSEN1 || lik == LIK_GAUSS) && a.diag && a.vec4 && !a.mask) {  // hot path
+  if (LPC <= 8 && (lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8)) && a.diag &&
+      a.vec4 && !a.mask) {  // hot path
     constexpr int FL = LPC <= 8 ? LPC : 8;  // (not instantiated above 8 lanes per chain)
     if (lik == LIK_ROSEN1) {
-      if (main) hipLaunchKernelGGL((k_fused_fast_rosen1<FL, true, LIK_ROSEN1>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((k_fused_fast_rosen1<FL, false, LIK_ROSEN1>), grid, block, 0, st, a);
+      if (main) hipLaunchKernelGGL((k_fused_fast<FL, true, LIK_ROSEN1>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((k_fused_fast<FL, false, LIK_ROSEN1>), grid, block, 0, st, a);
+    } else if (lik == LIK_GAUSS) {
+      if (main) hipLaunchKernelGGL((k_fused_fast<FL, true, LIK_GAUSS>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((k_fused_fast<FL, false, LIK_GAUSS>), grid, block, 0, st, a);
     } else {
-      if (main) hipLaunchKernelGGL((k_fused_fast_rosen1<FL, true, LIK_GAUSS>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((k_fused_fast_rosen1<FL, false, LIK_GAUSS>), grid, block, 0, st, a);
+      if (main) hipLaunchKernelGGL((k_fused_fast<FL, true, LIK_MIX>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((k_fused_fast<FL, false, LIK_MIX>), grid, block, 0, st, a);
     }
     HIPCHK(hipGetLastError());
     return MCX_OK;

@@ -195,6 +195,32 @@ __device__ __forceinline__ void sincos2pi_v1x2(uint32_t wa, uint32_t wb, f32x2 &
   c = f32x2{(ka == 1u || ka == 2u) ? -cv.x : cv.x, (kb == 1u || kb == 2u) ? -cv.y : cv.y};
 }
 
+// expf_v1 on two values: same operations in the same order; the range checks are selects
+__device__ __forceinline__ f32x2 expf_v1x2(f32x2 x)
+{
+  const f32x2 fn = {__builtin_floorf(__builtin_fmaf(x.x, 1.44269504f, 0.5f)),
+                    __builtin_floorf(__builtin_fmaf(x.y, 1.44269504f, 0.5f))};
+  f32x2 r = fma2(fn, splat2(-0.693359375f), x);
+  r = fma2(fn, splat2(2.12194440e-4f), r);
+  f32x2 p = splat2(1.9875691500e-4f);
+  p = fma2(p, r, splat2(1.3981999507e-3f));
+  p = fma2(p, r, splat2(8.3334519073e-3f));
+  p = fma2(p, r, splat2(4.1665795894e-2f));
+  p = fma2(p, r, splat2(1.6666665459e-1f));
+  p = fma2(p, r, splat2(5.0000001201e-1f));
+  const f32x2 z = r * r;
+  f32x2 y = fma2(p, z, r);
+  y = y + splat2(1.0f);
+  const int na = (int)fn.x, nb = (int)fn.y;
+  const int na1 = na >> 1, nb1 = nb >> 1;
+  y = y * f32x2{as_f32((uint32_t)(na1 + 127) << 23), as_f32((uint32_t)(nb1 + 127) << 23)};
+  y = y * f32x2{as_f32((uint32_t)(na - na1 + 127) << 23), as_f32((uint32_t)(nb - nb1 + 127) << 23)};
+  f32x2 o;
+  o.x = x.x > 88.72283f ? __builtin_inff() : (x.x < -87.33654f ? 0.0f : y.x);
+  o.y = x.y > 88.72283f ? __builtin_inff() : (x.y < -87.33654f ? 0.0f : y.y);
+  return o;
+}
+
 // Correctly rounded sqrt for x = +-0 or x >= 2^-96: the raw v_sqrt_f32 (<= 1 ulp) plus
 // the one-ulp-down / one-ulp-up residual test -- the sequence hipcc emits for IEEE sqrtf, minus its
 // denormal pre-scaling and its zero/inf class check, neither of which the Box-Muller argument

@@ -200,7 +200,8 @@ def test_sample_stride_thins_the_store(fuse):
     assert np.array_equal(part, want[2 * n:7 * n])
 
 
-@pytest.mark.parametrize("kind,d", [(O.VL_ROSENBROCK1, 16), (O.VL_GAUSSIAN, 8), (O.VL_GAUSSIAN, 32), (O.VL_GAUSSIAN, 12)])
+@pytest.mark.parametrize("kind,d", [(O.VL_ROSENBROCK1, 16), (O.VL_GAUSSIAN, 8), (O.VL_GAUSSIAN, 32), (O.VL_GAUSSIAN, 12),
+                                    (O.VL_GAUSSMIX, 32), (O.VL_GAUSSMIX, 8), (O.VL_GAUSSMIX, 4)])
 def test_fast_kernel_without_mask_recording(kind, d):
     """the hot-path kernel is used only when no accept mask is recorded: compare everything else"""
     import mcpar_amd as M
@@ -209,10 +210,14 @@ def test_fast_kernel_without_mask_recording(kind, d):
     params = None
     if kind == O.VL_GAUSSIAN:
         params = np.concatenate([np.linspace(-1, 1, d), np.linspace(0.5, 2, d)]).astype(np.float32)
-    vo, _k1 = O.make_vlfunc(kind, d, params)
+    K = 0
+    if kind == O.VL_GAUSSMIX:
+        K = {32: 8, 8: 3, 4: 7}[d]
+        params = mix_params(d, K)
+    vo, _k1 = O.make_vlfunc(kind, d, params, K)
     eo = O.Engine(d, n, pl=0.9)
     eo.run(nsamp, nburn, p, vo)
-    vg, _k2 = M.make_vlfunc(kind, d, params)
+    vg, _k2 = M.make_vlfunc(kind, d, params, K)
     eg = M.Engine(d, n, pl=0.9)
     eg.run(nsamp, nburn, p, vg)
     c = eg.counters
