@@ -201,11 +201,16 @@ __device__ __forceinline__ void store_pairs(float *__restrict__ base, size_t row
 // factor, scaled by the tuner).  diag: T is diagonal (identity covariance, any tuner history).
 // Tl = T staged in LDS (full path only).
 // ---------------------------------------------------------------------------------------------
+// zbuf: per-workgroup LDS scratch of BLOCK float4 (or null): with T in LDS and d % 4 == 0 the lane
+// group exchanges z through it (one b128 write, broadcast b128 reads) and reads T four columns at a
+// time; otherwise z goes through LDS-crossbar shuffles and T is read element by element.
 template <int LPC>
 __device__ __forceinline__ void propose_block(const float x[4], float pt[4], const float tdiag[4],
                                               const float *Tl, bool diag, int d, int q, int nv,
-                                              uint32_t t, uint32_t g, uint32_t seed)
+                                              uint32_t t, uint32_t g, uint32_t seed, float *zbuf = nullptr,
+                                              int ldt = 0)
 {
+  if (ldt == 0) ldt = d;  // row stride of Tl (LDS copy is padded against bank conflicts)
   float z[4];
   {
     f32x2 ze, zo;  // packed Box-Muller: same bits as normal4_from_words, half the instructions
@@ -215,6 +220,31 @@ __device__ __forceinline__ void propose_block(const float x[4], float pt[4], con
   if (diag) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) pt[k] = __builtin_fmaf(tdiag[k], z[k], x[k]);
+  } else if (zbuf) {
+    float4 *zb = reinterpret_cast<float4 *>(zbuf);
+    zb[threadIdx.x] = make_float4(z[0], z[1], z[2], z[3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // a lane group never spans wavefronts; LDS is in order per wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int base = (int)threadIdx.x & ~(LPC - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pt[k] = x[k];
+#pragma unroll
+    for (int qq = 0; qq < LPC; ++qq) {
+      if (qq <= q && nv == 4) {  // columns j = 4qq .. 4qq+3 in ascending order; entries above the
+        const float4 zz = zb[base + qq];  // diagonal are exact zeros, i.e. exact no-ops
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 tr = *reinterpret_cast<const float4 *>(&Tl[(4 * q + k) * ldt + 4 * qq]);
+          pt[k] = __builtin_fmaf(tr.x, zz.x, pt[k]);
+          pt[k] = __builtin_fmaf(tr.y, zz.y, pt[k]);
+          pt[k] = __builtin_fmaf(tr.z, zz.z, pt[k]);
+          pt[k] = __builtin_fmaf(tr.w, zz.w, pt[k]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // all reads of this step precede the next step's write
   } else {
     const int lane0 = (int)(threadIdx.x & 63u) & ~(LPC - 1);
 #pragma unroll
@@ -230,7 +260,7 @@ __device__ __forceinline__ void propose_block(const float x[4], float pt[4], con
           if (k < nv) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              if (4 * qq + c < d) pt[k] = __builtin_fmaf(Tl[(4 * q + k) * d + 4 * qq + c], zz[c], pt[k]);
+              if (4 * qq + c < d) pt[k] = __builtin_fmaf(Tl[(4 * q + k) * ldt + 4 * qq + c], zz[c], pt[k]);
           }
       }
     }
@@ -283,14 +313,21 @@ struct SegArgs {
 template <int LPC, int LIK, bool MAIN>
 __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
 {
-  __shared__ float Tlds[MAXD_LDS * MAXD_LDS];
+  // rows padded by 4 floats: the 4-row blocks of different lanes then start 16 banks apart instead of
+  // on the same bank (8-way -> 2-way conflict at d = 32) and stay 16-byte aligned
+  __shared__ __attribute__((aligned(16))) float Tlds[MAXD_LDS * (MAXD_LDS + 4)];
+  __shared__ __attribute__((aligned(16))) float zlds[BLOCK * 4];
   const bool diag = a.diag != 0, vec4 = a.vec4 != 0;
   const int d = a.d;
   const float *Tl = a.T;
+  float *zbuf = nullptr;
+  int ldt = d;
   if (!diag && d <= MAXD_LDS) {
-    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tlds[i] = a.T[i];
+    ldt = d + 4;
+    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tlds[(i / d) * ldt + (i % d)] = a.T[i];
     __syncthreads();
     Tl = Tlds;
+    if (vec4) zbuf = zlds;
   }
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t chain = gid / LPC;
@@ -320,7 +357,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
   for (int s = 0; s < a.nsteps; ++s) {
     const uint32_t t = a.t0 + (uint32_t)s;
     float pt[4];
-    propose_block<LPC>(x, pt, tdiag, Tl, diag, d, q, nv, t, g, a.seed);
+    propose_block<LPC>(x, pt, tdiag, Tl, diag, d, q, nv, t, g, a.seed, zbuf, ldt);
     const float lyt = L.eval(pt, nv);
     if ((t >> 2) != ablk) {  // one Philox block serves four consecutive steps
       ablk = t >> 2;
@@ -600,14 +637,21 @@ struct StepArgs {
 template <int LPC>
 __global__ __launch_bounds__(BLOCK) void k_propose_local(const StepArgs a)
 {
-  __shared__ float Tlds[MAXD_LDS * MAXD_LDS];
+  // rows padded by 4 floats: the 4-row blocks of different lanes then start 16 banks apart instead of
+  // on the same bank (8-way -> 2-way conflict at d = 32) and stay 16-byte aligned
+  __shared__ __attribute__((aligned(16))) float Tlds[MAXD_LDS * (MAXD_LDS + 4)];
+  __shared__ __attribute__((aligned(16))) float zlds[BLOCK * 4];
   const bool diag = a.diag != 0, vec4 = a.vec4 != 0;
   const int d = a.d;
   const float *Tl = a.T;
+  float *zbuf = nullptr;
+  int ldt = d;
   if (!diag && d <= MAXD_LDS) {
-    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tlds[i] = a.T[i];
+    ldt = d + 4;
+    for (int i = threadIdx.x; i < d * d; i += BLOCK) Tlds[(i / d) * ldt + (i % d)] = a.T[i];
     __syncthreads();
     Tl = Tlds;
+    if (vec4) zbuf = zlds;
   }
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t chain = gid / LPC;
@@ -619,7 +663,7 @@ __global__ __launch_bounds__(BLOCK) void k_propose_local(const StepArgs a)
   load_block(a.x, chain, d, k0, nv, vec4, x);
 #pragma unroll
   for (int k = 0; k < 4; ++k) tdiag[k] = (diag && k < nv) ? a.T[(k0 + k) * d + k0 + k] : 0.0f;
-  propose_block<LPC>(x, pt, tdiag, Tl, diag, d, q, nv, a.t, a.g0 + (uint32_t)chain, a.seed);
+  propose_block<LPC>(x, pt, tdiag, Tl, diag, d, q, nv, a.t, a.g0 + (uint32_t)chain, a.seed, zbuf, ldt);
   store_block(a.ptrial, chain, d, k0, nv, vec4, pt);
   if (q == 0) a.cfac[chain] = 1.0f;  // src/mcpar.cc:309
 }

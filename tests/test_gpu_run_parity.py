@@ -131,6 +131,14 @@ def test_full_covariance():
     cov = (a @ a.T / d + 0.5 * np.eye(d)).astype(np.float32)
     eo, eg = run_pair(O.VL_ROSENBROCK1, d, 200, 120, 40, 0.9, incov=cov)
     assert_same(eo, eg, "fullcov")
+    # ragged lane groups (d = 12: the fourth lane of a chain owns nothing) and 8 lanes per chain
+    for d, n in ((12, 70), (32, 40), (6, 50)):
+        a = rng.normal(size=(d, d)).astype(np.float32)
+        cov = (a @ a.T / d + 0.5 * np.eye(d)).astype(np.float32)
+        eo, eg = run_pair(O.VL_ROSENBROCK1, d, n, 60, 25, 0.9, incov=cov)
+        assert_same(eo, eg, "fullcov%d" % d)
+        eo, eg = run_pair(O.VL_ROSENBROCK1, d, n, 60, 25, 0.9, incov=cov, fuse=0)
+        assert_same(eo, eg, "fullcov%d unfused" % d)
     # np > 32: factor read from L2 instead of LDS
     d = 40
     a = rng.normal(size=(d, d)).astype(np.float32)
