@@ -1,51 +1,56 @@
-// mcout.hh -- the reference's sample sink (src/mcout.hh:1-54), same public interface.  MCPar::run
-// fills it in bulk from the engine's HBM-resident sample store at the points where the reference
-// dumps output; rows, row order and the text format are the reference's (src/mcout.cc:30-48,129-145).
+// mcout.hh -- sample sink with the public interface of the reference's MCout (src/mcout.hh:32-50):
+// rows of (np parameters, log-likelihood), appended per (step, chain), dumped as text by rank 0.
+// MCPar::run fills it in bulk (add_rows) from the engine's HBM-resident sample store at the points
+// where the reference dumps output; row order and text format follow src/mcout.cc:30-48,129-145.
 #ifndef MCPAR_AMD_MCOUT_HH_
 #define MCPAR_AMD_MCOUT_HH_
 
-#include <assert.h>
+#include <cstddef>
 #include <iostream>
 #include <vector>
 
 #include "mpi_compat.hh"
 
 class MCout {
-  std::vector<float> pvals;
-  std::vector<float> maxlparams;
-  float maxlval;
-  const int mnparam;  // number of model parameters
-  const int mncol;    // number of data columns = # of parameters + 1
-  size_t next;
-  int npset;     // number of parameter sets stored
-  int maxsamps;  // maximum number of parameter sets that can be stored
-  size_t nextout;  // offset (in elements) of the next parameter set to be output
-  std::ostream *outstream;
-  MPI_Comm mComm;
-  int mrank;
-  int msize;
-
 public:
   MCout(int np, std::ostream *aoutstream, MPI_Comm acomm);
+
+  // ---- filling -------------------------------------------------------------------------------
+  // reserve room for nsamp more rows (call before a loop that adds nsamp samples)
   void newsamps(int nsamp)
   {
-    maxsamps += nsamp;
-    pvals.resize(pvals.size() + (size_t)nsamp * mncol);
+    capacity_rows_ += nsamp;
+    rows_.resize(rows_.size() + static_cast<std::size_t>(nsamp) * width_);
   }
-  void add(const float *pv, float lval);
-  // bulk form of add(): nrows rows of (np+1) floats, already in MCout layout
-  void add_rows(const float *rows, size_t nrows);
-  int size(void) const { return npset; }
-  int maxsize(void) const { return maxsamps; }
-  int ncol(void) { return mncol; }
-  int vsize(void) const { return (int)pvals.size(); }
-  const float *getpset(int i) const { return &pvals[(size_t)i * mncol]; }
-  float getlval(int i) const { return pvals[(size_t)(i + 1) * mncol - 1]; }
-  void output();
-  float *collect(size_t *ntot);
-  void rewind(void) { nextout = 0; }
-  // Warning: maxlike is a COLLECTIVE call.  All processes in the group must call it at the same time.
+  void add(const float *pv, float lval);                   // one row
+  void add_rows(const float *rows, std::size_t nrows);     // nrows rows already in (np+1)-column layout
+
+  // ---- inspection ----------------------------------------------------------------------------
+  int size(void) const { return stored_rows_; }            // rows stored
+  int maxsize(void) const { return capacity_rows_; }       // rows reserved
+  int ncol(void) { return width_; }                        // np + 1
+  int vsize(void) const { return static_cast<int>(rows_.size()); }
+  const float *getpset(int i) const { return &rows_[static_cast<std::size_t>(i) * width_]; }
+  float getlval(int i) const { return rows_[static_cast<std::size_t>(i + 1) * width_ - 1]; }
+
+  // ---- output --------------------------------------------------------------------------------
+  void output();                       // print the rows added since the last output()/collect()
+  float *collect(std::size_t *ntot);   // rank 0: new[] buffer of all ranks' new rows (caller deletes)
+  void rewind(void) { flushed_ = 0; }  // make every stored row "new" again
+  // COLLECTIVE: every rank of the communicator must call it.  Best sample over all ranks.
   const std::vector<float> &maxlike(float *lmax);
+
+private:
+  const int nparam_, width_;      // parameters per row, columns per row
+  std::vector<float> rows_;       // row-major storage
+  std::size_t fill_, flushed_;    // elements written / elements already handed to output()
+  int stored_rows_, capacity_rows_;
+  float best_l_;                  // running maximum of the log-likelihood column
+  std::vector<float> best_p_;     // and the parameters it was seen at
+  std::ostream *sink_;            // rank 0 only
+  MPI_Comm comm_;
+  int rank_, nranks_;
+  void note_row(const float *row);
 };
 
 #endif

@@ -7,6 +7,7 @@
 // with status 2 (src/mcpar.cc:34-40), run() returns 0 (src/mcpar.cc:213).
 #include "../../include/mcpar/mcpar.hh"
 
+#include <cassert>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -24,119 +25,110 @@ static void die(const char *where)
 }
 
 // ---------------------------------------------------------------------------------------------
-// MCout (src/mcout.cc)
+// MCout: behaviour of src/mcout.cc
 // ---------------------------------------------------------------------------------------------
-MCout::MCout(int anparam, std::ostream *aoutstream, MPI_Comm acomm)
-    : mnparam(anparam), mncol(anparam + 1), next(0), npset(0), maxsamps(0), nextout(0)
+MCout::MCout(int np, std::ostream *aoutstream, MPI_Comm acomm)
+    : nparam_(np), width_(np + 1), fill_(0), flushed_(0), stored_rows_(0), capacity_rows_(0),
+      best_l_(-std::numeric_limits<float>::infinity()), best_p_(static_cast<size_t>(np), 0.0f), sink_(0)
 {
 #ifdef MCX_WITH_MPI
-  if (MPI_Comm_dup(acomm, &mComm) != MPI_SUCCESS) {
+  if (MPI_Comm_dup(acomm, &comm_) != MPI_SUCCESS) {
     std::cerr << "MCout: unable to duplicate input communicator in constructor." << std::endl;
     MPI_Abort(acomm, 1);
   }
 #else
-  mComm = acomm;
+  comm_ = acomm;
 #endif
-  MPI_Comm_rank(mComm, &mrank);
-  MPI_Comm_size(mComm, &msize);
-  maxlparams.resize(mnparam);
-  maxlval = -(std::numeric_limits<float>::infinity());
-  outstream = mrank == 0 ? aoutstream : 0;  // all output through rank 0, like the reference
+  MPI_Comm_rank(comm_, &rank_);
+  MPI_Comm_size(comm_, &nranks_);
+  if (rank_ == 0) sink_ = aoutstream;  // all text goes through rank 0, like the reference
+}
+
+void MCout::note_row(const float *row)
+{
+  if (row[nparam_] > best_l_) {  // first strict maximum wins (src/mcout.cc:140-144)
+    best_l_ = row[nparam_];
+    best_p_.assign(row, row + nparam_);
+  }
 }
 
 void MCout::add(const float *pv, float lval)
 {
-  assert(next + mncol <= pvals.size());
-  float *strt = &pvals[next];
-  for (int i = 0; i < mnparam; ++i) strt[i] = pv[i];
-  strt[mnparam] = lval;
-  next += mncol;
-  npset++;
-  if (lval > maxlval) {
-    maxlval = lval;
-    for (int i = 0; i < mnparam; ++i) maxlparams[i] = pv[i];
-  }
+  assert(fill_ + width_ <= rows_.size());
+  float *dst = &rows_[fill_];
+  std::memcpy(dst, pv, sizeof(float) * nparam_);
+  dst[nparam_] = lval;
+  note_row(dst);
+  fill_ += width_;
+  ++stored_rows_;
 }
 
 void MCout::add_rows(const float *rows, size_t nrows)
 {
-  assert(next + nrows * mncol <= pvals.size());
-  std::memcpy(&pvals[next], rows, nrows * mncol * sizeof(float));
-  for (size_t r = 0; r < nrows; ++r) {
-    const float *row = rows + r * mncol;
-    if (row[mnparam] > maxlval) {
-      maxlval = row[mnparam];
-      for (int i = 0; i < mnparam; ++i) maxlparams[i] = row[i];
-    }
-  }
-  next += nrows * mncol;
-  npset += (int)nrows;
+  assert(fill_ + nrows * width_ <= rows_.size());
+  std::memcpy(&rows_[fill_], rows, nrows * width_ * sizeof(float));
+  for (size_t r = 0; r < nrows; ++r) note_row(rows + r * width_);
+  fill_ += nrows * width_;
+  stored_rows_ += static_cast<int>(nrows);
 }
 
-// rows as "v0  v1  ...  LL  \n": two spaces after every field, stream default precision
+// text format of the reference: every field followed by two blanks, stream-default precision
 void MCout::output()
 {
-  size_t ntot = 0;
-  float *buf = collect(&ntot);
-  if (mrank == 0 && ntot > 0) {
-    const size_t nrow = ntot / mncol;
-    size_t indx = 0;
-    for (size_t i = 0; i < nrow; ++i) {
-      for (int j = 0; j < mncol; ++j) (*outstream) << buf[indx++] << "  ";
-      (*outstream) << "\n";
-    }
-    delete[] buf;
+  size_t count = 0;
+  float *all = collect(&count);
+  if (rank_ != 0 || count == 0) return;
+  std::ostream &os = *sink_;
+  for (size_t i = 0; i < count; ++i) {
+    os << all[i] << "  ";
+    if ((i + 1) % width_ == 0) os << "\n";
   }
+  delete[] all;
 }
 
-// newly allocated buffer on rank 0 (caller deletes), NULL elsewhere; rank-major order
+// rows added since the last flush, all ranks', rank-major; buffer exists on rank 0 only
 float *MCout::collect(size_t *ntot)
 {
-  float *buf = 0;
-  const size_t nout = next > nextout ? next - nextout : 0;
-  if (nout == 0) {
-    *ntot = 0;
-    return buf;
-  }
-  if (mrank == 0) {
-    *ntot = (size_t)msize * nout;
-    buf = new float[*ntot];
-  } else {
-    *ntot = 0;
+  *ntot = 0;
+  const size_t fresh = fill_ > flushed_ ? fill_ - flushed_ : 0;
+  if (fresh == 0) return 0;
+  float *gathered = 0;
+  if (rank_ == 0) {
+    *ntot = fresh * static_cast<size_t>(nranks_);
+    gathered = new float[*ntot];
   }
 #ifdef MCX_WITH_MPI
-  if (msize > 1) {
-    int st = MPI_Gather((void *)&pvals[nextout], (int)nout, MPI_FLOAT, (void *)buf, (int)nout, MPI_FLOAT, 0, mComm);
+  if (nranks_ > 1) {
+    const int st = MPI_Gather((void *)&rows_[flushed_], (int)fresh, MPI_FLOAT, (void *)gathered, (int)fresh,
+                              MPI_FLOAT, 0, comm_);
     if (st != MPI_SUCCESS) {
       std::cerr << "Unable to gather output data.  Aborting.\n";
       MPI_Abort(MPI_COMM_WORLD, st);
     }
-    nextout = next;
-    return buf;
+    flushed_ = fill_;
+    return gathered;
   }
 #endif
-  if (mrank == 0) std::memcpy(buf, &pvals[nextout], nout * sizeof(float));
-  nextout = next;
-  return buf;
+  if (gathered) std::memcpy(gathered, &rows_[flushed_], fresh * sizeof(float));
+  flushed_ = fill_;
+  return gathered;
 }
 
 const std::vector<float> &MCout::maxlike(float *lmax)
 {
 #ifdef MCX_WITH_MPI
-  if (msize > 1) {
-    struct { float val; int rank; } snd, rcv;
-    snd.val = maxlval;
-    snd.rank = mrank;
-    if (MPI_Allreduce(&snd, &rcv, 1, MPI_FLOAT_INT, MPI_MAXLOC, mComm) != MPI_SUCCESS ||
-        MPI_Bcast(&maxlparams[0], mnparam, MPI_FLOAT, rcv.rank, mComm) != MPI_SUCCESS) {
-      std::cerr << "rank " << mrank << ":  MPI failure in MCout::maxlike().\n";
+  if (nranks_ > 1) {
+    struct { float v; int r; } mine = {best_l_, rank_}, top;
+    if (MPI_Allreduce(&mine, &top, 1, MPI_FLOAT_INT, MPI_MAXLOC, comm_) != MPI_SUCCESS ||
+        MPI_Bcast(&best_p_[0], nparam_, MPI_FLOAT, top.r, comm_) != MPI_SUCCESS) {
+      std::cerr << "rank " << rank_ << ":  MPI failure in MCout::maxlike().\n";
       MPI_Abort(MPI_COMM_WORLD, 1);
     }
-    maxlval = rcv.val;
+    best_l_ = top.v;
   }
 #endif
-  *lmax = maxlval;
-  return maxlparams;
+  *lmax = best_l_;
+  return best_p_;
 }
 
 // ---------------------------------------------------------------------------------------------

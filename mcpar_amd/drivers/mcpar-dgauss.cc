@@ -1,49 +1,23 @@
-// mcpar-dgauss -- same command line (none) and output surface as the reference demo
-// (src/mcpar-dgauss.cc): 2-D DualGaussian(5), 4 chains per rank, 500 burn-in + 8 samples;
-// stdout = sample rows then "max likelihood value: X" and the parameters; per-rank file
-// mcpar-dgauss.RRR.txt with tab-separated parameters; log in mcpar-log.000.txt.
-#include <fstream>
-#include <iomanip>
-#include <iostream>
-#include <sstream>
-
-#include "mcpar/mcout.hh"
+// mcpar-dgauss -- MI355X build of the reference's two-Gaussian demo: no arguments; 2-D
+// DualGaussian(5), 4 chains per rank, 500 burn-in steps + 8 kept steps.  Output surface as the
+// reference's: sample rows on stdout, then the maximum-likelihood sample; mcpar-dgauss.RRR.txt with
+// the parameters of this rank's samples; mcpar-log.000.txt.
+#include "driver_util.hh"
 #include "mcpar/mcpar.hh"
 #include "mcpar/rosenbrock.hh"
 
 int main(int argc, char *argv[])
 {
-  const int nparam = 2;
-  DualGaussian L(5.0f);
+  drv::Session mpi(argc, argv);
+  if (!mpi.ok) return 1;
 
-  if (MPI_Init(&argc, &argv) != MPI_SUCCESS) {
-    std::cerr << "Error on MPI_Init.  Exiting.\n";
-    return 1;
-  }
-  int size, rank;
-  MPI_Comm_size(MPI_COMM_WORLD, &size);
-  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+  enum { NPARAM = 2, NCHAIN = 4, NBURN = 500, NKEEP = 8 };
+  DualGaussian target(5.0f);
+  MCout store(NPARAM, &std::cout, MPI_COMM_WORLD);
+  MCPar sampler(NPARAM, NCHAIN, mpi.nranks, mpi.rank);
+  sampler.run(NKEEP, NBURN, drv::demo_start(), target, store);
 
-  MCout rslts(nparam, &std::cout, MPI_COMM_WORLD);
-  MCPar mcpar(nparam, 4, size, rank);  // 2 parameters, 4 chains per process
-  float pinit[8] = {0.0f, 0.0f, 2.0f, 2.0f, 0.0f, 1.5f, 0.0f, -2.0f};
-  mcpar.run(8, 500, pinit, L, rslts);
-
-  std::stringstream ofname;
-  ofname << "mcpar-dgauss." << std::setfill('0') << std::setw(3) << rank << ".txt";
-  std::ofstream outfile(ofname.str().c_str());
-  for (int i = 0; i < rslts.size(); ++i) {
-    const float *pset = rslts.getpset(i);
-    for (int j = 0; j < rslts.ncol() - 1; ++j) outfile << pset[j] << "\t";
-    outfile << "\n";
-  }
-
-  float lmax;
-  const std::vector<float> &pmax = rslts.maxlike(&lmax);
-  std::cout << "max likelihood value: " << lmax << "\n";
-  for (size_t i = 0; i < pmax.size(); ++i) std::cout << pmax[i] << "  ";
-  std::cout << "\n";
-
-  MPI_Finalize();
+  drv::dump_params(store, "mcpar-dgauss", mpi.rank);
+  drv::report_maxlike(store, std::cout);
   return 0;
 }

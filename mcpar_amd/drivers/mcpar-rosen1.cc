@@ -1,36 +1,24 @@
-// mcpar-rosen1 [nsamp] -- same command line and output surface as the reference demo
-// (src/mcpar-rosen1.cc): 2-D Rosenbrock1, 4 chains per rank, 500 burn-in, nsamp (default 100000)
-// samples; stdout = "nsamp = N" then the sample rows.
+// mcpar-rosen1 [nsamp] -- MI355X build of the reference's Rosenbrock demo: 2-D Rosenbrock1,
+// 4 chains per rank, 500 burn-in steps, nsamp kept steps (default 100000).  stdout: "nsamp = N",
+// then the sample rows.
 #include <cstdlib>
-#include <iostream>
 
-#include "mcpar/mcout.hh"
+#include "driver_util.hh"
 #include "mcpar/mcpar.hh"
 #include "mcpar/rosenbrock.hh"
 
 int main(int argc, char *argv[])
 {
-  const int nparam = 2;
-  Rosenbrock1 L(2);
-  int nsamp = 100000;
+  drv::Session mpi(argc, argv);
+  if (!mpi.ok) return 1;
 
-  if (MPI_Init(&argc, &argv) != MPI_SUCCESS) {
-    std::cerr << "Error on MPI_Init.  Exiting.\n";
-    return 1;
-  }
-  MCout rslts(nparam, &std::cout, MPI_COMM_WORLD);
-  int size, rank;
-  MPI_Comm_size(MPI_COMM_WORLD, &size);
-  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+  const int nkeep = argc > 1 ? std::atoi(argv[1]) : 100000;
+  Rosenbrock1 target(2);
+  MCout store(2, &std::cout, MPI_COMM_WORLD);
+  if (mpi.rank == 0) std::cout << "nsamp = " << nkeep << "\n";
 
-  if (argc > 1) nsamp = atoi(argv[1]);
-  if (rank == 0) std::cout << "nsamp = " << nsamp << "\n";
-
-  MCPar mcpar(nparam, 4, size, rank);
-  float pinit[8] = {0.0f, 0.0f, 2.0f, 2.0f, 0.0f, 1.5f, 0.0f, -2.0f};
-  mcpar.run(nsamp, 500, pinit, L, rslts);
-  rslts.output();
-
-  MPI_Finalize();
+  MCPar sampler(2, 4, mpi.nranks, mpi.rank);
+  sampler.run(nkeep, 500, drv::demo_start(), target, store);
+  store.output();  // nothing left after run(); kept for parity with the reference demo
   return 0;
 }
