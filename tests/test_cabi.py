@@ -61,3 +61,18 @@ def test_fails_loudly_without_a_device():
         M.vlfunc_eval(M.VL_ROSENBROCK1, 2, [[1.0, 1.0]])
     with pytest.raises(M.McxError):
         M.debug_numerics(0, [1, 2, 3])
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the boundary is a C ABI: include/mcx.h must compile as C99 and link against libmcx.so"""
+    import subprocess
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "mcx.h"\nint main(void){ mcx_vlfunc f = {MCX_VL_ROSENBROCK1, 2, 0, 0, 0, 0}; (void)f;\n'
+                   ' mcx_plan_item it; int n = 0; (void)it;\n'
+                   ' if (mcx_plan(10, 60, 10, 0.9f, 1u, 0u, 1, 0, 1, 256, 0, 0, 0, &n) != MCX_OK || n < 3) return 2;\n'
+                   ' return mcx_abi_version() == MCX_ABI_VERSION ? 0 : 1; }\n')
+    exe = tmp_path / "cabi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", os.path.join(ROOT, "mcpar_amd"), "-lmcx",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mcpar_amd")])
+    assert subprocess.call([str(exe)]) == 0
