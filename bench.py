@@ -206,16 +206,19 @@ def main():
         if fm["launches"] > 0 and fm["ms"] > 0:
             bpc = alg_bytes_per_chain_step(d, True, emit)
             achieved = fm["chain_steps"] * bpc / (fm["ms"] * 1e-3)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get("k_fused_steps_main_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            # PMC numbers cannot be collected inside this process: they come from the committed rocprofv3
+            # --pmc passes of this same command (profiles/, tools/collect_profiles.py)
+            traffic = valu_busy = None
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
+                    "k_fused_steps_main_bytes_per_launch")
+                valu_busy = json.load(open(os.path.join(ROOT, "profiles", "r01_fused_kernel_sq_counters.json"))).get(
+                    "valu_busy_fraction")
+            except Exception:
+                pass
             roofline = dict(bound="hbm", kernel="k_fused_fast<LPC=%d,MAIN>" % max(1, (d + 3) // 4),
                             achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                            frac=achieved / HBM_PEAK, traffic=traffic,
+                            frac=achieved / HBM_PEAK, traffic=traffic, valu_busy=valu_busy,
                             alg_bytes_per_chain_step=bpc,
                             avg_launch_ms=fm["ms"] / fm["launches"], launches=fm["launches"],
                             chain_steps_per_launch=fm["chain_steps"] / fm["launches"],
