@@ -332,6 +332,7 @@ struct mcx_engine {
   int SYNCSTEP;
   uint32_t seed, tbase = 0;
   int lpc, vec4;
+  int device = 0;  // the HIP device the engine lives on (current device at mcx_create)
   // device state (src/mcpar.hh:61-88)
   DevBuf<float> pvals, ptrial, mu, sig, psum2, mutrial, sigtrial, musigall, winvall;
   DevBuf<float> lylast, lytrial, cfac, cmax, cov, trace;
@@ -362,6 +363,14 @@ struct mcx_engine {
   std::vector<EvPair> evs;
   mcx_profile prof{};
 };
+
+// every entry point may be called from a thread whose current device is another one
+static inline int enter(mcx_engine *e)
+{
+  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  HIPCHK(hipSetDevice(e->device));
+  return MCX_OK;
+}
 
 struct ProfScope {
   mcx_engine *e;
@@ -414,6 +423,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
     return fail(MCX_ERR_INVALID, "tchains*np*2 overflows int32 (the reference indexes musigall with int)");
   MCXCHK(need_device());
   mcx_engine *e = new mcx_engine();
+  if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
   e->nparam = np; e->nchain = nc; e->ntot = np * nc; e->ncov = np * np;
   e->size = nshards; e->rank = shard; e->tchains = nshards * nc;
   e->PLOCAL = pl; e->TGT_ARATE_MIN = armin; e->TGT_ARATE_MAX = armax;
@@ -455,6 +465,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
 extern "C" int mcx_destroy(mcx_engine *e)
 {
   if (!e) return MCX_OK;
+  (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   prof_collect(e);
   e->pvals.release(); e->ptrial.release(); e->mu.release(); e->sig.release(); e->psum2.release();
@@ -537,6 +548,7 @@ static int covar_install(mcx_engine *e, const float *incov, float *cov_out, bool
 
 extern "C" int mcx_covar_setup(mcx_engine *e, const float *incov, float *cov)
 {
+  MCXCHK(enter(e));
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
   return covar_install(e, incov, cov);
 }
@@ -816,6 +828,7 @@ extern "C" int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed,
 extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L,
                        const float *incov)
 {
+  MCXCHK(enter(e));
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
   if (nsamp < 0 || nburn < 0) return fail(MCX_ERR_INVALID, "bad run arguments");
   if (!pinit && !e->pinit_staged) return fail(MCX_ERR_INVALID, "pinit is NULL and no state was staged (mcx_stage_pinit)");
@@ -982,6 +995,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
 
 extern "C" int mcx_stage_pinit(mcx_engine *e, const float *pinit)
 {
+  MCXCHK(enter(e));
   if (!e || !pinit) return fail(MCX_ERR_INVALID, "bad arguments");
   MCXCHK(e->pinit_dev.alloc((size_t)e->ntot));
   HIPCHK(hipMemcpyAsync(e->pinit_dev.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -1049,6 +1063,7 @@ extern "C" int mcx_vlfunc_eval(const mcx_vlfunc *f, int npset, const float *x, f
 
 extern "C" int mcx_gen_local(mcx_engine *e, uint32_t t, const float *pvals, float *ptrial, float *cfac)
 {
+  MCXCHK(enter(e));
   if (!e || !pvals || !ptrial || !cfac) return fail(MCX_ERR_INVALID, "bad arguments");
   hipStream_t st = e->stream;
   DevBuf<float> x;
@@ -1073,6 +1088,7 @@ extern "C" int mcx_gen_local(mcx_engine *e, uint32_t t, const float *pvals, floa
 extern "C" int mcx_gen_remote(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
                               float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass)
 {
+  MCXCHK(enter(e));
   if (!e || !pvals || !musigall || !ptrial || !cfac) return fail(MCX_ERR_INVALID, "bad arguments");
   hipStream_t st = e->stream;
   DevBuf<float> x, ms;
@@ -1103,6 +1119,7 @@ template <typename T>
 static int d2h(mcx_engine *e, T *dst, const T *src, size_t count)
 {
   if (!e || !dst) return fail(MCX_ERR_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return MCX_OK;
@@ -1124,6 +1141,7 @@ extern "C" int mcx_get_accept_counts(mcx_engine *e, uint32_t *v) { return d2h(e,
 
 extern "C" int mcx_get_accept_mask(mcx_engine *e, uint8_t *mask)
 {
+  MCXCHK(enter(e));
   if (!e || !mask) return fail(MCX_ERR_INVALID, "bad arguments");
   if (!e->have_run || !e->opt_mask || !e->mask.p) return fail(MCX_ERR_INVALID, "no accept mask recorded (MCX_OPT_ACCEPT_MASK)");
   return d2h(e, mask, e->mask.p, (size_t)(e->last_nburn + e->last_nsamp) * e->nchain);
@@ -1131,6 +1149,7 @@ extern "C" int mcx_get_accept_mask(mcx_engine *e, uint8_t *mask)
 
 extern "C" int mcx_get_tuner_trace(mcx_engine *e, float *scales, int maxn, int *n)
 {
+  MCXCHK(enter(e));
   if (!e || !n) return fail(MCX_ERR_INVALID, "bad arguments");
   int nt = 0;
   MCXCHK(d2h(e, &nt, e->ntrace.p, 1));
@@ -1152,6 +1171,7 @@ extern "C" int mcx_samples_steps(mcx_engine *e, int *nsteps)
 // pageable buffer.  Off the hot path: this is the MCout::add / collect side of the boundary.
 extern "C" int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float *rows)
 {
+  MCXCHK(enter(e));
   if (!e || !rows || first_step < 0 || nsteps < 0) return fail(MCX_ERR_INVALID, "bad arguments");
   if (first_step + nsteps > e->samp_steps) return fail(MCX_ERR_INVALID, "steps [%d,%d) not in the sample store (%d steps)", first_step, first_step + nsteps, e->samp_steps);
   const size_t n = (size_t)e->nchain, d = (size_t)e->nparam, ncol = d + 1, nr = (size_t)nsteps * n;
@@ -1201,6 +1221,7 @@ extern "C" int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float
 
 extern "C" int mcx_samples_maxlike(mcx_engine *e, float *lmax, float *params)
 {
+  MCXCHK(enter(e));
   if (!e || !lmax || !params) return fail(MCX_ERR_INVALID, "bad arguments");
   const size_t n = (size_t)e->nchain, d = (size_t)e->nparam, nr = (size_t)e->samp_steps * n;
   if (nr == 0) return fail(MCX_ERR_INVALID, "sample store is empty");
