@@ -121,22 +121,62 @@ def main():
     vl, _keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     p = pinit_for(d, n, rank * n)
 
-    state = {}
+    state = {"backend": None}
     if world > 1:
         # engine kernels and the RCCL all-gather are ordered through torch's current stream
         stream = torch.cuda.current_stream()
         eng.set_option(E.OPT_STREAM, stream.cuda_stream)
+        lib = M.load()
+        # Safety net: a host-staged all-gather over a gloo group, used only if the zero-copy RCCL path
+        # (in-place all_gather_into_tensor on a __cuda_array_interface__ view) does not work on this
+        # stack.  The decision is taken once, collectively, on a probe buffer.
+        gloo = dist.new_group(backend="gloo") if args.backend == "nccl" else None
+        ok = 0 if os.environ.get("MCX_BENCH_FORCE_STAGED") else 1  # (rehearsal switch for the fallback)
+        try:
+            if not ok:
+                raise RuntimeError("forced")
+            probe = torch.zeros(world * 256, dtype=torch.float32, device="cuda")
+            view = torch.as_tensor(CudaArrayView(probe.data_ptr(), probe.numel()), device="cuda")
+            own = view[rank * 256:(rank + 1) * 256]
+            own.fill_(float(rank + 1))
+            dist.all_gather_into_tensor(view, own)
+            torch.cuda.synchronize()
+            got = probe.view(world, 256)[:, 0].cpu()
+            ok = int(bool((got == torch.arange(1, world + 1, dtype=torch.float32)).all()))
+        except Exception as ex:  # noqa: BLE001
+            print("rank %d: zero-copy RCCL all-gather probe failed: %r" % (rank, ex), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
+        zero_copy = int(flag.item()) == 1
+        state["backend"] = ("rccl" if args.backend == "nccl" else args.backend) if zero_copy else "gloo, host-staged (fallback)"
 
         def exchange(phase, ptr, slot, shard, nshards, st):
-            if phase == E.XCHG_BEGIN:
-                if "all" not in state:
-                    state["all"] = torch.as_tensor(CudaArrayView(ptr, slot * nshards), device="cuda")
-                    state["own"] = state["all"][shard * slot:(shard + 1) * slot]
-                state["work"] = dist.all_gather_into_tensor(state["all"], state["own"], async_op=True)
-            else:
-                w = state.pop("work", None)
-                if w is not None:
-                    w.wait()
+            if zero_copy:
+                if phase == E.XCHG_BEGIN:
+                    if "all" not in state:
+                        state["all"] = torch.as_tensor(CudaArrayView(ptr, slot * nshards), device="cuda")
+                        state["own"] = state["all"][shard * slot:(shard + 1) * slot]
+                    state["work"] = dist.all_gather_into_tensor(state["all"], state["own"], async_op=True)
+                else:
+                    w = state.pop("work", None)
+                    if w is not None:
+                        w.wait()
+                return 0
+            if phase != E.XCHG_BEGIN:
+                return 0
+            host = state.setdefault("host", np.empty(slot * nshards, np.float32))
+            vp = C.c_void_p
+            rc = lib.mcx_copy_to_host(vp(host.ctypes.data + shard * slot * 4), vp(ptr + shard * slot * 4), slot * 4, vp(st))
+            if rc:
+                return rc
+            t = torch.from_numpy(host)
+            dist.all_gather_into_tensor(t, t[shard * slot:(shard + 1) * slot].clone(), group=gloo)
+            for r in range(nshards):
+                if r != shard:
+                    rc = lib.mcx_copy_to_device(vp(ptr + r * slot * 4), vp(host.ctypes.data + r * slot * 4), slot * 4, vp(st))
+                    if rc:
+                        return rc
             return 0
         eng.set_exchange(exchange)
 
@@ -242,6 +282,7 @@ def main():
                        "samples": "all kept in HBM" if emit else "none (summary only)",
                        "parallelism": "chains sharded x%d, RCCL all-gather of the (mu, sig^2) snapshots that a Murray "
                                       "step or the end of the run reads" % world if world > 1 else "single GPU",
+                       "exchange_backend": state["backend"],
                        "eager_exchange": eager,
                        "accept_rate_main": cnt["naccept_main"] / float(n * nsamp),
                        "value_with_host_pinit": value_host_pinit,
