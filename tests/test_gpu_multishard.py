@@ -12,14 +12,14 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1):
+def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, vlspec=None):
     import mcpar_amd as M
     from mcpar_amd import engine as E
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipDeviceSynchronize.argtypes = []
     engs = [M.Engine(d, n, nshards=nshards, shard=s, pl=pl, sync=sync) for s in range(nshards)]
-    vl, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    vl, keep = M.make_vlfunc(*(vlspec or (M.VL_ROSENBROCK1, d)))
     ptrs = [None] * nshards
     bar = threading.Barrier(nshards)
     errs = []
@@ -109,3 +109,20 @@ def test_multishard_hot_path_kernel(pl, eager):
         assert c["naccept_main"] == eo.naccept_main and c["remote_passes"] == eo.remote_passes
         for name in ("state", "mean", "var", "samples", "musigall"):
             assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
+
+
+def test_c5_shape_mixture_four_shards():
+    """BASELINE config 5 in miniature: 32-D 8-component mixture, chains over 4 shards, Murray swaps"""
+    d, K, n, nshards, nburn, nsamp, pl = 32, 8, 256, 4, 120, 60, 0.85
+    means = np.stack([np.full(d, 5.0 * k / (K - 1)) for k in range(K)]).astype(np.float32)
+    params = np.concatenate([means.ravel(), [5] + [1] * (K - 1)]).astype(np.float32)
+    vo, keep = O.make_vlfunc(O.VL_GAUSSMIX, d, params, K)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl, threads=8) for s in range(nshards)]
+    O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+    assert eos[0].remote_steps > 0
+    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, mask=0, vlspec=(O.VL_GAUSSMIX, d, params, K))
+    for s in range(nshards):
+        c = egs[s].counters
+        assert c["remote_passes"] == eos[s].remote_passes and c["naccept_main"] == eos[s].naccept_main
+        for name in ("state", "mean", "var", "samples", "musigall"):
+            assert np.array_equal(getattr(egs[s], name).view(np.uint32), getattr(eos[s], name).view(np.uint32)), name
