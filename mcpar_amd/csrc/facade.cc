@@ -6,6 +6,7 @@
 // a sample store that does not fit prints "Unable to allocate space for output samples." and exits
 // with status 2 (src/mcpar.cc:34-40), run() returns 0 (src/mcpar.cc:213).
 #include "../../include/mcpar/mcpar.hh"
+#include "../../include/mcpar/mcutil.hh"
 
 #include <cassert>
 #include <cstdio>
@@ -298,4 +299,65 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   mcx_get_counters(eng, &counters);
   outsamples.output();  // output remaining samples (src/mcpar.cc:212)
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mcutil::qriguess (role of src/mcutil.cc:3-34): Sobol points scaled into [plo, phi]
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// Joe & Kuo (2008) "new-joe-kuo-6" primitive polynomials and initial direction numbers, dimensions
+// 2..21: {degree s, coefficients a, m_1..m_s}.  Dimension 1 is the van der Corput sequence.
+const unsigned kSobolInit[20][9] = {
+    {1, 0, 1},          {2, 1, 1, 3},          {3, 1, 1, 3, 1},        {3, 2, 1, 1, 1},
+    {4, 1, 1, 1, 3, 3}, {4, 4, 1, 3, 5, 13},   {5, 2, 1, 1, 5, 5, 17}, {5, 4, 1, 1, 5, 5, 5},
+    {5, 7, 1, 1, 7, 11, 19},  {5, 11, 1, 1, 5, 1, 1},   {5, 13, 1, 1, 1, 3, 11}, {5, 14, 1, 3, 5, 5, 31},
+    {6, 1, 1, 3, 3, 9, 7, 49}, {6, 13, 1, 1, 1, 15, 21, 21}, {6, 16, 1, 3, 1, 13, 27, 49},
+    {6, 19, 1, 1, 1, 15, 7, 5}, {6, 22, 1, 3, 1, 15, 13, 25}, {6, 25, 1, 1, 5, 5, 19, 61},
+    {7, 1, 1, 3, 7, 11, 23, 15, 103}, {7, 4, 1, 3, 7, 13, 13, 15, 69}};
+
+// direction numbers v[j] (32 bits, bit 31 = 1/2) of one dimension
+void sobol_directions(int dim, unsigned v[32])
+{
+  if (dim == 0) {
+    for (int j = 0; j < 32; ++j) v[j] = 1u << (31 - j);
+    return;
+  }
+  const unsigned *row = kSobolInit[dim - 1];
+  const int s = (int)row[0];
+  const unsigned a = row[1];
+  unsigned m[32];
+  for (int j = 0; j < 32; ++j) {
+    if (j < s) m[j] = row[2 + j];
+    else {
+      unsigned x = m[j - s] ^ (m[j - s] << s);
+      for (int k = 1; k < s; ++k)
+        if ((a >> (s - 1 - k)) & 1u) x ^= m[j - k] << k;
+      m[j] = x;
+    }
+    v[j] = m[j] << (31 - j);
+  }
+}
+
+}  // namespace
+
+void mcutil::qriguess(int rank, int npset, int nparam, const float plo[], const float phi[], float *restrict pout)
+{
+  if (nparam < 1 || nparam > MAXDIM) throw("mcutil::qriguess supports 1 <= nparam <= 21");
+  if (npset < 0 || rank < 0) throw("mcutil::qriguess: bad rank or npset");
+  const unsigned long long first = (unsigned long long)rank * (unsigned long long)npset;
+  for (int i = 0; i < nparam; ++i) {
+    unsigned v[32];
+    sobol_directions(i, v);
+    for (int j = 0; j < npset; ++j) {
+      // point number n (counting from 1, so that the all-zero point is skipped) in Gray-code order
+      const unsigned long long n = first + (unsigned long long)j + 1ull;
+      const unsigned long long g = n ^ (n >> 1);
+      unsigned x = 0;
+      for (int b = 0; b < 32; ++b)
+        if ((g >> b) & 1ull) x ^= v[b];
+      const float u = (float)(x >> 8) * (1.0f / 16777216.0f);  // [0, 1) on a 2^-24 grid
+      pout[(size_t)j * nparam + i] = plo[i] + u * (phi[i] - plo[i]);
+    }
+  }
 }

@@ -145,6 +145,32 @@ struct DevBuf {
   }
 };
 
+// pinned host staging (host-callback likelihoods move nc*np floats out and nc floats in every step)
+template <typename T>
+struct PinBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count)
+  {
+    if (count <= n && p) return MCX_OK;
+    release();
+    if (count == 0) count = 1;
+    if (hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+      return fail(MCX_ERR_ALLOC, "hipHostMalloc(%zu bytes) failed", count * sizeof(T));
+    }
+    n = count;
+    return MCX_OK;
+  }
+  void release()
+  {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
 // device-side likelihood descriptor built from an mcx_vlfunc
 struct LikDev {
   int kind = 0;  // LikKind, or MCX_VL_HOST
@@ -344,7 +370,8 @@ struct mcx_engine {
   bool pinit_staged = false;
   DevBuf<uint8_t> mask;
   // host staging
-  std::vector<float> h_ptrial, h_lytrial, h_cov, h_winv;
+  PinBuf<float> h_ptrial, h_lytrial;
+  std::vector<float> h_cov, h_winv;
   // run bookkeeping
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -474,6 +501,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
+  e->h_ptrial.release(); e->h_lytrial.release();
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MCX_OK;
@@ -558,12 +586,13 @@ static int eval_trials(mcx_engine *e, const float *x_dev, float *y_dev, uint64_t
 {
   const int n = e->nchain, d = e->nparam;
   if (e->lik.kind == MCX_VL_HOST) {
-    e->h_ptrial.resize((size_t)e->ntot);
-    e->h_lytrial.resize((size_t)n);
-    HIPCHK(hipMemcpyAsync(e->h_ptrial.data(), x_dev, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    MCXCHK(e->h_ptrial.alloc((size_t)e->ntot));
+    MCXCHK(e->h_lytrial.alloc((size_t)n));
+    HIPCHK(hipMemcpyAsync(e->h_ptrial.p, x_dev, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    (void)e->lik.fn(e->lik.ctx, n, e->h_ptrial.data(), e->h_lytrial.data());  // return code ignored like the reference
-    HIPCHK(hipMemcpyAsync(y_dev, e->h_lytrial.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    (void)e->lik.fn(e->lik.ctx, n, e->h_ptrial.p, e->h_lytrial.p);  // return code ignored like the reference
+    HIPCHK(hipMemcpyAsync(y_dev, e->h_lytrial.p, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // the callback may reuse nothing, but the next step rewrites h_lytrial
     return MCX_OK;
   }
   ProfScope ps(e, MCX_K_EVAL, cs);
