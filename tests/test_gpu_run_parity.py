@@ -233,3 +233,12 @@ def test_fast_kernel_without_mask_recording(kind, d):
     np.testing.assert_array_equal(eg.accept_counts, eo.accept_counts)
     for name in ("state", "loglike", "mean", "var", "musigall", "samples", "chol"):
         assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
+
+
+@pytest.mark.parametrize("d,n,nburn,nsamp,pl", [(1, 1, 60, 20, 0.8), (1, 37, 0, 25, 0.8), (2, 1, 120, 0, 1.0),
+                                                (3, 5, 0, 0, 0.9), (4, 64, 1, 1, 1.0), (16, 3, 53, 11, 0.5)])
+def test_degenerate_sizes(d, n, nburn, nsamp, pl):
+    """one chain, one parameter, no burn-in, no samples: the loops of src/mcpar.cc:55-210 with empty ranges"""
+    kind = O.VL_GAUSSIAN if d % 2 else O.VL_ROSENBROCK1
+    eo, eg = run_pair(kind, d, n, nburn, nsamp, pl)
+    assert_same(eo, eg, "degenerate")
