@@ -213,7 +213,8 @@ int mcx_device_info(char *name, size_t namelen, int *cu_count, size_t *hbm_bytes
 int mcx_set_device(int device);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:
  * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
- * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf */
+ * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf,
+ * 9/10 packed expf lane 0/1, 11 packed logf, 12/13 packed/scalar sincos hash */
 int mcx_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out_bits);
 /* number of float bit patterns in [lo_bits, hi_bits) where the kernels' lean sqrt (valid for +-0 and
  * positive normal floats) differs from IEEE sqrtf, and the smallest such pattern */

@@ -1093,6 +1093,11 @@ __global__ void k_debug_numerics(int what, int n, const uint32_t *in, uint32_t *
   case 6: r = philox4x32_10(w, 0, 0, 0, 0, 0).x; break;
   case 7: r = as_u32(sqrt_rn_pos(as_f32(w))); break;
   case 8: r = as_u32(__builtin_sqrtf(as_f32(w))); break;
+  case 9: r = as_u32(expf_v1x2(f32x2{as_f32(w), 1.0f}).x); break;
+  case 10: r = as_u32(expf_v1x2(f32x2{-3.0f, as_f32(w)}).y); break;
+  case 11: r = as_u32(logf_v1x2(f32x2{as_f32(w), 0.5f}).x); break;
+  case 12: { f32x2 s2, c2; sincos2pi_v1x2(w, w ^ 0x9e3779b9u, s2, c2); r = as_u32(s2.x) ^ (as_u32(c2.x) << 1); } break;
+  case 13: { float s1, c1; sincos2pi_v1(w, s1, c1); r = as_u32(s1) ^ (as_u32(c1) << 1); } break;
   default: break;
   }
   out[i] = r;

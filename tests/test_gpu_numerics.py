@@ -85,3 +85,21 @@ def test_sqrt_rn_exhaustive():
     # and against the host's sqrtf on a random sample of the Box-Muller domain
     x = np.random.default_rng(4).uniform(1e-7, 45.0, 200000).astype(np.float32)
     assert np.array_equal(M.debug_numerics(7, x.view(np.uint32)), np.sqrt(x).view(np.uint32))
+
+
+def test_packed_forms_equal_scalar_forms():
+    """the 2-wide (v_pk_*_f32) log / exp / sincos used by the hot-path kernel give the same bits as the
+    scalar forms, in either lane, including out-of-range and special inputs"""
+    import mcpar_amd as M
+    rng = np.random.default_rng(11)
+    xe = np.concatenate([rng.uniform(-100, 95, 50000), [0.0, -0.0, 88.72283, 88.7229, -87.33654, -87.3366,
+                                                        np.inf, -np.inf, 1e-30, -1e-30]]).astype(np.float32)
+    ref = M.debug_numerics(1, xe.view(np.uint32))
+    assert np.array_equal(M.debug_numerics(9, xe.view(np.uint32)), ref)
+    assert np.array_equal(M.debug_numerics(10, xe.view(np.uint32)), ref)
+    nan = np.array([np.nan], np.float32).view(np.uint32)
+    assert np.isnan(M.debug_numerics(9, nan).view(np.float32)[0])
+    xl = np.concatenate([rng.uniform(1e-30, 1e30, 20000), rng.random(30000) + 1e-9]).astype(np.float32)
+    assert np.array_equal(M.debug_numerics(11, xl.view(np.uint32)), M.debug_numerics(0, xl.view(np.uint32)))
+    w = rng.integers(0, 2 ** 32, 60000, dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(M.debug_numerics(12, w), M.debug_numerics(13, w))
