@@ -23,6 +23,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver on this pool only supports dmabuf IPC (needed by RCCL across processes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md chip table
 
