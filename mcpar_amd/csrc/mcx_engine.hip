@@ -380,7 +380,6 @@ struct mcx_engine {
   int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
   bool have_run = false, diag = true, xchg_pending = false;
   int published_steps = 0;  // main-loop steps reflected in this shard's musigall slot
-  float pwgt_last = 0.0f;
   LikDev lik;
   mcx_exchange_fn xfn = nullptr;
   void *xctx = nullptr;
@@ -999,7 +998,6 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   }
   e->cnt.nsteps_burn = (uint64_t)nburn;
   e->cnt.nsteps_main = (uint64_t)nsamp;
-  e->pwgt_last = (float)nsamp;
   if (nsamp > 0) {
     hipLaunchKernelGGL(k_variance, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->psum2.p,
                        e->sig.p, (size_t)e->ntot, 1.0f / (float)nsamp);

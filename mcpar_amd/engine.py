@@ -174,11 +174,6 @@ class Engine:
         check(load().mcx_covar_setup(self.h, _fp(ic) if ic is not None else None, _fp(out)))
         return out
 
-    def _get(self, name, shape, dtype=np.float32):
-        out = np.empty(shape, dtype)
-        check(getattr(load(), name)(self.h, out.ctypes.data_as(C.c_void_p)))
-        return out
-
     @property
     def state(self): return self._getf("mcx_get_state", (self.nc, self.np))
     @property
