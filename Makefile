@@ -8,16 +8,23 @@ HIPFLAGS  = -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-f
 
 all: lib oracle
 
-lib: mcpar_amd/libmcx.so
+lib:
+	$(MAKE) -j4 mcpar_amd/libmcx.so
 
-mcpar_amd/libmcx.so: $(CSRC)/mcx_engine.hip $(CSRC)/mcx_device.hpp $(CSRC)/mcx_numerics.hpp include/mcx.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/mcx_engine.hip
+OBJS = $(CSRC)/mcx_engine.o $(CSRC)/mcx_k_fast.o $(CSRC)/mcx_k_generic_burn.o $(CSRC)/mcx_k_generic_main.o
+HDRS = $(CSRC)/mcx_device.hpp $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_launch.hpp include/mcx.h
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+mcpar_amd/libmcx.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS)
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f mcpar_amd/libmcx.so
+	rm -f mcpar_amd/libmcx.so $(CSRC)/*.o
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib oracle clean

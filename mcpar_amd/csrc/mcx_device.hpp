@@ -689,7 +689,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval(const float *__restrict__ x, flo
 
 // Rosenbrock2 exactly as written (src/rosenbrock.cc:25-41): flat index, x[i+1] read across the
 // set boundary, '-' on the second term, last set one term short.
-__global__ __launch_bounds__(BLOCK) void k_eval_rosen2(const float *__restrict__ x,
+static __global__ __launch_bounds__(BLOCK) void k_eval_rosen2(const float *__restrict__ x,
                                                        float *__restrict__ y, int n, int d)
 {
   const size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(BLOCK) void k_accept(const StepArgs a)
 }
 
 // start of the main loop: mu = 0, psum2 = FPEPS (src/mcpar.cc:99-104)
-__global__ void k_init_moments(float *mu, float *psum2, size_t ntot)
+static __global__ void k_init_moments(float *mu, float *psum2, size_t ntot)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < ntot) { mu[i] = 0.0f; psum2[i] = FPEPS; }
@@ -770,7 +770,7 @@ __global__ void k_init_moments(float *mu, float *psum2, size_t ntot)
 // Publish this shard's (mu, sig^2) pairs into its musigall slot (src/mcpar.cc:202-208).  The
 // reference rewrites the slot every step; the slot is only read by genRemote and by the exchange,
 // so it is written once, right before either of them, from the resident moments.
-__global__ void k_publish(const float *__restrict__ mu, const float *__restrict__ psum2,
+static __global__ void k_publish(const float *__restrict__ mu, const float *__restrict__ psum2,
                           float *__restrict__ slot, size_t ntot, float winv)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -778,7 +778,7 @@ __global__ void k_publish(const float *__restrict__ mu, const float *__restrict_
 }
 
 // sig = psum2 / pwgt for the getter (src/mcpar.cc:202)
-__global__ void k_variance(const float *psum2, float *sig, size_t ntot, float winv)
+static __global__ void k_variance(const float *psum2, float *sig, size_t ntot, float winv)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < ntot) sig[i] = psum2[i] * winv;
@@ -810,13 +810,13 @@ __device__ __forceinline__ unsigned long long block_sum_slots(uint32_t *slots, i
 }
 
 // accepted proposals of the main loop so far: *dst += sum(slots)
-__global__ void k_reduce_slots(uint32_t *slots, int nslots, unsigned long long *dst)
+static __global__ void k_reduce_slots(uint32_t *slots, int nslots, unsigned long long *dst)
 {
   const unsigned long long t = block_sum_slots(slots, nslots);
   if (threadIdx.x == 0) *dst += t;
 }
 
-__global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsigned long long add_trials,
+static __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsigned long long add_trials,
                         int check, float armin, float armax, float dfac, float ifac, float *trace,
                         int *ntrace, uint32_t *slots, int nslots)
 {
@@ -854,7 +854,7 @@ __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsigned lo
 // per-chain Gaussians Q_i streamed through wave-uniform (scalar) loads.
 // ---------------------------------------------------------------------------------------------
 // qpar[i] = (mu_i, 1/sig2_i): one Q_i is 2d contiguous floats, fetched with wide scalar loads
-__global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ qpar, size_t nd)
+static __global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ qpar, size_t nd)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nd) {
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
 }
 
 // numerator of cfac: max_i Q_i(pvals_j) (src/mcpar.cc:421-437); does not depend on the pass
-__global__ void k_remote_cmax_combine(const float *__restrict__ pmax, float *__restrict__ cmax, int n, int S)
+static __global__ void k_remote_cmax_combine(const float *__restrict__ pmax, float *__restrict__ cmax, int n, int S)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -966,7 +966,7 @@ __global__ void k_remote_cmax_combine(const float *__restrict__ pmax, float *__r
 }
 
 // rejection test of the pass (src/mcpar.cc:397-441); survivors are compacted for the next pass
-__global__ void k_remote_decide(const RemoteArgs a)
+static __global__ void k_remote_decide(const RemoteArgs a)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.nact) return;
@@ -998,7 +998,7 @@ __device__ __forceinline__ float q_arg_mem(const float *__restrict__ qp, const f
   return arg;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_remote_cmax_big(const float *__restrict__ pvals,
+static __global__ __launch_bounds__(BLOCK) void k_remote_cmax_big(const float *__restrict__ pvals,
                                                            const float *__restrict__ qpar,
                                                            float *__restrict__ cmax, int n, int d, int N)
 {
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_cmax_big(const float *__restri
   cmax[j] = cm;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteArgs a)
+static __global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteArgs a)
 {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.nact) return;
@@ -1057,14 +1057,14 @@ __global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteArgs a)
 }
 
 // src/mcpar.cc:447-448
-__global__ void k_square(float *v, size_t n)
+static __global__ void k_square(float *v, size_t n)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = v[i] * v[i];
 }
 
 // MCout row format (src/mcout.cc:129-137): (np parameters, log-likelihood) per (step, chain)
-__global__ void k_rows_interleave(const float *__restrict__ sx, const float *__restrict__ sl,
+static __global__ void k_rows_interleave(const float *__restrict__ sx, const float *__restrict__ sl,
                                   float *__restrict__ rows, size_t nrows, int d)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1076,7 +1076,7 @@ __global__ void k_rows_interleave(const float *__restrict__ sx, const float *__r
 }
 
 // test hooks -----------------------------------------------------------------------------------
-__global__ void k_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out)
+static __global__ void k_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1104,7 +1104,7 @@ __global__ void k_debug_numerics(int what, int n, const uint32_t *in, uint32_t *
 }
 
 // counts bit patterns in [lo, hi) where sqrt_rn_pos differs from the compiler's IEEE sqrtf
-__global__ void k_debug_sqrt_sweep(uint32_t lo, uint32_t hi, unsigned long long *nbad, uint32_t *first_bad)
+static __global__ void k_debug_sqrt_sweep(uint32_t lo, uint32_t hi, unsigned long long *nbad, uint32_t *first_bad)
 {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   unsigned long long bad = 0;
@@ -1118,7 +1118,7 @@ __global__ void k_debug_sqrt_sweep(uint32_t lo, uint32_t hi, unsigned long long 
   if (bad) atomicAdd(nbad, bad);
 }
 
-__global__ void k_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uint32_t g0, uint32_t a,
+static __global__ void k_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uint32_t g0, uint32_t a,
                                 uint32_t q, int n, float *out)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -5,6 +5,7 @@
 // HIP device and returns MCX_ERR_NO_DEVICE without one.
 #include "../../include/mcx.h"
 #include "mcx_device.hpp"
+#include "mcx_launch.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -276,37 +277,16 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   default: return fail(MCX_ERR_UNSUPPORTED, "internal: register Murray kernels cover np <= 32"); \
   }
 
-template <int LPC>
-static int launch_fused(int lik, bool main, const SegArgs &a, hipStream_t st)
+// the two fused-kernel families are compiled in their own translation units (mcx_k_fast.hip,
+// mcx_k_generic_*.hip) so that the library builds in parallel; see mcx_launch.hpp
+static int launch_fused(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st)
 {
-  const dim3 grid(nblocks((size_t)a.n * LPC)), block(BLOCK);
-  if (LPC <= 8 && (lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8)) && a.diag &&
-      a.vec4 && !a.mask) {  // hot path
-    constexpr int FL = LPC <= 8 ? LPC : 8;  // (not instantiated above 8 lanes per chain)
-    if (lik == LIK_ROSEN1) {
-      if (main) hipLaunchKernelGGL((k_fused_fast<FL, true, LIK_ROSEN1>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((k_fused_fast<FL, false, LIK_ROSEN1>), grid, block, 0, st, a);
-    } else if (lik == LIK_GAUSS) {
-      if (main) hipLaunchKernelGGL((k_fused_fast<FL, true, LIK_GAUSS>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((k_fused_fast<FL, false, LIK_GAUSS>), grid, block, 0, st, a);
-    } else {
-      if (main) hipLaunchKernelGGL((k_fused_fast<FL, true, LIK_MIX>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((k_fused_fast<FL, false, LIK_MIX>), grid, block, 0, st, a);
-    }
-    HIPCHK(hipGetLastError());
-    return MCX_OK;
-  }
-#define LF(LK)                                                                       \
-  if (main) hipLaunchKernelGGL((k_fused_steps<LPC, LK, true>), grid, block, 0, st, a); \
-  else hipLaunchKernelGGL((k_fused_steps<LPC, LK, false>), grid, block, 0, st, a);
-  switch (lik) {
-  case LIK_ROSEN1: LF(LIK_ROSEN1) break;
-  case LIK_GAUSS: LF(LIK_GAUSS) break;
-  case LIK_MIX: LF(LIK_MIX) break;
-  default: return fail(MCX_ERR_INVALID, "likelihood %d has no fused kernel", lik);
-  }
-#undef LF
-  HIPCHK(hipGetLastError());
+  hipError_t err;
+  const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
+  if (lpc <= 8 && fast_lik && a.diag && a.vec4 && !a.mask) err = mcxk_launch_fast(lpc, lik, main, a, st);  // hot path
+  else err = main ? mcxk_launch_generic_main(lpc, lik, a, st) : mcxk_launch_generic_burn(lpc, lik, a, st);
+  if (err == hipErrorInvalidValue) return fail(MCX_ERR_UNSUPPORTED, "no fused kernel for lanes/chain = %d, likelihood %d", lpc, lik);
+  HIPCHK(err);
   return MCX_OK;
 }
 
@@ -920,7 +900,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
         sa.mask = e->opt_mask ? e->mask.p + (size_t)isamp * n : nullptr;
         sa.nsteps = steps; sa.t0 = t0; sa.isamp0 = 0; sa.snap_after = -1;
         ProfScope ps(e, MCX_K_FUSED_BURN, (uint64_t)steps * n);
-        DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, false, sa, st))));
+        MCXCHK(launch_fused(e->lpc, e->lik.kind, false, sa, st));
       } else {
         for (int s = 0; s < steps; ++s) {
           StepArgs a;
@@ -981,7 +961,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
           e->published_steps = isamp + it.aux + 1;
         }
         ProfScope ps(e, MCX_K_FUSED_MAIN, (uint64_t)steps * n);
-        DISPATCH_LPC(e->lpc, MCXCHK((launch_fused<LPC_>(e->lik.kind, true, sa, st))));
+        MCXCHK(launch_fused(e->lpc, e->lik.kind, true, sa, st));
       } else {
         for (int s = 0; s < steps; ++s) {
           StepArgs a;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Compile mcx_engine.hip with -save-temps and summarise one kernel: registers and the instruction
+"""Compile the translation units of libmcx with -save-temps and summarise one kernel: registers and the instruction
 mix of its biggest loop.  usage: tools/kernel_asm.py <mangled-name-substring> [--dump]"""
 import collections
 import os
@@ -14,11 +14,15 @@ TMP = "/tmp/mcx_asm"
 def main():
     pat = sys.argv[1]
     os.makedirs(TMP, exist_ok=True)
-    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
-                           "-fno-fast-math", "-fno-gpu-flush-denormals-to-zero", "-I" + ROOT + "/include", "-c",
-                           "-save-temps", "-o", "x.o", ROOT + "/mcpar_amd/csrc/mcx_engine.hip"], cwd=TMP,
-                          stderr=subprocess.DEVNULL)
-    s = open(TMP + "/mcx_engine-hip-amdgcn-amd-amdhsa-gfx950.s").read()
+    s = ""
+    for tu in ("mcx_k_fast", "mcx_k_generic_main", "mcx_k_generic_burn", "mcx_engine"):
+        if pat.startswith("k_fused_fast") and tu != "mcx_k_fast":
+            continue
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
+                               "-fno-fast-math", "-fno-gpu-flush-denormals-to-zero", "-I" + ROOT + "/include", "-c",
+                               "-save-temps", "-o", "x.o", ROOT + "/mcpar_amd/csrc/%s.hip" % tu], cwd=TMP,
+                              stderr=subprocess.DEVNULL)
+        s += open(TMP + "/%s-hip-amdgcn-amd-amdhsa-gfx950.s" % tu).read()
     names = sorted(set(re.findall(r"^(_Z\w+):", s, flags=re.M)))
     hits = [n for n in names if pat in n]
     for name in hits:
