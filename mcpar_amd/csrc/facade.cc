@@ -207,7 +207,33 @@ struct RunCtx {
   std::ofstream *log;
   int nchain, ncol, copied_steps, nsamp;
   std::vector<float> stage;
+  // optional per-step diagnostics of the reference (src/mcpar.cc:121-126, 129-139)
+  bool logging, mpi;
+  int logstep, syncstep, logged_upto, size0;
 };
+
+// The reference writes its `logging` diagnostics inside the step loop.  The steps run on the GPU in
+// long launches here, so the same lines are written -- in the reference's order -- when the host
+// regains control: everything of iterations [logged_upto, upto) that precedes iteration upto's dump.
+void write_step_diagnostics(RunCtx *c, int upto)
+{
+  if (!c->logging || c->logstep < 1) {
+    c->logged_upto = upto;
+    return;
+  }
+  std::ofstream &lf = *c->log;
+  for (int isamp = c->logged_upto; isamp < upto; ++isamp) {
+    if (isamp % c->logstep == 0)
+      lf << "sample step " << isamp << ":\toutsamples size= " << (c->size0 + isamp * c->nchain)
+         << "  maxsize = " << c->out->maxsize() << "  ncol= " << c->out->ncol() << "\n\tvsize = " << c->out->vsize()
+         << "  offset = " << (isamp * c->ncol) << std::endl;
+    if (c->mpi && isamp % c->syncstep == 0) {
+      lf << "\tisamp = " << isamp << "  entering allgather " << std::endl;
+      lf << "\tisamp = " << isamp << "  exiting allgather " << std::endl;
+    }
+  }
+  c->logged_upto = upto;
+}
 
 // where the reference dumps output (src/mcpar.cc:115-119): move the new rows from the HBM sample
 // store into MCout, then let MCout print them
@@ -221,6 +247,7 @@ int output_hook(void *vctx, int steps_done)
     c->out->add_rows(c->stage.data(), (size_t)ns * c->nchain);
     c->copied_steps = steps_done;
   }
+  write_step_diagnostics(c, steps_done);  // iterations before this dump point
   if (steps_done < c->nsamp) {
     (*c->log) << "Beginning output at step " << steps_done << std::endl;
     c->out->output();
@@ -275,7 +302,8 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   HostL hl = {&L};
   if (!L.device_descriptor(nparam, &f)) f = mcx_vlfunc{MCX_VL_HOST, nparam, 0, 0, host_tramp, &hl};
 
-  RunCtx ctx = {eng, &outsamples, &logfile, nchain, nparam + 1, 0, nsamp, std::vector<float>()};
+  RunCtx ctx = {eng,   &outsamples, &logfile, nchain,   nparam + 1, 0, nsamp, std::vector<float>(),
+                logging, mpi,        logstep,  SYNCSTEP, 0,          outsamples.size()};
   mcx_set_output_hook(eng, output_hook, &ctx);
 #ifdef MCX_WITH_MPI
   XchgCtx xc;

@@ -72,6 +72,15 @@ int main()
   run(builtin, np, nc, nsamp, nburn, 0.8f, a);
   run(user, np, nc, nsamp, nburn, 0.8f, b);
   std::cout << a.str() << "=====\n" << b.str() << "=====\n" << "user calls " << user.ncalls << "\n";
+  {  // the reference's optional step diagnostics (mcpar.logging / logstep)
+    std::ostringstream c;
+    MCout r2(np, &c, MPI_COMM_WORLD);
+    MCPar m2(np, 4, 1, 0, 1.0f);
+    m2.logging = true;
+    m2.logstep = 7;
+    std::vector<float> p0(4 * np, 0.25f);
+    m2.run(20, 10, p0.data(), builtin, r2);
+  }
   // constructor guard of the reference (src/rosenbrock.hh:13-16)
   try {
     Rosenbrock1 bad(3);

@@ -79,6 +79,17 @@ def test_cpp_api_builtin_and_user_vlfunc(tmp_path):
     # VLFunc is called once before burn-in and once per step (src/mcpar.cc:53,60,160)
     assert "user calls %d" % (1 + nburn + nsamp) in tail
     assert "guard: N for Rosenbrock1 must be even and >= 2" in tail
+    # mcpar.logging = true, logstep = 7, nsamp = 20 (outstep 5), 4 chains: the reference's diagnostics, in
+    # its order (src/mcpar.cc:115-126): dump message of iteration i, then the diagnostic of iteration i
+    log = (tmp_path / "mcpar-log.000.txt").read_text()
+    want = ("Starting burn-in.  Samples = 10\nStarting main sample loop:  nsamp = 20\nOutput after each 5 steps.\n"
+            "sample step 0:\toutsamples size= 0  maxsize = 80  ncol= 9\n\tvsize = 720  offset = 0\n"
+            "Beginning output at step 5\nOutput finished\n\n"
+            "sample step 7:\toutsamples size= 28  maxsize = 80  ncol= 9\n\tvsize = 720  offset = 63\n"
+            "Beginning output at step 10\nOutput finished\n\n"
+            "sample step 14:\toutsamples size= 56  maxsize = 80  ncol= 9\n\tvsize = 720  offset = 126\n"
+            "Beginning output at step 15\nOutput finished\n\n")
+    assert want in log, log
     assert "r2 0 -1" in tail
 
 
