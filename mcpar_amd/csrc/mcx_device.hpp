@@ -308,6 +308,8 @@ struct SegArgs {
   const float *winv;  // winv[i] = 1/(i+1), i = main-loop step index (host-computed, correctly rounded)
   float *musig_own;   // this shard's musigall slot, written after local step snap_after (or never: -1)
   int snap_after;
+  const float *zpre;  // pre-generated normals Z[nsteps][n][d] and accept thresholds U[nsteps][n] of this
+  const float *upre;  // launch (k_gen_normals), or null: small-n mode, see k_fused_fast<..., PREGEN>
 };
 
 template <int LPC, int LIK, bool MAIN>
@@ -421,6 +423,37 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
 //   * the lane-group reductions are DPP row operations instead of LDS-crossbar shuffles;
 //   * 1/pwgt comes from a host-built table through a scalar load instead of a VALU division.
 // ---------------------------------------------------------------------------------------------
+// Random numbers of nsteps consecutive local steps for every chain of the shard (small-n mode):
+// Z[s][chain][k] = the normal of parameter k at step t0+s (LOCAL stream), U[s][chain] = the accept
+// threshold (ACCEPT stream; one Philox block serves steps 4b..4b+3, drawn by the lane of the first of
+// them that lies in this launch).  One lane per (step, chain, 4-parameter block): fully parallel.
+template <int LPC>
+__global__ __launch_bounds__(BLOCK) void k_gen_normals(float *__restrict__ Z, float *__restrict__ U, int n,
+                                                       int d, int nsteps, uint32_t t0, uint32_t g0,
+                                                       uint32_t seed)
+{
+  const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t per_step = (size_t)n * LPC;
+  const int s = (int)(gid / per_step);
+  if (s >= nsteps) return;
+  const size_t rem = gid - (size_t)s * per_step;
+  const size_t chain = rem / LPC;
+  const int q = (int)(rem % LPC);
+  const uint32_t t = t0 + (uint32_t)s, g = g0 + (uint32_t)chain;
+  if (4 * q < d) {
+    f32x2 ze, zo;
+    normal4_packed(philox4x32_10(t, g, (uint32_t)q, 0u, seed, ST_LOCAL), ze, zo);
+    *reinterpret_cast<float4 *>(Z + ((size_t)s * n + chain) * d + 4 * q) = make_float4(ze.x, zo.x, ze.y, zo.y);
+  }
+  if (q == 0 && ((t & 3u) == 0u || s == 0)) {
+    const u32x4 aw = philox4x32_10(t >> 2, g, 0u, 0u, seed, ST_ACCEPT);
+    for (uint32_t w = t & 3u; w < 4u; ++w) {
+      const int s2 = s + (int)(w - (t & 3u));
+      if (s2 < nsteps) U[(size_t)s2 * n + chain] = u24(pick_word(aw, w));
+    }
+  }
+}
+
 // value of lane `owner` of this lane's LPC-group (owner is wave-uniform), by DPP
 template <int LPC>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t owner, int q)
@@ -446,7 +479,11 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t owner, int 
   return (uint32_t)r;
 }
 
-template <int LPC, bool MAIN, int LIK = LIK_ROSEN1>
+// PREGEN: the normals and accept thresholds of the launch were produced beforehand by k_gen_normals
+// (same functions, same bits) and are streamed in with a 4-step register prefetch ring.  With few
+// chains the fused kernel is bound by the latency of one wave's instruction stream, two thirds of which
+// is the random-number work -- which does not depend on the chain state and can run on the idle SIMDs.
+template <int LPC, bool MAIN, int LIK = LIK_ROSEN1, bool PREGEN = false>
 __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
 {
   static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX,
@@ -497,10 +534,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
   float *sl = a.samp_x ? a.samp_ly + chain : nullptr;
   const size_t sx_stride = (size_t)a.n * d, sl_stride = (size_t)a.n;
 
-  for (int s = 0; s < a.nsteps; ++s) {
-    const uint32_t t = a.t0 + (uint32_t)s;
-    f32x2 ze, zo;
-    normal4_packed(philox4x32_10(t, g, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
+  // one Metropolis step given this lane's four normals (ze = z0,z2; zo = z1,z3) and the accept threshold
+  auto step = [&](int s, f32x2 ze, f32x2 zo, float u, float winv_s) {
     const f32x2 pe = fma2(te, ze, xe), po = fma2(to, zo, xo);  // src/mcpar.cc:302-312
     float acc = 0.0f;
     if (LIK == LIK_ROSEN1) {
@@ -558,22 +593,15 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
     } else {
       lyt = 0.0f - group_sum<LPC>(acc);
     }
-    // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
-    // lanes of a chain split the work: lane q draws block b for b % LPC == q, once per 4*LPC steps.
-    const uint32_t blk = t >> 2;
-    if ((blk & ~(uint32_t)(LPC - 1)) != ablk) {
-      ablk = blk & ~(uint32_t)(LPC - 1);
-      aw = philox4x32_10(ablk + (uint32_t)q, g, 0u, 0u, a.seed, ST_ACCEPT);
-    }
-    const uint32_t word = group_bcast<LPC>(pick_word(aw, t & 3u), blk & (uint32_t)(LPC - 1), q);
-    const bool take = accept_decision(lyt, ly, 1.0f, word);  // src/mcpar.cc:62-75
+    // src/mcpar.cc:62-75 (cfac = 1 for local proposals)
+    const bool take = u < (PREGEN ? expf_v1_sel(lyt - ly) : expf_v1(lyt - ly));
     xe = take ? pe : xe;
     xo = take ? po : xo;
     ly = take ? lyt : ly;
     cnt += take ? 1u : 0u;
     wacc += (uint32_t)__popcll(__ballot(take && q == 0));
     if (MAIN) {
-      const f32x2 w2 = splat2(a.winv[a.isamp0 + s]);  // src/mcpar.cc:186-187
+      const f32x2 w2 = splat2(winv_s);               // src/mcpar.cc:186-187
       const f32x2 de = xe - me, dO = xo - mo;         // src/mcpar.cc:199-202
       me = fma2(de, w2, me);
       mo = fma2(dO, w2, mo);
@@ -596,6 +624,61 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
           if (live) *reinterpret_cast<float4 *>(sx + row * sx_stride) = make_float4(xe.x, xo.x, xe.y, xo.y);
           if (q == 0) sl[row * sl_stride] = ly;
         }
+      }
+    }
+  };
+
+  if (!PREGEN) {
+    for (int s = 0; s < a.nsteps; ++s) {
+      const uint32_t t = a.t0 + (uint32_t)s;
+      f32x2 ze, zo;
+      normal4_packed(philox4x32_10(t, g, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
+      // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
+      // lanes of a chain split the work: lane q draws block b for b % LPC == q, once per 4*LPC steps.
+      const uint32_t blk = t >> 2;
+      if ((blk & ~(uint32_t)(LPC - 1)) != ablk) {
+        ablk = blk & ~(uint32_t)(LPC - 1);
+        aw = philox4x32_10(ablk + (uint32_t)q, g, 0u, 0u, a.seed, ST_ACCEPT);
+      }
+      const uint32_t word = group_bcast<LPC>(pick_word(aw, t & 3u), blk & (uint32_t)(LPC - 1), q);
+      step(s, ze, zo, u24(word), MAIN ? a.winv[a.isamp0 + s] : 1.0f);
+    }
+  } else {
+    // Batches of P steps, double buffered: at the top of a batch every load of it (issued one whole
+    // batch earlier) is awaited at once and moved to `cur`, then the loads of the next batch are issued,
+    // then the P steps run without touching memory counters (a per-step wait would expose the full
+    // load latency every step: the counters retire in order).
+    constexpr int P = 8;
+    const float *zp = a.zpre + (live ? off : 0), *up = a.upre + chain;  // idle lanes read a valid address
+    const float *wp = MAIN ? a.winv + a.isamp0 : a.upre;                 // (burn-in: any valid address)
+    const int last = a.nsteps - 1;
+    float4 nxt[P], cur[P];
+    float nxu[P], cuu[P], nxw[P], cuw[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {  // indices are clamped instead of branched on: straight-line loads
+      const int sn = k < last ? k : last;
+      nxt[k] = *reinterpret_cast<const float4 *>(zp + (size_t)sn * sx_stride);
+      nxu[k] = up[(size_t)sn * sl_stride];
+      nxw[k] = wp[sn];
+    }
+    for (int s0 = 0; s0 < a.nsteps; s0 += P) {
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        cur[k] = nxt[k];
+        cuu[k] = nxu[k];
+        cuw[k] = nxw[k];
+      }
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const int sn = s0 + P + k < last ? s0 + P + k : last;
+        nxt[k] = *reinterpret_cast<const float4 *>(zp + (size_t)sn * sx_stride);
+        nxu[k] = up[(size_t)sn * sl_stride];
+        nxw[k] = wp[sn];
+      }
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const int s = s0 + k;
+        if (s < a.nsteps) step(s, f32x2{cur[k].x, cur[k].z}, f32x2{cur[k].y, cur[k].w}, cuu[k], cuw[k]);
       }
     }
   }

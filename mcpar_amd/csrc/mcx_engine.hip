@@ -277,13 +277,12 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   default: return fail(MCX_ERR_UNSUPPORTED, "internal: register Murray kernels cover np <= 32"); \
   }
 
-// the two fused-kernel families are compiled in their own translation units (mcx_k_fast.hip,
-// mcx_k_generic_*.hip) so that the library builds in parallel; see mcx_launch.hpp
-static int launch_fused(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st)
+// The fused-kernel families are compiled in their own translation units (mcx_k_fast.hip,
+// mcx_k_pregen.hip, mcx_k_generic_*.hip) so that the library builds in parallel; see mcx_launch.hpp.
+static int launch_fused_plain(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st, bool fast)
 {
   hipError_t err;
-  const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
-  if (lpc <= 8 && fast_lik && a.diag && a.vec4 && !a.mask) err = mcxk_launch_fast(lpc, lik, main, a, st);  // hot path
+  if (fast) err = mcxk_launch_fast(lpc, lik, main, a, st);  // hot path
   else err = main ? mcxk_launch_generic_main(lpc, lik, a, st) : mcxk_launch_generic_burn(lpc, lik, a, st);
   if (err == hipErrorInvalidValue) return fail(MCX_ERR_UNSUPPORTED, "no fused kernel for lanes/chain = %d, likelihood %d", lpc, lik);
   HIPCHK(err);
@@ -346,7 +345,7 @@ struct mcx_engine {
   int nslots = 0;
   DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
   DevBuf<int> active0, active1, nact, ntrace;
-  DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev;
+  DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev, zpre, upre;
   bool pinit_staged = false;
   DevBuf<uint8_t> mask;
   // host staging
@@ -356,6 +355,7 @@ struct mcx_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int opt_stride = 1;
+  int opt_split = -1;  // small-n mode: -1 auto, 0 off, 1 on (when the hot-path kernel applies)
   int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0;
   int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
   bool have_run = false, diag = true, xchg_pending = false;
@@ -399,6 +399,45 @@ struct ProfScope {
     e->evs.push_back(p);
   }
 };
+
+// Launch one segment of consecutive local steps.  Small-n mode (MCX_OPT_SPLIT_RNG): with few chains the
+// fused kernel is bound by the latency of a single wave's instruction stream, two thirds of it random
+// numbers that do not depend on the chain state; they are then generated for SPLIT_CHUNK steps at a time
+// by a fully parallel kernel on the otherwise idle SIMDs and streamed into the step kernel.
+constexpr int SPLIT_CHUNK = 64;
+constexpr size_t SPLIT_AUTO_MAX_WAVES = 640;
+
+static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t st)
+{
+  const int lik = e->lik.kind, lpc = e->lpc;
+  const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
+  const bool fast = lpc <= 8 && fast_lik && a.diag && a.vec4 && !a.mask;
+  const size_t waves = ((size_t)a.n * lpc + 63) / 64;
+  const bool split = fast && (e->opt_split > 0 || (e->opt_split < 0 && waves < SPLIT_AUTO_MAX_WAVES));
+  if (!split) return launch_fused_plain(lpc, lik, main, a, st, fast);
+  // generator and step kernel alternate on the engine's stream (overlapping them on two streams was
+  // measured slower: the cross-stream event waits cost more than the generator, which is ~10 % of a chunk)
+  MCXCHK(e->zpre.alloc((size_t)SPLIT_CHUNK * a.n * a.d));
+  MCXCHK(e->upre.alloc((size_t)SPLIT_CHUNK * a.n));
+  for (int c0 = 0; c0 < a.nsteps; c0 += SPLIT_CHUNK) {
+    const int ns = std::min(SPLIT_CHUNK, a.nsteps - c0);
+    HIPCHK(mcxk_launch_gen(lpc, e->zpre.p, e->upre.p, a.n, a.d, ns, a.t0 + (uint32_t)c0, a.g0, a.seed, st));
+    SegArgs b = a;
+    b.nsteps = ns;
+    b.t0 = a.t0 + (uint32_t)c0;
+    b.isamp0 = a.isamp0 + c0;
+    b.snap_after = (a.snap_after >= c0 && a.snap_after < c0 + ns) ? a.snap_after - c0 : -1;
+    if (b.samp_x && a.samp_stride <= 1) {
+      b.samp_x += (size_t)c0 * a.n * a.d;
+      b.samp_ly += (size_t)c0 * a.n;
+    }
+    b.zpre = e->zpre.p;
+    b.upre = e->upre.p;
+    HIPCHK(mcxk_launch_fast_pregen(lpc, lik, main, b, st));
+    e->cnt.kernel_launches += 2;
+  }
+  return MCX_OK;
+}
 
 static void prof_collect(mcx_engine *e)
 {
@@ -480,7 +519,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
-  e->h_ptrial.release(); e->h_lytrial.release();
+  e->h_ptrial.release(); e->h_lytrial.release(); e->zpre.release(); e->upre.release();
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MCX_OK;
@@ -519,6 +558,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
     break;
   case MCX_OPT_PROFILE: e->opt_profile = value ? 1 : 0; break;
   case MCX_OPT_EAGER_EXCHANGE: e->opt_eager = value ? 1 : 0; break;
+  case MCX_OPT_SPLIT_RNG: e->opt_split = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_STREAM:
     if (e->own_stream && e->stream) {
       (void)hipStreamSynchronize(e->stream);
@@ -886,6 +926,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   sa.samp_stride = e->opt_stride;
   sa.musig_own = e->musigall.p + 2 * (size_t)e->rank * e->ntot;
   sa.snap_after = -1;
+  sa.zpre = sa.upre = nullptr;
 
   const PlanCfg cfg = {nsamp, nburn, e->SYNCSTEP, e->PLOCAL, e->seed, e->tbase, e->size > 1, e->opt_eager != 0,
                        fused, e->ofn != nullptr, e->opt_maxseg};
@@ -900,7 +941,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
         sa.mask = e->opt_mask ? e->mask.p + (size_t)isamp * n : nullptr;
         sa.nsteps = steps; sa.t0 = t0; sa.isamp0 = 0; sa.snap_after = -1;
         ProfScope ps(e, MCX_K_FUSED_BURN, (uint64_t)steps * n);
-        MCXCHK(launch_fused(e->lpc, e->lik.kind, false, sa, st));
+        MCXCHK(launch_fused(e, false, sa, st));
       } else {
         for (int s = 0; s < steps; ++s) {
           StepArgs a;
@@ -961,7 +1002,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
           e->published_steps = isamp + it.aux + 1;
         }
         ProfScope ps(e, MCX_K_FUSED_MAIN, (uint64_t)steps * n);
-        MCXCHK(launch_fused(e->lpc, e->lik.kind, true, sa, st));
+        MCXCHK(launch_fused(e, true, sa, st));
       } else {
         for (int s = 0; s < steps; ++s) {
           StepArgs a;

@@ -195,6 +195,28 @@ __device__ __forceinline__ void sincos2pi_v1x2(uint32_t wa, uint32_t wb, f32x2 &
   c = f32x2{(ka == 1u || ka == 2u) ? -cv.x : cv.x, (kb == 1u || kb == 2u) ? -cv.y : cv.y};
 }
 
+// expf_v1 with the range checks as selects instead of branches (same bits; for latency-bound code)
+__device__ __forceinline__ float expf_v1_sel(float x)
+{
+  const float fn = __builtin_floorf(__builtin_fmaf(x, 1.44269504f, 0.5f));
+  float r = __builtin_fmaf(fn, -0.693359375f, x);
+  r = __builtin_fmaf(fn, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  const float z = r * r;
+  float y = __builtin_fmaf(p, z, r);
+  y = y + 1.0f;
+  const int n = (int)fn;
+  const int n1 = n >> 1;
+  y = y * as_f32((uint32_t)(n1 + 127) << 23);
+  y = y * as_f32((uint32_t)(n - n1 + 127) << 23);
+  return x > 88.72283f ? __builtin_inff() : (x < -87.33654f ? 0.0f : y);  // NaN falls through as NaN
+}
+
 // expf_v1 on two values: same operations in the same order; the range checks are selects
 __device__ __forceinline__ f32x2 expf_v1x2(f32x2 x)
 {

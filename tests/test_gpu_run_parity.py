@@ -242,3 +242,36 @@ def test_degenerate_sizes(d, n, nburn, nsamp, pl):
     kind = O.VL_GAUSSIAN if d % 2 else O.VL_ROSENBROCK1
     eo, eg = run_pair(kind, d, n, nburn, nsamp, pl)
     assert_same(eo, eg, "degenerate")
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("kind,d,n,nburn,nsamp,pl", [(O.VL_ROSENBROCK1, 16, 333, 120, 150, 0.9), (O.VL_ROSENBROCK1, 8, 70, 59, 66, 1.0),
+                                                     (O.VL_GAUSSIAN, 12, 40, 110, 129, 0.8), (O.VL_GAUSSMIX, 32, 64, 60, 70, 0.9),
+                                                     (O.VL_ROSENBROCK1, 4, 1, 130, 3, 1.0)])
+def test_small_n_mode_split_rng(split, kind, d, n, nburn, nsamp, pl):
+    """MCX_OPT_SPLIT_RNG on/off: pre-generated normals streamed into the step kernel vs generated in it;
+    segment lengths straddle the 64-step chunk and the 4-step accept blocks"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    p = O.default_pinit(d, n)
+    params, K = None, 0
+    if kind == O.VL_GAUSSIAN:
+        params = np.concatenate([np.linspace(-1, 1, d), np.linspace(0.5, 2, d)]).astype(np.float32)
+    if kind == O.VL_GAUSSMIX:
+        K = 8
+        params = mix_params(d, K)
+    vo, _k1 = O.make_vlfunc(kind, d, params, K)
+    eo = O.Engine(d, n, pl=pl)
+    eo.run(nsamp, nburn, p, vo)
+    vg, _k2 = M.make_vlfunc(kind, d, params, K)
+    eg = M.Engine(d, n, pl=pl)
+    eg.set_option(E.OPT_SPLIT_RNG, split)
+    eg.set_option(E.OPT_SAMPLE_STRIDE, 1 + split)  # also the thinned store through the chunked launches
+    eg.run(nsamp, nburn, p, vg)
+    c = eg.counters
+    assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+    np.testing.assert_array_equal(eg.accept_counts, eo.accept_counts)
+    for name in ("state", "loglike", "mean", "var", "musigall", "chol"):
+        assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
+    want = eo.samples.reshape(nsamp, n, d + 1)[::1 + split].reshape(-1, d + 1)
+    assert np.array_equal(eg.samples.view(np.uint32), want.view(np.uint32))
