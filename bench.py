@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU (weak scaling, the default) or in total (--strong)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --chains is the total, split evenly over the GPUs")
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--nburn", type=int, default=500)
     ap.add_argument("--nsamp", type=int, default=1000)
@@ -114,7 +115,7 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     nsh = world
     M.load().mcx_set_device(local_rank)
-    d, n, nburn, nsamp = args.dim, args.chains, args.nburn, args.nsamp
+    d, n, nburn, nsamp = args.dim, (args.chains // world if args.strong else args.chains), args.nburn, args.nsamp
     emit = not args.no_samples
     eng = M.Engine(d, n, nshards=nsh, shard=rank, pl=args.pl)
     eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
@@ -276,7 +277,7 @@ def main():
             "metric": "chain-steps/sec (all chains), 16-D Rosenbrock",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "mcpar-rosen2 (C3): Rosenbrock1(%d) x %d chains/GPU, R-local job "
                                    "(pl=%.2f, nburn=%d, nsamp=%d, sync=10), one bench step = one full run()"
                                    % (d, n, args.pl, nburn, nsamp),
