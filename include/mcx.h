@@ -133,7 +133,7 @@ enum {
   MCX_OPT_STREAM = 6,      /* value = hipStream_t to run on (default: engine-owned stream) */
   MCX_OPT_SAMPLE_STRIDE = 8, /* k >= 1: keep only main-loop steps with isamp % k == 0 in the sample store
                               (thinning; the reference keeps every step, k = 1) [default 1] */
-  MCX_OPT_SPLIT_RNG = 9,   /* small-n mode: random numbers of 64 steps at a time from a separate, fully parallel
+  MCX_OPT_SPLIT_RNG = 9,   /* small-n mode: random numbers of 32-256 steps at a time from a separate, fully parallel
                               kernel, streamed into the step kernel (same bits).  -1 auto [default: when the
                               chains fill fewer than 640 wavefronts], 0 off, 1 on */
   MCX_OPT_EAGER_EXCHANGE = 7 /* 0 [default]: gather the latest sync-point snapshot only when a Murray step (or

@@ -402,9 +402,10 @@ struct ProfScope {
 
 // Launch one segment of consecutive local steps.  Small-n mode (MCX_OPT_SPLIT_RNG): with few chains the
 // fused kernel is bound by the latency of a single wave's instruction stream, two thirds of it random
-// numbers that do not depend on the chain state; they are then generated for SPLIT_CHUNK steps at a time
+// numbers that do not depend on the chain state; they are then generated for 32..256 steps at a time
 // by a fully parallel kernel on the otherwise idle SIMDs and streamed into the step kernel.
-constexpr int SPLIT_CHUNK = 64;
+constexpr int SPLIT_CHUNK_MAX = 256;
+constexpr size_t SPLIT_Z_BYTES = (size_t)32 << 20;  // keep a chunk's normals L2-resident (4 MiB per XCD)
 constexpr size_t SPLIT_AUTO_MAX_WAVES = 640;
 
 static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t st)
@@ -417,6 +418,8 @@ static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t 
   if (!split) return launch_fused_plain(lpc, lik, main, a, st, fast);
   // generator and step kernel alternate on the engine's stream (overlapping them on two streams was
   // measured slower: the cross-stream event waits cost more than the generator, which is ~10 % of a chunk)
+  const size_t per_step = (size_t)a.n * a.d * sizeof(float);
+  const int SPLIT_CHUNK = (int)std::max<size_t>(32, std::min<size_t>(SPLIT_CHUNK_MAX, (SPLIT_Z_BYTES / per_step) & ~(size_t)7));
   MCXCHK(e->zpre.alloc((size_t)SPLIT_CHUNK * a.n * a.d));
   MCXCHK(e->upre.alloc((size_t)SPLIT_CHUNK * a.n));
   for (int c0 = 0; c0 < a.nsteps; c0 += SPLIT_CHUNK) {
