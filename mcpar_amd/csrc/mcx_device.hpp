@@ -310,6 +310,7 @@ struct SegArgs {
   int snap_after;
   const float *zpre;  // pre-generated normals Z[nsteps][n][d] and accept thresholds U[nsteps][n] of this
   const float *upre;  // launch (k_gen_normals), or null: small-n mode, see k_fused_fast<..., PREGEN>
+  float *trash;       // PREGEN: 16 B per lane where lanes that own no parameters dump their stores
 };
 
 template <int LPC, int LIK, bool MAIN>
@@ -533,6 +534,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
   float *sx = a.samp_x ? a.samp_x + off : nullptr;
   float *sl = a.samp_x ? a.samp_ly + chain : nullptr;
   const size_t sx_stride = (size_t)a.n * d, sl_stride = (size_t)a.n;
+  float *sxv = (PREGEN && a.samp_x) ? (live ? a.samp_x + off : a.trash + 4 * gid) : nullptr;  // per-lane pointer
+  const size_t sxv_stride = live ? sx_stride : 0;
 
   // one Metropolis step given this lane's four normals (ze = z0,z2; zo = z1,z3) and the accept threshold
   auto step = [&](int s, f32x2 ze, f32x2 zo, float u, float winv_s) {
@@ -614,7 +617,14 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
         slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
       }
       if (sx) {  // src/mcpar.cc:177-182
-        if (a.samp_stride <= 1) {
+        if (PREGEN && a.samp_stride <= 1) {
+          // latency-bound mode: no exec-mask regions -- idle lanes store to their trash slot, every lane
+          // of the chain stores the (same) log-likelihood
+          *reinterpret_cast<float4 *>(sxv) = make_float4(xe.x, xo.x, xe.y, xo.y);
+          *sl = ly;
+          sxv += sxv_stride;
+          sl += sl_stride;
+        } else if (a.samp_stride <= 1) {
           if (live) *reinterpret_cast<float4 *>(sx) = make_float4(xe.x, xo.x, xe.y, xo.y);
           if (q == 0) *sl = ly;
           sx += sx_stride;
@@ -647,40 +657,43 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
     // Batches of P steps, double buffered: at the top of a batch every load of it (issued one whole
     // batch earlier) is awaited at once and moved to `cur`, then the loads of the next batch are issued,
     // then the P steps run without touching memory counters (a per-step wait would expose the full
-    // load latency every step: the counters retire in order).
+    // load latency every step: the counters retire in order).  Z, U and the 1/pwgt table are padded by
+    // 2P steps, so the prefetch never needs a bounds check; pointers advance by addition only.
     constexpr int P = 8;
-    const float *zp = a.zpre + (live ? off : 0), *up = a.upre + chain;  // idle lanes read a valid address
-    const float *wp = MAIN ? a.winv + a.isamp0 : a.upre;                 // (burn-in: any valid address)
-    const int last = a.nsteps - 1;
+    const float *zq = a.zpre + (live ? off : 0), *uq = a.upre + chain;  // idle lanes read a valid address
+    const float *wq = MAIN ? a.winv + a.isamp0 : a.upre;                 // (burn-in: any valid address)
     float4 nxt[P], cur[P];
     float nxu[P], cuu[P], nxw[P], cuw[P];
+    auto fetch = [&]() {
+      const float *zk = zq, *uk = uq;
 #pragma unroll
-    for (int k = 0; k < P; ++k) {  // indices are clamped instead of branched on: straight-line loads
-      const int sn = k < last ? k : last;
-      nxt[k] = *reinterpret_cast<const float4 *>(zp + (size_t)sn * sx_stride);
-      nxu[k] = up[(size_t)sn * sl_stride];
-      nxw[k] = wp[sn];
-    }
-    for (int s0 = 0; s0 < a.nsteps; s0 += P) {
+      for (int k = 0; k < P; ++k) {
+        nxt[k] = *reinterpret_cast<const float4 *>(zk);
+        nxu[k] = *uk;
+        nxw[k] = wq[k];
+        zk += sx_stride;
+        uk += sl_stride;
+      }
+      zq = zk;
+      uq = uk;
+      wq += P;
+    };
+    fetch();
+    int s0 = 0;
+    for (; s0 + P <= a.nsteps; s0 += P) {  // full batches: no per-step bounds test
 #pragma unroll
       for (int k = 0; k < P; ++k) {
         cur[k] = nxt[k];
         cuu[k] = nxu[k];
         cuw[k] = nxw[k];
       }
+      fetch();
 #pragma unroll
-      for (int k = 0; k < P; ++k) {
-        const int sn = s0 + P + k < last ? s0 + P + k : last;
-        nxt[k] = *reinterpret_cast<const float4 *>(zp + (size_t)sn * sx_stride);
-        nxu[k] = up[(size_t)sn * sl_stride];
-        nxw[k] = wp[sn];
-      }
-#pragma unroll
-      for (int k = 0; k < P; ++k) {
-        const int s = s0 + k;
-        if (s < a.nsteps) step(s, f32x2{cur[k].x, cur[k].z}, f32x2{cur[k].y, cur[k].w}, cuu[k], cuw[k]);
-      }
+      for (int k = 0; k < P; ++k) step(s0 + k, f32x2{cur[k].x, cur[k].z}, f32x2{cur[k].y, cur[k].w}, cuu[k], cuw[k]);
     }
+#pragma unroll
+    for (int k = 0; k < P; ++k)  // the last, partial batch
+      if (s0 + k < a.nsteps) step(s0 + k, f32x2{nxt[k].x, nxt[k].z}, f32x2{nxt[k].y, nxt[k].w}, nxu[k], nxw[k]);
   }
 
   if (live) *reinterpret_cast<float4 *>(a.x + off) = make_float4(xe.x, xo.x, xe.y, xo.y);

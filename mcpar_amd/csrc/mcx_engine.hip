@@ -345,7 +345,7 @@ struct mcx_engine {
   int nslots = 0;
   DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
   DevBuf<int> active0, active1, nact, ntrace;
-  DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev, zpre, upre;
+  DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev, zpre, upre, trash;
   bool pinit_staged = false;
   DevBuf<uint8_t> mask;
   // host staging
@@ -420,8 +420,10 @@ static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t 
   // measured slower: the cross-stream event waits cost more than the generator, which is ~10 % of a chunk)
   const size_t per_step = (size_t)a.n * a.d * sizeof(float);
   const int SPLIT_CHUNK = (int)std::max<size_t>(32, std::min<size_t>(SPLIT_CHUNK_MAX, (SPLIT_Z_BYTES / per_step) & ~(size_t)7));
-  MCXCHK(e->zpre.alloc((size_t)SPLIT_CHUNK * a.n * a.d));
-  MCXCHK(e->upre.alloc((size_t)SPLIT_CHUNK * a.n));
+  constexpr int PAD = 16;  // the step kernel prefetches two 8-step batches ahead without bounds checks
+  MCXCHK(e->zpre.alloc((size_t)(SPLIT_CHUNK + PAD) * a.n * a.d));
+  MCXCHK(e->upre.alloc((size_t)(SPLIT_CHUNK + PAD) * a.n));
+  MCXCHK(e->trash.alloc(4 * (size_t)a.n * lpc));
   for (int c0 = 0; c0 < a.nsteps; c0 += SPLIT_CHUNK) {
     const int ns = std::min(SPLIT_CHUNK, a.nsteps - c0);
     HIPCHK(mcxk_launch_gen(lpc, e->zpre.p, e->upre.p, a.n, a.d, ns, a.t0 + (uint32_t)c0, a.g0, a.seed, st));
@@ -436,6 +438,7 @@ static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t 
     }
     b.zpre = e->zpre.p;
     b.upre = e->upre.p;
+    b.trash = e->trash.p;
     HIPCHK(mcxk_launch_fast_pregen(lpc, lik, main, b, st));
     e->cnt.kernel_launches += 2;
   }
@@ -522,7 +525,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
-  e->h_ptrial.release(); e->h_lytrial.release(); e->zpre.release(); e->upre.release();
+  e->h_ptrial.release(); e->h_lytrial.release(); e->zpre.release(); e->upre.release(); e->trash.release();
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MCX_OK;
@@ -905,7 +908,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     HIPCHK(hipStreamSynchronize(st));      // correctly rounded on the host; rebuilt only when it grows
     e->h_winv.resize((size_t)nsamp);
     for (int i = 0; i < nsamp; ++i) e->h_winv[(size_t)i] = 1.0f / (float)(i + 1);
-    MCXCHK(e->winv_tab.alloc((size_t)nsamp));
+    MCXCHK(e->winv_tab.alloc((size_t)nsamp + 16));  // + the small-n kernel's unchecked prefetch distance
     HIPCHK(hipMemcpyAsync(e->winv_tab.p, e->h_winv.data(), e->h_winv.size() * sizeof(float), hipMemcpyHostToDevice, st));
   }
   e->cnt = mcx_counters{};
@@ -930,6 +933,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   sa.musig_own = e->musigall.p + 2 * (size_t)e->rank * e->ntot;
   sa.snap_after = -1;
   sa.zpre = sa.upre = nullptr;
+  sa.trash = nullptr;
 
   const PlanCfg cfg = {nsamp, nburn, e->SYNCSTEP, e->PLOCAL, e->seed, e->tbase, e->size > 1, e->opt_eager != 0,
                        fused, e->ofn != nullptr, e->opt_maxseg};
