@@ -116,6 +116,22 @@ typedef int (*mcx_exchange_fn)(void *ctx, int phase, void *musigall_dev, size_t 
                                int shard, int nshards, void *stream);
 int mcx_set_exchange(mcx_engine *e, mcx_exchange_fn fn, void *ctx);
 
+/* The exchange the library ships: an in-place ncclAllGather (RCCL over xGMI) of the musigall slots --
+ * sendbuff = musigall + shard*2*ntot, 2*ntot floats per shard, the slot layout of src/mcpar.cc:206 -- on a
+ * side stream, BEGIN = enqueue behind the engine's stream, WAIT = the engine's stream waits for it.
+ * One process (or thread) per GPU, communicator rank = shard.  librccl.so.1 is loaded on first use.
+ *   rank 0:     mcx_rccl_unique_id(id);  ship the MCX_RCCL_ID_BYTES bytes to every rank (MPI_Bcast, ...)
+ *   every rank: mcx_exchange_rccl_init(e, id);     collective, like MPI_Comm_dup at src/mcpar.cc:228
+ * or hand over a communicator the caller already has (ncclComm_t, rank == shard, nranks == nshards). */
+#define MCX_RCCL_ID_BYTES 128
+int mcx_rccl_available(void); /* 1 / 0 (mcx_last_error says why not) */
+int mcx_rccl_unique_id(void *id);
+int mcx_exchange_rccl_init(mcx_engine *e, const void *id);
+int mcx_exchange_rccl_adopt(mcx_engine *e, void *nccl_comm);
+int mcx_exchange_rccl_destroy(mcx_engine *e); /* also done by mcx_destroy */
+/* run the installed exchange hook once, now (BEGIN, WAIT, drain): start-up self-check / tests */
+int mcx_debug_exchange(mcx_engine *e);
+
 /* called where the reference dumps output (isamp % outstep == 0 && isamp > 0, and after the
  * last step: src/mcpar.cc:110-119,212) with the number of main-loop steps completed. */
 typedef int (*mcx_output_fn)(void *ctx, int steps_done);
@@ -214,6 +230,7 @@ const char *mcx_last_error(void);
 int mcx_abi_version(void);
 int mcx_device_info(char *name, size_t namelen, int *cu_count, size_t *hbm_bytes);
 int mcx_set_device(int device);
+int mcx_device_count(int *n);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:
  * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
  * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf,

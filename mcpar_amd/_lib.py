@@ -85,6 +85,13 @@ def load():
         "mcx_abi_version": [],
         "mcx_device_info": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
         "mcx_set_device": [C.c_int],
+        "mcx_device_count": [C.POINTER(C.c_int)],
+        "mcx_rccl_available": [],
+        "mcx_rccl_unique_id": [vp],
+        "mcx_exchange_rccl_init": [vp, vp],
+        "mcx_exchange_rccl_adopt": [vp, vp],
+        "mcx_exchange_rccl_destroy": [vp],
+        "mcx_debug_exchange": [vp],
         "mcx_debug_numerics": [C.c_int, C.c_int, u32p, u32p],
         "mcx_debug_normals": [C.c_uint32] * 6 + [C.c_int, fp],
         "mcx_debug_sqrt_sweep": [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), u32p],

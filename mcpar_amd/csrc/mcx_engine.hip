@@ -7,6 +7,9 @@
 #include "mcx_device.hpp"
 #include "mcx_launch.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: librccl.so.1 is loaded at run time (mcx_rccl_*), never linked
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -363,6 +366,11 @@ struct mcx_engine {
   LikDev lik;
   mcx_exchange_fn xfn = nullptr;
   void *xctx = nullptr;
+  // native RCCL exchange (mcx_exchange_rccl_*): in-place ncclAllGather of the musigall slots on a side stream
+  ncclComm_t xcomm = nullptr;
+  bool xcomm_owned = false;
+  hipStream_t xstream = nullptr;
+  hipEvent_t xready = nullptr, xdone = nullptr;
   mcx_output_fn ofn = nullptr;
   void *octx = nullptr;
   mcx_counters cnt{};
@@ -519,6 +527,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   prof_collect(e);
+  (void)mcx_exchange_rccl_destroy(e);
   e->pvals.release(); e->ptrial.release(); e->mu.release(); e->sig.release(); e->psum2.release();
   e->mutrial.release(); e->sigtrial.release(); e->musigall.release(); e->winvall.release();
   e->lylast.release(); e->lytrial.release(); e->cfac.release(); e->cmax.release(); e->cov.release();
@@ -772,6 +781,180 @@ static int exchange_begin(mcx_engine *e)
     return fail(MCX_ERR_EXCHANGE, "exchange hook failed in BEGIN");
   e->xchg_pending = true;
   e->cnt.exchanges++;
+  return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Native RCCL exchange: the MPI_Allgather(MPI_IN_PLACE, ..., musigall, 2*ntot, MPI_FLOAT) of
+// src/mcpar.cc:127-140 as an in-place ncclAllGather over xGMI.  One process (or thread) per GPU, one
+// communicator rank per shard, slot layout of src/mcpar.cc:206 (rank r owns floats [r*2*ntot, (r+1)*2*ntot)).
+// BEGIN enqueues the collective on a side stream behind everything already queued on the engine's
+// stream; WAIT makes the engine's stream wait for it -- so under the reference's own schedule
+// (MCX_OPT_EAGER_EXCHANGE) the gather overlaps the next segment of local steps.  librccl.so.1 is loaded
+// on first use: single-GPU users never need it.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;
+};
+RcclApi g_rccl;
+
+bool rccl_load()
+{
+  if (g_rccl.handle) return true;
+  if (!g_rccl.why.empty()) return false;
+  // if another RCCL is already in the process (e.g. the one PyTorch-ROCm ships) the soname resolves to it
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!h) {
+    g_rccl.why = std::string("librccl.so.1 not loadable: ") + (dlerror() ? dlerror() : "?");
+    return false;
+  }
+  bool ok = true;
+  auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) { ok = false; g_rccl.why = std::string("missing RCCL symbol ") + n; } return p; };
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
+  g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) return false;
+  g_rccl.handle = h;
+  return true;
+}
+
+#define NCCLCHK(expr)                                                                          \
+  do {                                                                                         \
+    ncclResult_t r_ = (expr);                                                                  \
+    if (r_ != ncclSuccess)                                                                     \
+      return fail(MCX_ERR_EXCHANGE, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));        \
+  } while (0)
+
+// the exchange hook itself: mcx_exchange_fn with ctx = the engine
+int rccl_exchange(void *ctx, int phase, void *dev, size_t slot, int shard, int nshards, void *stream)
+{
+  mcx_engine *e = static_cast<mcx_engine *>(ctx);
+  hipStream_t st = (hipStream_t)stream;
+  (void)nshards;
+  if (phase == MCX_XCHG_BEGIN) {
+    HIPCHK(hipEventRecord(e->xready, st));
+    HIPCHK(hipStreamWaitEvent(e->xstream, e->xready, 0));
+    float *base = static_cast<float *>(dev);
+    NCCLCHK(g_rccl.AllGather(base + slot * (size_t)shard, base, slot, ncclFloat, e->xcomm, e->xstream));  // in place
+    HIPCHK(hipEventRecord(e->xdone, e->xstream));
+  } else {
+    HIPCHK(hipStreamWaitEvent(st, e->xdone, 0));
+  }
+  return 0;
+}
+
+int rccl_install(mcx_engine *e, ncclComm_t comm, bool owned)
+{
+  int cnt = 0, rk = -1;
+  NCCLCHK(g_rccl.CommCount(comm, &cnt));
+  NCCLCHK(g_rccl.CommUserRank(comm, &rk));
+  if (cnt != e->size || rk != e->rank)
+    return fail(MCX_ERR_INVALID, "communicator is rank %d of %d but the engine is shard %d of %d", rk, cnt, e->rank, e->size);
+  if (!e->xstream) HIPCHK(hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking));
+  if (!e->xready) HIPCHK(hipEventCreateWithFlags(&e->xready, hipEventDisableTiming));
+  if (!e->xdone) HIPCHK(hipEventCreateWithFlags(&e->xdone, hipEventDisableTiming));
+  e->xcomm = comm;
+  e->xcomm_owned = owned;
+  e->xfn = rccl_exchange;
+  e->xctx = e;
+  return MCX_OK;
+}
+}  // namespace
+
+extern "C" int mcx_rccl_available(void)
+{
+  if (rccl_load()) return 1;
+  (void)fail(MCX_ERR_EXCHANGE, "%s", g_rccl.why.c_str());
+  return 0;
+}
+
+extern "C" int mcx_rccl_unique_id(void *id)
+{
+  if (!id) return fail(MCX_ERR_INVALID, "id is NULL");
+  if (!rccl_load()) return fail(MCX_ERR_EXCHANGE, "%s", g_rccl.why.c_str());
+  static_assert(sizeof(ncclUniqueId) == MCX_RCCL_ID_BYTES, "MCX_RCCL_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
+  ncclUniqueId u;
+  NCCLCHK(g_rccl.GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof u);
+  return MCX_OK;
+}
+
+extern "C" int mcx_exchange_rccl_init(mcx_engine *e, const void *id)
+{
+  MCXCHK(enter(e));
+  if (!id) return fail(MCX_ERR_INVALID, "id is NULL");
+  if (!rccl_load()) return fail(MCX_ERR_EXCHANGE, "%s", g_rccl.why.c_str());
+  MCXCHK(mcx_exchange_rccl_destroy(e));
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  ncclComm_t comm = nullptr;
+  NCCLCHK(g_rccl.CommInitRank(&comm, e->size, u, e->rank));  // collective over the nshards engines
+  const int rc = rccl_install(e, comm, true);
+  if (rc != MCX_OK) (void)g_rccl.CommDestroy(comm);
+  return rc;
+}
+
+extern "C" int mcx_exchange_rccl_adopt(mcx_engine *e, void *nccl_comm)
+{
+  MCXCHK(enter(e));
+  if (!nccl_comm) return fail(MCX_ERR_INVALID, "communicator is NULL");
+  if (!rccl_load()) return fail(MCX_ERR_EXCHANGE, "%s", g_rccl.why.c_str());
+  MCXCHK(mcx_exchange_rccl_destroy(e));
+  return rccl_install(e, (ncclComm_t)nccl_comm, false);
+}
+
+extern "C" int mcx_exchange_rccl_destroy(mcx_engine *e)
+{
+  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  if (e->xcomm) {
+    (void)hipSetDevice(e->device);
+    if (e->xstream) (void)hipStreamSynchronize(e->xstream);
+    if (e->xcomm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->xcomm);
+    if (e->xfn == rccl_exchange) { e->xfn = nullptr; e->xctx = nullptr; }
+    e->xcomm = nullptr;
+    e->xcomm_owned = false;
+    e->xchg_pending = false;
+  }
+  if (e->xready) { (void)hipEventDestroy(e->xready); e->xready = nullptr; }
+  if (e->xdone) { (void)hipEventDestroy(e->xdone); e->xdone = nullptr; }
+  if (e->xstream) { (void)hipStreamDestroy(e->xstream); e->xstream = nullptr; }
+  return MCX_OK;
+}
+
+// One exchange right now (publish is the caller's business): BEGIN + WAIT + drain.  Lets a test (or a
+// start-up self-check) push the installed hook through the device without running a job.
+extern "C" int mcx_debug_exchange(mcx_engine *e)
+{
+  MCXCHK(enter(e));
+  if (!e->xfn) return fail(MCX_ERR_EXCHANGE, "no exchange hook installed");
+  MCXCHK(exchange_begin(e));
+  MCXCHK(exchange_wait(e));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MCX_OK;
+}
+
+extern "C" int mcx_device_count(int *n)
+{
+  if (!n) return fail(MCX_ERR_INVALID, "n is NULL");
+  *n = 0;
+  MCXCHK(need_device());
+  HIPCHK(hipGetDeviceCount(n));
   return MCX_OK;
 }
 

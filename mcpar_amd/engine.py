@@ -60,6 +60,23 @@ def plan(nsamp, nburn, sync=10, pl=0.9, seed=8675309, tbase=0, nshards=1, eager=
     return [(PLAN_NAMES[it.kind], it.first, it.nsteps, it.aux) for it in items[:n.value]]
 
 
+def device_count():
+    n = C.c_int(0)
+    check(load().mcx_device_count(C.byref(n)))
+    return n.value
+
+
+def rccl_available():
+    return bool(load().mcx_rccl_available())
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId: call on one rank, ship the 128 bytes to every rank, pass them to Engine.rccl_init"""
+    buf = C.create_string_buffer(128)
+    check(load().mcx_rccl_unique_id(buf))
+    return buf.raw
+
+
 def device_info():
     name = C.create_string_buffer(256)
     cu = C.c_int(0)
@@ -121,6 +138,18 @@ class Engine:
         cb = XCHGFN(tramp)
         self._keep.append(cb)
         check(load().mcx_set_exchange(self.h, cb, None))
+
+    def rccl_init(self, unique_id):
+        """install the library's own exchange: in-place ncclAllGather over the nshards engines (collective)"""
+        assert len(unique_id) == 128
+        self._keep.append(unique_id)
+        check(load().mcx_exchange_rccl_init(self.h, C.c_char_p(unique_id)))
+
+    def rccl_destroy(self):
+        check(load().mcx_exchange_rccl_destroy(self.h))
+
+    def debug_exchange(self):
+        check(load().mcx_debug_exchange(self.h))
 
     def set_output_hook(self, pyfn):
         def tramp(ctx, steps_done):

@@ -78,6 +78,9 @@ mcxo_engine *mcxo_create(int np, int nc, int nshards, int shard, float pl, float
 void mcxo_destroy(mcxo_engine *e);
 void mcxo_set_exchange(mcxo_engine *e, mcxo_exchange_fn fn, void *ctx);
 void mcxo_set_threads(mcxo_engine *e, int nthreads);
+/* 1: the Murray sweep runs as plain scalar loops; 0 (default): eight Gaussians at a time with AVX2 when
+ * the CPU has it -- the same IEEE operations per element, hence the same bits (checked by the tests) */
+void mcxo_set_scalar_sweep(int on);
 /* keep_samples: 1 = store every (chain, step) row like MCout (src/mcpar.cc:177-182) */
 void mcxo_set_record(mcxo_engine *e, int keep_samples, int keep_accept_mask);
 

@@ -59,6 +59,7 @@ def lib():
     L.mcxo_destroy.argtypes = [C.c_void_p]
     L.mcxo_set_exchange.argtypes = [C.c_void_p, XFN, C.c_void_p]
     L.mcxo_set_threads.argtypes = [C.c_void_p, C.c_int]
+    L.mcxo_set_scalar_sweep.argtypes = [C.c_int]
     L.mcxo_set_record.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.mcxo_run.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, C.POINTER(VLFunc), fp]
     L.mcxo_run_all.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(fp),

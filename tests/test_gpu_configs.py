@@ -1,0 +1,235 @@
+"""BASELINE.json's configurations at their full per-GPU sizes against the CPU oracle, bit for bit
+(VERDICT r1 item 1): the whole C3 R-local job, C3 R-murray, C5's per-GPU shape as one shard and as two
+shards of one GPU, and a multi-shard run whose exchange hook is asynchronous (side stream + events), so
+that the BEGIN/WAIT contract of mcx_set_exchange is exercised under real overlap.
+
+The oracle's Murray sweep is O(n N d) per rejection pass; its AVX2 form (same bits as the scalar
+statement, tests/test_oracle_numerics.py) keeps each of these cases to tens of seconds of host time."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+THREADS = 16  # the GPU box's CPU share for one GPU
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def mix_params(d, K):
+    """K unit-variance components, means 5k/(K-1) * 1, weights (5, 1, ..., 1)"""
+    means = np.stack([np.full(d, 5.0 * k / (K - 1)) for k in range(K)]).astype(np.float32)
+    return np.concatenate([means.ravel(), [5] + [1] * (K - 1)]).astype(np.float32)
+
+
+def test_c3_full_job_bit_exact():
+    """BASELINE config 3 as benchmarked: Rosenbrock1(16) x 65 536 chains, pl = 1, nburn 500, nsamp 1000.
+    Hot-path kernel (no mask) and generic kernel (with the full accept mask) against the oracle."""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    d, n, nburn, nsamp = 16, 65536, 500, 1000
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=1.0, threads=THREADS)
+    eo.set_record(samples=False, mask=True)
+    t0 = time.time()
+    eo.run(nsamp, nburn, p, vo)
+    print("oracle C3 job: %.1f s" % (time.time() - t0))
+    vg, k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eg = M.Engine(d, n, pl=1.0)
+    eg.run(nsamp, nburn, p, vg)  # hot-path kernel, all 65.5 M sample rows kept in HBM
+    c = eg.counters
+    assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+    assert np.array_equal(eg.accept_counts, eo.accept_counts)
+    assert np.array_equal(eg.tuner_trace, eo.tuner_trace) and len(eo.tuner_trace) == 9
+    for name in ("state", "loglike", "mean", "var", "musigall"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
+    last = eg.samples_range(nsamp - 1, 1)
+    assert same_bits(last[:, :d], eo.state) and same_bits(last[:, d], eo.loglike)
+    eg.close()
+    em = M.Engine(d, n, pl=1.0)
+    em.set_option(E.OPT_ACCEPT_MASK, 1)
+    em.set_option(E.OPT_SAMPLES, 0)
+    em.run(nsamp, nburn, p, vg)
+    assert np.array_equal(em.accept_mask, eo.accept_mask)  # 98.3 M accept decisions
+    for name in ("state", "loglike", "mean", "var"):
+        assert same_bits(getattr(em, name), getattr(eo, name)), name
+
+
+def test_c3_murray_job_bit_exact():
+    """C3 R-murray: Rosenbrock1(16) x 65 536 chains, pl = 0.9, nburn 500, nsamp 100"""
+    import mcpar_amd as M
+    d, n, nburn, nsamp = 16, 65536, 500, 100
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=0.9, threads=THREADS)
+    eo.set_record(samples=False, mask=False)
+    t0 = time.time()
+    eo.run(nsamp, nburn, p, vo)
+    print("oracle C3 R-murray: %.1f s, %d remote steps, %d passes" % (time.time() - t0, eo.remote_steps, eo.remote_passes))
+    vg, k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eg = M.Engine(d, n, pl=0.9)
+    eg.run(nsamp, nburn, p, vg)
+    c = eg.counters
+    assert c["remote_steps"] == eo.remote_steps > 0 and c["remote_passes"] == eo.remote_passes
+    assert c["naccept_main"] == eo.naccept_main and c["naccept_burn"] == eo.naccept_burn
+    assert np.array_equal(eg.accept_counts, eo.accept_counts)
+    for name in ("state", "loglike", "mean", "var", "musigall"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
+
+
+def test_c5_per_gpu_shape_single_shard_bit_exact():
+    """BASELINE config 5's per-GPU shape: 32-D 8-component mixture x 32 768 chains, pl 0.9, 500 + 100"""
+    import mcpar_amd as M
+    d, K, n, nburn, nsamp = 32, 8, 32768, 500, 100
+    params = mix_params(d, K)
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(O.VL_GAUSSMIX, d, params, K)
+    eo = O.Engine(d, n, pl=0.9, threads=THREADS)
+    eo.set_record(samples=False, mask=False)
+    t0 = time.time()
+    eo.run(nsamp, nburn, p, vo)
+    print("oracle C5 shape: %.1f s, %d remote steps, %d passes" % (time.time() - t0, eo.remote_steps, eo.remote_passes))
+    vg, k2 = M.make_vlfunc(M.VL_GAUSSMIX, d, params, K)
+    eg = M.Engine(d, n, pl=0.9)
+    eg.run(nsamp, nburn, p, vg)
+    c = eg.counters
+    assert c["remote_steps"] == eo.remote_steps > 0 and c["remote_passes"] == eo.remote_passes
+    assert c["naccept_main"] == eo.naccept_main and c["naccept_burn"] == eo.naccept_burn
+    assert np.array_equal(eg.accept_counts, eo.accept_counts)
+    for name in ("state", "loglike", "mean", "var", "musigall"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
+
+
+# ---------------------------------------------------------------------------------------------
+# asynchronous exchange hook: what an RCCL all-gather on a side stream does, with device copies
+# ---------------------------------------------------------------------------------------------
+class Hip:
+    def __init__(self):
+        h = C.CDLL("libamdhip64.so")
+        vp = C.c_void_p
+        h.hipStreamCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]
+        h.hipStreamDestroy.argtypes = [vp]
+        h.hipEventCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]
+        h.hipEventRecord.argtypes = [vp, vp]
+        h.hipStreamWaitEvent.argtypes = [vp, vp, C.c_uint]
+        h.hipMemcpyAsync.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+        h.hipStreamSynchronize.argtypes = [vp]
+        self.h = h
+
+    def stream(self):
+        s = C.c_void_p()
+        assert self.h.hipStreamCreateWithFlags(C.byref(s), 1) == 0  # hipStreamNonBlocking
+        return s
+
+    def event(self):
+        e = C.c_void_p()
+        assert self.h.hipEventCreateWithFlags(C.byref(e), 2) == 0  # hipEventDisableTiming
+        return e
+
+
+def run_sharded_async(d, n, nshards, nburn, nsamp, pl, eager, vlspec=None, sync=10):
+    """One engine per shard in its own thread.  BEGIN only ENQUEUES: an event on the engine's stream, a side
+    stream that waits for every shard's event and then pulls the peers' slots with asynchronous device
+    copies.  Nothing waits on the host for the device; WAIT makes the engine's stream wait for every shard's
+    copies (a peer reads this shard's slot, so its completion is part of "the gather is done")."""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    hip = Hip()
+    engs = [M.Engine(d, n, nshards=nshards, shard=s, pl=pl, sync=sync) for s in range(nshards)]
+    vl, keep = M.make_vlfunc(*(vlspec or (M.VL_ROSENBROCK1, d)))
+    side = [hip.stream() for _ in range(nshards)]
+    pub = [hip.event() for _ in range(nshards)]
+    done = [hip.event() for _ in range(nshards)]
+    ptrs = [None] * nshards
+    bar = threading.Barrier(nshards)
+    errs = []
+    nbegin = [0] * nshards
+
+    def make_hook(s):
+        def hook(phase, ptr, slot, shard, ns, stream):
+            if phase == E.XCHG_BEGIN:
+                ptrs[s] = ptr
+                assert hip.h.hipEventRecord(pub[s], stream) == 0
+                bar.wait(timeout=120)  # host-side only: every shard has recorded its event
+                for r in range(ns):
+                    assert hip.h.hipStreamWaitEvent(side[s], pub[r], 0) == 0
+                for r in range(ns):
+                    if r != s:
+                        off = r * slot * 4
+                        assert hip.h.hipMemcpyAsync(ptr + off, ptrs[r] + off, slot * 4, 3, side[s]) == 0
+                assert hip.h.hipEventRecord(done[s], side[s]) == 0
+                nbegin[s] += 1
+                bar.wait(timeout=120)  # every shard's `done` is recorded before anybody's WAIT can run
+            else:
+                for r in range(ns):
+                    assert hip.h.hipStreamWaitEvent(stream, done[r], 0) == 0
+            return 0
+        return hook
+
+    def work(s):
+        try:
+            engs[s].set_option(E.OPT_EAGER_EXCHANGE, eager)
+            engs[s].set_exchange(make_hook(s))
+            engs[s].run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+            bar.abort()
+
+    th = [threading.Thread(target=work, args=(s,)) for s in range(nshards)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for s in side:
+        hip.h.hipStreamSynchronize(s)
+        hip.h.hipStreamDestroy(s)
+    return engs, nbegin
+
+
+@pytest.mark.parametrize("eager", [0, 1], ids=["lazy", "eager"])
+@pytest.mark.parametrize("nshards,n,pl", [(2, 4096, 0.85), (3, 1000, 1.0), (4, 512, 0.7)])
+def test_multishard_async_exchange_equals_oracle(nshards, n, pl, eager):
+    d, nburn, nsamp = 16, 150, 95
+    vo, keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl, threads=THREADS) for s in range(nshards)]
+    for e in eos:
+        e.set_record(samples=True, mask=False)
+    O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+    egs, nbegin = run_sharded_async(d, n, nshards, nburn, nsamp, pl, eager)
+    for s in range(nshards):
+        eo, eg = eos[s], egs[s]
+        c = eg.counters
+        assert c["remote_steps"] == eo.remote_steps and c["remote_passes"] == eo.remote_passes
+        assert c["naccept_main"] == eo.naccept_main
+        assert c["exchanges"] == nbegin[s] and (not eager or nbegin[s] == (nsamp + 9) // 10)
+        for name in ("state", "mean", "var", "samples", "musigall"):
+            assert same_bits(getattr(eg, name), getattr(eo, name)), (s, name)
+
+
+def test_c5_per_gpu_shape_two_shards_bit_exact():
+    """C5's per-GPU chain count split over two shards of this GPU (2 x 16 384), asynchronous exchange"""
+    import mcpar_amd as M
+    d, K, n, nshards, nburn, nsamp, pl = 32, 8, 16384, 2, 500, 100, 0.9
+    params = mix_params(d, K)
+    vo, k1 = O.make_vlfunc(O.VL_GAUSSMIX, d, params, K)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl, threads=THREADS) for s in range(nshards)]
+    for e in eos:
+        e.set_record(samples=False, mask=False)
+    t0 = time.time()
+    O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+    print("oracle C5 2 x 16384: %.1f s, %d passes" % (time.time() - t0, eos[0].remote_passes))
+    egs, nbegin = run_sharded_async(d, n, nshards, nburn, nsamp, pl, 0, vlspec=(M.VL_GAUSSMIX, d, params, K))
+    for s in range(nshards):
+        eo, eg = eos[s], egs[s]
+        c = eg.counters
+        assert c["remote_steps"] == eo.remote_steps > 0 and c["remote_passes"] == eo.remote_passes
+        assert c["naccept_main"] == eo.naccept_main
+        for name in ("state", "mean", "var", "musigall"):
+            assert same_bits(getattr(eg, name), getattr(eo, name)), (s, name)

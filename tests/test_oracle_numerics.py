@@ -77,3 +77,27 @@ def test_cholesky_identity_and_spd():
     assert np.all(np.triu(f, 1) == 0)
     bad = -np.eye(3, dtype=np.float32)
     assert L.mcxo_cholesky(3, O.fptr(bad)) != 0
+
+
+def test_vectorised_murray_sweep_equals_the_scalar_statement():
+    """The oracle's Murray sweep has a plain scalar statement and an eight-at-a-time AVX2 form of the same
+    IEEE operations (oracle/mcx_oracle.c: sweep_scalar / sweep_avx2).  They must agree bit for bit,
+    in the many-pass regime too (d not a multiple of 4, N not a multiple of 8 or of QBLOCK)."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    try:
+        for d, n, nsh in ((16, 700, 1), (6, 301, 2), (32, 260, 1), (2, 9, 1)):
+            N = n * nsh
+            ms = (rng.random((N, d, 2)) + 0.5).astype(np.float32)
+            pv = rng.standard_normal((n, d)).astype(np.float32)
+            out = []
+            for scalar in (1, 0):
+                O.lib().mcxo_set_scalar_sweep(scalar)
+                e = O.Engine(d, n, nshards=nsh, shard=nsh - 1, threads=4)
+                out.append(e.gen_remote(11, pv, ms))
+                e.close()
+            assert out[0][4] == out[1][4] and out[0][4] > 3  # pass counts
+            for a, b in zip(out[0][:4], out[1][:4]):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        O.lib().mcxo_set_scalar_sweep(0)
