@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- chain-steps/sec of the MI355X-native Metropolis-Hastings engine on BASELINE.json's
-metric config: 16-D Rosenbrock (Rosenbrock1(16): SURVEY fact 4), 65 536 chains per GPU, the R-local
-job shape of SURVEY §8d (pl = 1.0, nburn = 500, nsamp = 1000, default tuner constants, seed 8675309,
-pinit[g][i] = 0.5 sin(0.37 (g d + i))), every (chain, step) sample retained in HBM like the
-reference's MCout.
+"""bench.py -- chain-steps/sec of the MI355X-native Metropolis-Hastings engine (libmcx, C ABI) on the
+configurations of BASELINE.json / SURVEY §8d.
 
-A bench "step" is ONE complete MCPar::run-shaped job (burn-in with tuner + main loop with sample
-emission + the inter-shard exchange every SYNCSTEP steps when N > 1) = n * (nburn + nsamp)
-chain-steps per GPU.  Chains shard across GPUs (weak scaling: 65 536 chains per GPU).
+Default workload (`--config c3`, the one BASELINE.json's metric is quoted on): Rosenbrock1(16) x 65 536
+chains per GPU, R-local job (pl = 1.0, nburn = 500, nsamp = 1000, default tuner constants, seed 8675309,
+pinit[g][i] = 0.5 sin(0.37 (g d + i))), every (chain, step) sample row retained in HBM like the reference's
+MCout.  Other configurations: c2 (8-D x 4096, R-local), c5 (32-D 8-component mixture x 32 768 per GPU,
+R-murray: pl = 0.9, nburn = 500, nsamp = 100), c3-murray (C3's shape, R-murray).
 
-  python bench.py [--gpus N --steps K --warmup W]
+A bench "step" is ONE complete MCPar::run-shaped job (burn-in with tuner + main loop with sample emission
++ the inter-shard exchange when N > 1) = n (nburn + nsamp) chain-steps per GPU.  Chains shard across GPUs
+(weak scaling: the configuration's chain count per GPU), the (mu, sig^2) slots are exchanged with the
+library's own in-place ncclAllGather (RCCL over xGMI, mcx_exchange_rccl_*).
+
+  python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c5|c3-murray]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries: `end_to_end` (the same job with every sample
+row copied out to host memory), `roofline` with hardware counters collected live by child `rocprofv3 --pmc`
+passes of this same script (falling back to the committed summaries under profiles/, labelled as such),
+the other configurations as `config.other_configs`, and `cpu_baseline` (the CPU oracle on the host cores).
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,7 +38,17 @@ sys.path.insert(0, ROOT)
 # the host driver on this pool only supports dmabuf IPC (needed by RCCL across processes)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md chip table
+HBM_PEAK = 8.0e12       # B/s, MI355X_MICROARCH.md chip table
+FP32_VALU_PEAK = 157.3e12  # flop/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+
+# SURVEY §8d.  lik: 1 = Rosenbrock1, 5 = K-component unit-variance Gaussian mixture
+CONFIGS = {
+    "c2": dict(name="mcpar-rosen1 (C2)", lik=1, d=8, n=4096, pl=1.0, nburn=500, nsamp=1000),
+    "c3": dict(name="mcpar-rosen2 (C3)", lik=1, d=16, n=65536, pl=1.0, nburn=500, nsamp=1000),
+    "c5": dict(name="mcpar-dgauss mixture (C5 per-GPU shape)", lik=5, d=32, K=8, n=32768, pl=0.9, nburn=500, nsamp=100),
+    "c3-murray": dict(name="mcpar-rosen2 (C3), R-murray", lik=1, d=16, n=65536, pl=0.9, nburn=500, nsamp=100),
+}
 
 
 def alg_bytes_per_chain_step(d, main, emit):
@@ -42,18 +64,39 @@ def pinit_for(d, n, g0):
     return (0.5 * np.sin(0.37 * (g * d + i))).astype(np.float32)
 
 
-class CudaArrayView:
-    """zero-copy torch view of engine-owned device memory (for the RCCL exchange)"""
+def mix_params(d, K):
+    """K unit-variance components, means 5k/(K-1) * 1, weights (5, 1, ..., 1)"""
+    import numpy as np
+    means = np.stack([np.full(d, 5.0 * k / (K - 1)) for k in range(K)]).astype(np.float32)
+    return np.concatenate([means.ravel(), [5] + [1] * (K - 1)]).astype(np.float32)
 
-    def __init__(self, ptr, nfloats):
-        self.__cuda_array_interface__ = dict(shape=(nfloats,), typestr="<f4", data=(int(ptr), False),
-                                             version=2, strides=None)
+
+def lpc_for(d):
+    """lanes per chain: next power of two of ceil(d / 4) (mcx_engine.hip:lpc_for)"""
+    nb, l = (d + 3) // 4, 1
+    while l < nb:
+        l <<= 1
+    return l
 
 
-def cpu_baseline(d, n, nburn, nsamp, pl):
-    """The CPU oracle (a port of the reference algorithm, oracle/mcx_oracle.c) on this box's host
-    cores, on a bounded sample of the same workload.  Reported beside the GPU number; never part
-    of the product path."""
+def make_lik(mod, cfg):
+    if cfg["lik"] == 5:
+        return mod.make_vlfunc(mod.VL_GAUSSMIX, cfg["d"], mix_params(cfg["d"], cfg["K"]), cfg["K"])
+    return mod.make_vlfunc(mod.VL_ROSENBROCK1, cfg["d"])
+
+
+def workload_text(cfg, n):
+    lik = "Rosenbrock1(%d)" % cfg["d"] if cfg["lik"] == 1 else "%d-D %d-component Gaussian mixture" % (cfg["d"], cfg["K"])
+    return ("%s: %s x %d chains/GPU, %s job (pl=%.2f, nburn=%d, nsamp=%d, sync=10), one bench step = one full run()"
+            % (cfg["name"], lik, n, "R-local" if cfg["pl"] >= 1.0 else "R-murray", cfg["pl"], cfg["nburn"], cfg["nsamp"]))
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a port of the reference algorithm) on this box's host cores
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(cfg):
+    """Reported beside the GPU number; never part of the product path.  R-local configurations run the
+    whole job; R-murray ones a bounded sample (the O(n N d) sweeps cost the CPU minutes at full size)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     try:
@@ -61,17 +104,114 @@ def cpu_baseline(d, n, nburn, nsamp, pl):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))  # the GPU box's CPU share for one GPU is 16 cores
-    vl, _keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    d, n, nburn, nsamp, pl = cfg["d"], cfg["n"], cfg["nburn"], cfg["nsamp"], cfg["pl"]
+    sample = "the whole job"
+    if pl < 1.0:
+        n = min(n, 8192)
+        sample = "same job on %d chains (the Murray sweep is O(n N d) per pass)" % n
+    vl, _keep = make_lik(O, cfg)
     p = pinit_for(d, n, 0)
     e = O.Engine(d, n, pl=pl, threads=cores)
     e.set_record(samples=True, mask=False)
     t0 = time.perf_counter()
     e.run(nsamp, nburn, p, vl)
     dt = time.perf_counter() - t0
+    passes = e.remote_passes
     e.close()
     return dict(value=n * (nburn + nsamp) / dt, unit="chain-steps/s", cores=cores, kind="port",
-                sample="%d chains x %d-D Rosenbrock1, %d burn-in + %d main steps, samples kept in host "
-                       "memory, OpenMP over chains (%.1f s)" % (n, d, nburn, nsamp, dt))
+                sample="%s: %d chains x %d-D, %d burn-in + %d main steps, pl=%.2f (%d Murray passes), samples kept in "
+                       "host memory, OpenMP over chains (%.1f s of %d cores)" % (sample, n, d, nburn, nsamp, pl, passes, dt, cores))
+
+
+# ---------------------------------------------------------------------------------------------
+# hardware counters: child rocprofv3 --pmc passes of this script (one counter group per pass)
+# ---------------------------------------------------------------------------------------------
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES"), ("GRBM_GUI_ACTIVE",))
+
+
+def pmc_child(cfg, n):
+    """what runs under rocprofv3: one warm job and one measured job of the configuration, nothing else"""
+    import mcpar_amd as M
+    M.load().mcx_set_device(0)
+    eng = M.Engine(cfg["d"], n, pl=cfg["pl"])
+    vl, _keep = make_lik(M, cfg)
+    eng.stage_pinit(pinit_for(cfg["d"], n, 0))
+    for _ in range(2):
+        eng.run(cfg["nsamp"], cfg["nburn"], None, vl)
+    eng.close()
+
+
+def collect_pmc(config_name, n, keep_dir=None, budget_s=240.0):
+    """-> ({kernel: {counter: mean per dispatch}}, {kernel: mean duration ns under the profiler}, note).
+    Each counter group is its own `rocprofv3 --pmc ... --kernel-trace` run of `bench.py --pmc-child`."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, None, "rocprofv3 not on PATH"
+    out, dur, t_start = {}, {}, time.time()
+    if keep_dir:
+        tmp = os.path.abspath(keep_dir)
+        os.makedirs(tmp, exist_ok=True)
+    else:
+        tmp = tempfile.mkdtemp(prefix="mcx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    for group in PMC_PASSES:
+        if time.time() - t_start > budget_s:
+            return out or None, dur, "time budget exhausted before " + ",".join(group)
+        ddir = os.path.join(tmp, "_".join(group))
+        cmd = [exe, "--pmc", *group, "--kernel-trace", "-f", "csv", "-d", ddir, "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", config_name, "--chains", str(n)]
+        try:
+            r = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150,
+                               env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
+        except Exception as ex:  # noqa: BLE001
+            return out or None, dur, "rocprofv3 %s: %r" % (",".join(group), ex)
+        files = glob.glob(os.path.join(ddir, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return out or None, dur, "rocprofv3 %s failed (rc %d): %s" % (",".join(group), r.returncode, r.stdout[-300:].decode("utf-8", "replace"))
+        acc, kd = {}, {}
+        for row in csv.DictReader(open(files[0])):
+            acc.setdefault((row["Kernel_Name"], row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+            if row["Counter_Name"] == group[0] and row.get("End_Timestamp") and row.get("Start_Timestamp"):
+                kd.setdefault(row["Kernel_Name"], []).append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+        for (k, c), v in acc.items():
+            # the second job's dispatches only (the first job warms allocations and code objects)
+            v = v[len(v) // 2:]
+            out.setdefault(k, {})[c] = sum(v) / len(v)
+        for k, v in kd.items():  # dispatch durations under the profiler, of this pass
+            v = v[len(v) // 2:]
+            dur.setdefault(k, {})["_".join(group)] = sum(v) / len(v)
+    if not keep_dir:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, dur, None
+
+
+def find_kernel(table, *needles):
+    for k in table or {}:
+        if all(s in k for s in needles):
+            return k
+    return None
+
+
+# ---------------------------------------------------------------------------------------------
+# one configuration on this rank's engine
+# ---------------------------------------------------------------------------------------------
+class Job:
+    def __init__(self, M, E, cfg, n, rank, world, emit=True, max_segment=0, rccl_id=None):
+        self.M, self.E, self.cfg, self.n = M, E, cfg, n
+        self.eng = M.Engine(cfg["d"], n, nshards=world, shard=rank, pl=cfg["pl"])
+        self.eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
+        if max_segment > 0:
+            self.eng.set_option(E.OPT_MAX_SEGMENT, max_segment)
+        self.vl, self._keep = make_lik(M, cfg)
+        self.p = pinit_for(cfg["d"], n, rank * n)
+        self.eng.stage_pinit(self.p)  # inputs resident in HBM before any timed region
+        if rccl_id is not None:
+            self.eng.rccl_init(rccl_id)
+
+    def run(self, host_pinit=False):
+        self.eng.run(self.cfg["nsamp"], self.cfg["nburn"], self.p if host_pinit else None, self.vl)
+
+    def close(self):
+        self.eng.close()
 
 
 def main():
@@ -79,18 +219,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU (weak scaling, the default) or in total (--strong)")
-    ap.add_argument("--strong", action="store_true", help="strong scaling: --chains is the total, split evenly over the GPUs")
-    ap.add_argument("--dim", type=int, default=16)
-    ap.add_argument("--nburn", type=int, default=500)
-    ap.add_argument("--nsamp", type=int, default=1000)
-    ap.add_argument("--pl", type=float, default=1.0)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--chains", type=int, default=0, help="override: chains per GPU (weak scaling, the default) or in total (--strong)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --chains (default: the configuration's count) is the total, split evenly")
+    ap.add_argument("--dim", type=int, default=0, help="override the configuration's dimension")
+    ap.add_argument("--nburn", type=int, default=-1)
+    ap.add_argument("--nsamp", type=int, default=-1)
+    ap.add_argument("--pl", type=float, default=-1.0)
     ap.add_argument("--no-samples", action="store_true", help="summary-only mode (not the default metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn rocprofv3 --pmc children; read profiles/ instead")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip end_to_end and the other configurations")
+    ap.add_argument("--keep-pmc", default="", help="directory in which to keep the rocprofv3 output of the PMC passes")
     ap.add_argument("--max-segment", type=int, default=0, help="cap on steps per fused launch (0 = engine default)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--exchange", default="rccl", choices=("rccl", "staged"),
+                    help="N > 1: rccl = the library's in-place ncclAllGather (default); staged = host-staged all-gather "
+                         "over a gloo group (rehearsals on one GPU only)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses device 0 (implies --exchange staged)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    if args.dim > 0:
+        cfg["d"] = args.dim
+    if args.nburn >= 0:
+        cfg["nburn"] = args.nburn
+    if args.nsamp >= 0:
+        cfg["nsamp"] = args.nsamp
+    if args.pl >= 0:
+        cfg["pl"] = args.pl
+
+    if args.pmc_child:
+        pmc_child(cfg, args.chains or cfg["n"])
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,205 +259,339 @@ def main():
     dist = None
     torch = None
     if world > 1:
-        import torch  # noqa: F811  (before libmcx so that both use one HIP runtime)
+        # torch.distributed is the launcher-side plumbing only (rendezvous, barrier, MAX over ranks, shipping the
+        # RCCL unique id) on a gloo group; the data path is libmcx's own ncclAllGather
+        import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
+        dist.init_process_group("gloo")
         if args.one_device:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
+            args.exchange = "staged"
     import numpy as np
     import mcpar_amd as M
     from mcpar_amd import engine as E
 
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    nsh = world
-    M.load().mcx_set_device(local_rank)
-    d, n, nburn, nsamp = args.dim, (args.chains // world if args.strong else args.chains), args.nburn, args.nsamp
+    lib = M.load()
+    lib.mcx_set_device(local_rank)
+    total = args.chains or cfg["n"]
+    n = total // world if args.strong else total
+    cfg["n"] = n
+    d, nburn, nsamp = cfg["d"], cfg["nburn"], cfg["nsamp"]
     emit = not args.no_samples
-    eng = M.Engine(d, n, nshards=nsh, shard=rank, pl=args.pl)
-    eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
-    if args.max_segment > 0:
-        eng.set_option(E.OPT_MAX_SEGMENT, args.max_segment)
-    vl, _keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
-    p = pinit_for(d, n, rank * n)
 
+    # ---- inter-shard exchange -------------------------------------------------------------------
     state = {"backend": None}
-    if world > 1:
-        # engine kernels and the RCCL all-gather are ordered through torch's current stream
-        stream = torch.cuda.current_stream()
-        eng.set_option(E.OPT_STREAM, stream.cuda_stream)
-        lib = M.load()
-        # Safety net: a host-staged all-gather over a gloo group, used only if the zero-copy RCCL path
-        # (in-place all_gather_into_tensor on a __cuda_array_interface__ view) does not work on this
-        # stack.  The decision is taken once, collectively, on a probe buffer.
-        gloo = dist.new_group(backend="gloo") if args.backend == "nccl" else None
-        ok = 0 if os.environ.get("MCX_BENCH_FORCE_STAGED") else 1  # (rehearsal switch for the fallback)
-        try:
-            if not ok:
-                raise RuntimeError("forced")
-            probe = torch.zeros(world * 256, dtype=torch.float32, device="cuda")
-            view = torch.as_tensor(CudaArrayView(probe.data_ptr(), probe.numel()), device="cuda")
-            own = view[rank * 256:(rank + 1) * 256]
-            own.fill_(float(rank + 1))
-            dist.all_gather_into_tensor(view, own)
-            torch.cuda.synchronize()
-            got = probe.view(world, 256)[:, 0].cpu()
-            ok = int(bool((got == torch.arange(1, world + 1, dtype=torch.float32)).all()))
-        except Exception as ex:  # noqa: BLE001
-            print("rank %d: zero-copy RCCL all-gather probe failed: %r" % (rank, ex), file=sys.stderr)
-            ok = 0
+
+    def bcast_bytes(b):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).clone()
+        dist.broadcast(t, src=0)
+        return bytes(t.numpy().tobytes())
+
+    def new_rccl_id():
+        """collective: rank 0 draws the ncclUniqueId, everybody gets it; None if RCCL is not usable everywhere"""
+        ok = 1 if M.engine.rccl_available() else 0
         flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=gloo)
-        zero_copy = int(flag.item()) == 1
-        state["backend"] = ("rccl" if args.backend == "nccl" else args.backend) if zero_copy else "gloo, host-staged (fallback)"
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            return None
+        uid = M.engine.rccl_unique_id() if rank == 0 else bytes(128)
+        return bcast_bytes(uid)
+
+    def staged_exchange(eng):
+        host = {}
 
         def exchange(phase, ptr, slot, shard, nshards, st):
-            if zero_copy:
-                if phase == E.XCHG_BEGIN:
-                    if "all" not in state:
-                        state["all"] = torch.as_tensor(CudaArrayView(ptr, slot * nshards), device="cuda")
-                        state["own"] = state["all"][shard * slot:(shard + 1) * slot]
-                    state["work"] = dist.all_gather_into_tensor(state["all"], state["own"], async_op=True)
-                else:
-                    w = state.pop("work", None)
-                    if w is not None:
-                        w.wait()
-                return 0
             if phase != E.XCHG_BEGIN:
                 return 0
-            host = state.setdefault("host", np.empty(slot * nshards, np.float32))
+            h = host.setdefault("buf", np.empty(slot * nshards, np.float32))
             vp = C.c_void_p
-            rc = lib.mcx_copy_to_host(vp(host.ctypes.data + shard * slot * 4), vp(ptr + shard * slot * 4), slot * 4, vp(st))
+            rc = lib.mcx_copy_to_host(vp(h.ctypes.data + shard * slot * 4), vp(ptr + shard * slot * 4), slot * 4, vp(st))
             if rc:
                 return rc
-            t = torch.from_numpy(host)
-            dist.all_gather_into_tensor(t, t[shard * slot:(shard + 1) * slot].clone(), group=gloo)
+            t = torch.from_numpy(h)
+            dist.all_gather_into_tensor(t, t[shard * slot:(shard + 1) * slot].clone())
             for r in range(nshards):
                 if r != shard:
-                    rc = lib.mcx_copy_to_device(vp(ptr + r * slot * 4), vp(host.ctypes.data + r * slot * 4), slot * 4, vp(st))
+                    rc = lib.mcx_copy_to_device(vp(ptr + r * slot * 4), vp(h.ctypes.data + r * slot * 4), slot * 4, vp(st))
                     if rc:
                         return rc
             return 0
         eng.set_exchange(exchange)
 
+    def make_job(c, nn, emit_=True):
+        if world == 1:
+            return Job(M, E, c, nn, 0, 1, emit_, args.max_segment)
+        uid = new_rccl_id() if args.exchange == "rccl" else None
+        j = Job(M, E, c, nn, rank, world, emit_, args.max_segment, rccl_id=uid)
+        if uid is None:
+            staged_exchange(j.eng)
+            state["backend"] = "gloo, host-staged (%s)" % ("requested" if args.exchange == "staged" else "fallback: " + lib.mcx_last_error().decode())
+        else:
+            j.eng.debug_exchange()  # one gather now: a broken fabric fails here, not inside the timed region
+            state["backend"] = "rccl (libmcx in-place ncclAllGather on a side stream)"
+        return j
+
     def sync():
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+            dist.barrier()  # run() is synchronous: it returns after this rank's stream has drained
 
-    # inputs resident in HBM before the timed region: the initial chain state is staged once; the
-    # host-pointer form run(pinit) is timed separately below (PCIe-inclusive, reported, never `value`)
-    eng.stage_pinit(p)
+    def timed(job, k, host_pinit=False):
+        """k jobs bracketed by barriers, MAX over ranks"""
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            job.run(host_pinit)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    job = make_job(cfg, n, emit)
+    eng = job.eng
     for _ in range(args.warmup):
-        eng.run(nsamp, nburn, None, vl)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.run(nsamp, nburn, None, vl)  # synchronous: returns after the stream has drained
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        job.run()
+    dt = timed(job, args.steps)
     cnt = eng.counters
     chain_steps = float(world) * n * (nburn + nsamp) * args.steps
     value = chain_steps / dt
-    sync()
-    th = time.perf_counter()
-    for _ in range(args.steps):
-        eng.run(nsamp, nburn, p, vl)  # pinit handed over as a host buffer each time
-    sync()
-    value_host_pinit = chain_steps / (time.perf_counter() - th)
+    value_host_pinit = chain_steps / timed(job, args.steps, host_pinit=True)  # PCIe-inclusive input, never `value`
 
-    # N > 1: the same job with the reference's own exchange schedule (an all-gather at every sync
-    # point, overlapped with compute) next to the default, which gathers only the snapshots a Murray
-    # step or the end of the run will read (bit-identical results; tests/test_gpu_multishard.py)
-    eager = None
+    # N > 1: the same job with the reference's own exchange schedule (an all-gather at every sync point,
+    # src/mcpar.cc:127-140, overlapped with the next segment) next to the default, which gathers only the
+    # snapshots a Murray step or the end of the run reads (bit-identical results: tests/test_gpu_multishard.py)
+    ref_sched = None
     if world > 1:
         eng.set_option(E.OPT_EAGER_EXCHANGE, 1)
-        eng.run(nsamp, nburn, None, vl)
-        sync()
-        t1 = time.perf_counter()
+        job.run()
         ke = max(1, args.steps // 2)
-        for _ in range(ke):
-            eng.run(nsamp, nburn, None, vl)
-        sync()
-        de = time.perf_counter() - t1
-        te = torch.tensor([de], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        eager = dict(value=float(world) * n * (nburn + nsamp) * ke / float(te.item()), unit="chain-steps/s",
-                     steps=ke, exchanges_per_run=eng.counters["exchanges"])
+        de = timed(job, ke)
+        ref_sched = dict(value=float(world) * n * (nburn + nsamp) * ke / de, unit="chain-steps/s", steps=ke,
+                         ms_per_step=de / ke * 1e3, exchanges_per_run=eng.counters["exchanges"],
+                         what="MCX_OPT_EAGER_EXCHANGE=1: one all-gather per SYNCSTEP main-loop steps like the reference")
         eng.set_option(E.OPT_EAGER_EXCHANGE, 0)
 
-    # ---- roofline of the dominant kernel (fused main-loop steps), HIP events on the engine stream
-    roofline = None
-    cpu = None
-    # every rank runs the profiled job (it contains the same collectives); rank 0 reports
-    eng.set_option(E.OPT_PROFILE, 1)
-    base = eng.profile
-    eng.run(nsamp, nburn, None, vl)
-    pr = eng.profile
-    eng.set_option(E.OPT_PROFILE, 0)
+    # ---- live timing of the dominant kernels: HIP events on the engine's stream (MCX_OPT_PROFILE) --------
+    def profiled(j):
+        j.eng.set_option(E.OPT_PROFILE, 1)
+        base = j.eng.profile
+        j.run()
+        pr = j.eng.profile
+        j.eng.set_option(E.OPT_PROFILE, 0)
+        return {k: {f: pr[k][f] - base[k][f] for f in ("ms", "launches", "chain_steps")} for k in pr}, j.eng.counters
+
+    prof, pcnt = profiled(job)  # every rank runs it (it contains the same collectives)
     sync()
+
+    def murray_block(c, nn, pr, cn):
+        """k_remote_sweep in flops (n_act N (3d+4) per pass + one exp per pair)"""
+        sw = pr["remote_sweep"]
+        if sw["launches"] <= 0 or sw["ms"] <= 0:
+            return None
+        dd = c["d"]
+        dm = 2
+        while dm < dd:
+            dm <<= 1
+        flops = sw["chain_steps"] * (3 * dd + 4)
+        ach = flops / (sw["ms"] * 1e-3)
+        return dict(bound="valu", kernel="k_remote_sweep<DMAX=%d>" % dm, achieved=ach / 1e12, peak=FP32_VALU_PEAK / 1e12,
+                    unit="TFLOP/s", frac=ach / FP32_VALU_PEAK, pairs=sw["chain_steps"], exp_per_pair=1,
+                    flop_per_pair=3 * dd + 4, launches=sw["launches"], total_ms=sw["ms"],
+                    remote_steps=cn["remote_steps"], passes=cn["remote_passes"], whole_genremote_ms=pr["remote"]["ms"],
+                    formula="achieved = pairs * (3d+4) / sum of k_remote_sweep durations (HIP events, this run); "
+                            "peak = fp32 vector peak 157.3 TFLOP/s (MI355X_MICROARCH.md); the polynomial exp per pair is "
+                            "not counted as flops")
+
+    roofline = murray = cpu = end_to_end = None
+    others = {}
     if rank == 0:
-        fm = {k: pr["fused_main"][k] - base["fused_main"][k] for k in ("ms", "launches", "chain_steps")}
-        fb = {k: pr["fused_burn"][k] - base["fused_burn"][k] for k in ("ms", "launches", "chain_steps")}
+        fm, fb = prof["fused_main"], prof["fused_burn"]
+        split = prof["gen_normals"]["launches"] > 0
+        lpc = lpc_for(d)
+        likname = {1: "LIK_ROSEN1", 5: "LIK_MIX"}[cfg["lik"]]
+        kname = "k_fused_fast<%d, true, %d, %s>" % (lpc, cfg["lik"], "true" if split else "false")
         if fm["launches"] > 0 and fm["ms"] > 0:
             bpc = alg_bytes_per_chain_step(d, True, emit)
-            achieved = fm["chain_steps"] * bpc / (fm["ms"] * 1e-3)
-            # PMC numbers cannot be collected inside this process: they come from the committed rocprofv3
-            # --pmc passes of this same command (profiles/, tools/collect_profiles.py)
-            traffic = valu_busy = None
-            try:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
-                    "k_fused_steps_main_bytes_per_launch")
-                valu_busy = json.load(open(os.path.join(ROOT, "profiles", "r01_fused_kernel_sq_counters.json"))).get(
-                    "valu_busy_fraction")
-            except Exception:
-                pass
-            roofline = dict(bound="hbm", kernel="k_fused_fast<LPC=%d,MAIN>" % max(1, (d + 3) // 4),
-                            achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                            frac=achieved / HBM_PEAK, traffic=traffic, valu_busy=valu_busy,
-                            alg_bytes_per_chain_step=bpc,
-                            avg_launch_ms=fm["ms"] / fm["launches"], launches=fm["launches"],
-                            chain_steps_per_launch=fm["chain_steps"] / fm["launches"],
-                            burn_kernel=dict(alg_bytes_per_chain_step=alg_bytes_per_chain_step(d, False, False),
-                                             avg_launch_ms=fb["ms"] / max(fb["launches"], 1),
-                                             achieved=(fb["chain_steps"] * alg_bytes_per_chain_step(d, False, False)
-                                                       / max(fb["ms"] * 1e-3, 1e-12)) / 1e9))
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(d, n, 500, 500, args.pl)
+            t_launch = fm["ms"] * 1e-3 / fm["launches"]
+            alg = fm["chain_steps"] * bpc / (fm["ms"] * 1e-3)
+            roofline = dict(
+                bound="valu", kernel=kname + " (%s%s)" % (likname, ", small-n mode: includes k_gen_normals" if split else ""),
+                avg_launch_ms=t_launch * 1e3, launches=fm["launches"], chain_steps_per_launch=fm["chain_steps"] / fm["launches"],
+                timing="HIP events on the engine's stream around each launch, this run (MCX_OPT_PROFILE)",
+                hbm_alg=dict(achieved=alg / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=alg / HBM_PEAK,
+                             bytes_per_chain_step=bpc,
+                             formula="SURVEY §8d bytes (state round trip 24d+8 + sample row 4(d+1)) x chain-steps per launch / "
+                                     "avg launch duration / 8 TB/s",
+                             note="NOT a fraction of a physical bound: the fused kernel keeps x, ly, mu, S in registers across "
+                                  "the launch's steps, so only the sample rows (and the state once per launch) reach HBM; "
+                                  "a value above 1 is the saved traffic, hbm_measured is what the memory system sees"),
+                burn_kernel=dict(bytes_per_chain_step=alg_bytes_per_chain_step(d, False, False),
+                                 avg_launch_ms=fb["ms"] / max(fb["launches"], 1), launches=fb["launches"],
+                                 hbm_alg_GBps=(fb["chain_steps"] * alg_bytes_per_chain_step(d, False, False)
+                                               / max(fb["ms"] * 1e-3, 1e-12)) / 1e9))
+        if cfg["pl"] < 1.0:
+            murray = murray_block(cfg, n, prof, pcnt)
+
+    # ---- N > 1: a Murray (pl < 1) configuration over the same ranks, first-class next to the R-local number ----
+    murray_multi = None
+    if world > 1 and cfg["pl"] >= 1.0 and not args.no_extras:
+        job.close()
+        c5 = dict(CONFIGS["c5"])
+        j5 = make_job(c5, c5["n"], True)
+        j5.run()
+        k5 = max(1, min(3, args.steps))
+        d5 = timed(j5, k5)
+        p5, c5cnt = profiled(j5)
+        sync()
+        murray_multi = dict(workload=workload_text(c5, c5["n"]), value=float(world) * c5["n"] * (c5["nburn"] + c5["nsamp"]) * k5 / d5,
+                            unit="chain-steps/s", steps=k5, ms_per_step=d5 / k5 * 1e3, remote_steps=c5cnt["remote_steps"],
+                            passes=c5cnt["remote_passes"], exchanges_per_run=c5cnt["exchanges"],
+                            sweep=murray_block(c5, c5["n"], p5, c5cnt) if rank == 0 else None)
+        j5.close()
+        job = None
+
+    # ---- N = 1 extras: end to end, other configurations, counters, CPU baseline ---------------------------
+    if world == 1 and rank == 0:
+        if emit and not args.no_extras:
+            # the reference's product is the samples on the host (src/mcout.cc:30-94): same job + every row out
+            ns = nsamp
+            rows = np.empty((ns * n, d + 1), np.float32)
+            job.run(); eng.samples_into(rows)  # warm (page-faults the destination once)
+            ke = max(1, min(3, args.steps))
+            t0 = time.perf_counter()
+            for _ in range(ke):
+                job.run()
+                eng.samples_into(rows)
+            de = (time.perf_counter() - t0) / ke
+            end_to_end = dict(value=n * (nburn + nsamp) / de, unit="chain-steps/s", ms_per_step=de * 1e3, steps=ke,
+                              host_bytes_per_job=int(rows.nbytes), copy_GBps=rows.nbytes / max(de - dt / args.steps, 1e-9) / 1e9,
+                              what="the same job followed by mcx_samples_copy of all nsamp*n rows, MCout layout (np+1 columns), "
+                                   "into host memory; `value` keeps the rows in HBM")
+            del rows
+        job.close()
+        job = None
+        if not args.no_extras:
+            for name in sorted(CONFIGS):
+                if name == args.config:
+                    continue
+                c = dict(CONFIGS[name])
+                j = Job(M, E, c, c["n"], 0, 1, True, args.max_segment)
+                j.run()
+                k = 3
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    j.run()
+                dd = (time.perf_counter() - t0) / k
+                pr, cn = profiled(j)
+                o = dict(workload=workload_text(c, c["n"]), value=c["n"] * (c["nburn"] + c["nsamp"]) / dd, unit="chain-steps/s",
+                         ms_per_step=dd * 1e3, steps=k, accept_rate_main=cn["naccept_main"] / float(c["n"] * c["nsamp"]),
+                         kernel_launches_per_run=cn["kernel_launches"])
+                if c["pl"] < 1.0:
+                    o["remote_steps"], o["passes"] = cn["remote_steps"], cn["remote_passes"]
+                    o["sweep"] = murray_block(c, c["n"], pr, cn)
+                others[name] = o
+                j.close()
+        # hardware counters of the dominant kernel, live
+        if roofline is not None:
+            pmc = pdur = None
+            note = "--no-pmc"
+            if not args.no_pmc:
+                pmc, pdur, note = collect_pmc(args.config, n, keep_dir=args.keep_pmc or None)
+            kk = find_kernel(pmc, "k_fused_fast<%d, true" % lpc_for(d))
+            t_launch = roofline["avg_launch_ms"] * 1e-3
+            if kk and all(c in pmc[kk] for c in ("FETCH_SIZE", "WRITE_SIZE")):
+                traffic = (2.0 * pmc[kk]["FETCH_SIZE"] + pmc[kk]["WRITE_SIZE"]) * 1024.0
+                src = ("live: child `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of `bench.py --pmc-child` "
+                       "(same configuration), mean over the measured job's launches of this kernel")
+                roofline["hbm_measured"] = dict(
+                    traffic=traffic, achieved=traffic / t_launch / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                    frac=traffic / t_launch / HBM_PEAK, source=src,
+                    formula="bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (FETCH_SIZE doubled: gfx950 correction for 16-B/lane "
+                            "streaming reads, MI355X_MICROARCH.md HBM section); frac = bytes / avg launch duration (HIP events) / 8 TB/s",
+                    unavoidable_bytes=fm_unavoidable(d, n, roofline["chain_steps_per_launch"], emit))
+                roofline["traffic"] = traffic
+            if kk and all(c in pmc[kk] for c in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
+                busy, insts, gui = pmc[kk]["SQ_ACTIVE_INST_VALU"], pmc[kk]["SQ_INSTS_VALU"], pmc[kk]["GRBM_GUI_ACTIVE"]
+                cyc = gui / 8.0
+                dur_ns = (pdur.get(kk) or {}).get("GRBM_GUI_ACTIVE")
+                waves = (n * lpc_for(d) + 63) // 64
+                steps_per_launch = roofline["chain_steps_per_launch"] / n
+                roofline.update(
+                    achieved=4.0 * busy / cyc, peak=float(N_SIMD), unit="VALU-busy SIMDs (of 1024)", frac=4.0 * busy / (N_SIMD * cyc),
+                    valu=dict(SQ_ACTIVE_INST_VALU=busy, SQ_INSTS_VALU=insts, GRBM_GUI_ACTIVE=gui,
+                              valu_instructions_per_wave_step=insts / (waves * steps_per_launch),
+                              busy_cycles_per_valu_instruction=4.0 * busy / insts,
+                              kernel_clock_GHz=(cyc / dur_ns) if dur_ns else None,
+                              source="live: child `rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES` and "
+                                     "`--pmc GRBM_GUI_ACTIVE` passes of `bench.py --pmc-child`",
+                              formula="frac = 4*SQ_ACTIVE_INST_VALU (quad-cycles -> cycles, summed over SIMDs) / (1024 SIMDs * "
+                                      "GRBM_GUI_ACTIVE/8 kernel cycles): the share of SIMD cycles in which a vector instruction "
+                                      "occupies the VALU -- the bound of this kernel once state stays in registers"))
+            if "frac" not in roofline or "traffic" not in roofline:
+                fallback_from_profiles(roofline, note, args.config)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg)
 
     if rank == 0:
         out = {
-            "metric": "chain-steps/sec (all chains), 16-D Rosenbrock",
+            "metric": "chain-steps/sec (all chains), 16-D Rosenbrock" if (cfg["lik"] == 1 and d == 16) else
+                      "chain-steps/sec (all chains)",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "mcpar-rosen2 (C3): Rosenbrock1(%d) x %d chains/GPU, R-local job "
-                                   "(pl=%.2f, nburn=%d, nsamp=%d, sync=10), one bench step = one full run()"
-                                   % (d, n, args.pl, nburn, nsamp),
-                       "chains_per_gpu": n, "nparam": d, "nburn": nburn, "nsamp": nsamp,
+            "config": {"workload": workload_text(cfg, n), "name": args.config,
+                       "chains_per_gpu": n, "nparam": d, "nburn": nburn, "nsamp": nsamp, "pl": cfg["pl"],
                        "samples": "all kept in HBM" if emit else "none (summary only)",
-                       "parallelism": "chains sharded x%d, RCCL all-gather of the (mu, sig^2) snapshots that a Murray "
-                                      "step or the end of the run reads" % world if world > 1 else "single GPU",
+                       "parallelism": ("chains sharded x%d (contiguous blocks, g = shard*n + j), in-place all-gather of the "
+                                       "(mu, sig^2) slots: default schedule gathers the snapshots a Murray step or the end of "
+                                       "the run reads" % world) if world > 1 else "single GPU",
                        "exchange_backend": state["backend"],
-                       "eager_exchange": eager,
-                       "accept_rate_main": cnt["naccept_main"] / float(n * nsamp),
+                       "reference_schedule": ref_sched,
+                       "murray": murray_multi,
+                       "accept_rate_main": cnt["naccept_main"] / float(n * nsamp) if nsamp else None,
+                       "remote_steps": cnt["remote_steps"], "remote_passes": cnt["remote_passes"],
                        "value_with_host_pinit": value_host_pinit,
-                       "exchanges_per_run": cnt["exchanges"], "kernel_launches_per_run": cnt["kernel_launches"]},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "exchanges_per_run": cnt["exchanges"], "kernel_launches_per_run": cnt["kernel_launches"],
+                       "other_configs": others or None},
+            "end_to_end": end_to_end, "roofline": roofline, "murray_roofline": murray, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    if job is not None:
+        job.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+
+
+def fm_unavoidable(d, n, chain_steps_per_launch, emit):
+    """bytes one launch cannot avoid: the sample rows it emits + state and moments once in and once out"""
+    rows = chain_steps_per_launch * 4 * (d + 1) if emit else 0
+    return rows + n * (2 * 4 * (3 * d + 1))
+
+
+def fallback_from_profiles(roofline, why, config_name="c3"):
+    """counters not collected in this run: use the committed summaries of the same command, and say so"""
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r02_%s_fused_kernel_counters.json" % config_name)))
+    except Exception:  # noqa: BLE001
+        roofline.setdefault("traffic", None)
+        roofline.setdefault("frac", None)
+        roofline["counters_note"] = "no live PMC (%s) and no committed summary" % why
+        return
+    t_launch = roofline["avg_launch_ms"] * 1e-3
+    src = "profiles/r02_%s_fused_kernel_counters.json (committed rocprofv3 --pmc passes of this command; live collection: %s)" % (config_name, why)
+    if "traffic" not in roofline and sq.get("traffic_bytes_per_launch"):
+        tr = sq["traffic_bytes_per_launch"]
+        roofline["traffic"] = tr
+        roofline["hbm_measured"] = dict(traffic=tr, achieved=tr / t_launch / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                                        frac=tr / t_launch / HBM_PEAK, source=src)
+    if "frac" not in roofline and sq.get("valu_busy_fraction"):
+        roofline.update(achieved=sq["valu_busy_fraction"] * N_SIMD, peak=float(N_SIMD), unit="VALU-busy SIMDs (of 1024)",
+                        frac=sq["valu_busy_fraction"], valu=dict(source=src))
 
 
 if __name__ == "__main__":

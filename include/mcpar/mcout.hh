@@ -11,6 +11,8 @@
 
 #include "mpi_compat.hh"
 
+MCPAR_ABI_NAMESPACE_BEGIN
+
 class MCout {
 public:
   MCout(int np, std::ostream *aoutstream, MPI_Comm acomm);
@@ -52,5 +54,7 @@ private:
   int rank_, nranks_;
   void note_row(const float *row);
 };
+
+MCPAR_ABI_NAMESPACE_END
 
 #endif

@@ -17,6 +17,8 @@
 #include "mpi_compat.hh"
 #include "vlfunc.hh"
 
+MCPAR_ABI_NAMESPACE_BEGIN
+
 class MCPar {
 public:
   enum { OK, INVALID, ERROR };
@@ -49,6 +51,10 @@ public:
   uint64_t naccept_main() const { return counters.naccept_main; }
   uint64_t remote_passes() const { return counters.remote_passes; }
   void set_seed_and_recreate(uint32_t seed);
+  // how the shards exchange their (mu, sig^2) slots (src/mcpar.cc:127-140): "none" (one shard), "rccl"
+  // (in-place ncclAllGather on device memory over xGMI; MPI only ships the communicator id) or "mpi-staged"
+  // (MPI_Allgather through host memory: ranks sharing a GPU, no RCCL, or MCPAR_EXCHANGE=mpi)
+  const char *exchange_backend() const;
 
 private:
   int nparam, nchain, ntot, ncov;
@@ -57,10 +63,13 @@ private:
   uint32_t rng_t;  // RNG step index used by the public genLocal/genRemote
   mcx_engine *eng;
   mcx_counters counters;
-#ifdef MCX_WITH_MPI
-  MPI_Comm mcparComm;
-#endif
+  struct Comm;  // the duplicated communicator (src/mcpar.cc:228) and the exchange it drives; null without MPI
+  Comm *comm;
   void create(uint32_t seed);
+  MCPar(const MCPar &);
+  MCPar &operator=(const MCPar &);
 };
+
+MCPAR_ABI_NAMESPACE_END
 
 #endif

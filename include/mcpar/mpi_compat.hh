@@ -19,4 +19,15 @@ inline int MPI_Comm_rank(MPI_Comm, int *rank) { *rank = 0; return MPI_SUCCESS; }
 #endif
 #endif
 
+// MCPar and MCout live in an inline namespace named after the build mode: user code is source-compatible
+// with the reference (the names resolve unqualified), but objects built with -DMCX_WITH_MPI cannot be
+// linked against the single-rank libmcpar.so or the reverse -- the symbols differ, so a mismatch is a link
+// error instead of a silent difference in class layout.
+#ifdef MCX_WITH_MPI
+#define MCPAR_ABI_NAMESPACE_BEGIN inline namespace mcpar_mpi {
+#else
+#define MCPAR_ABI_NAMESPACE_BEGIN inline namespace mcpar_single {
+#endif
+#define MCPAR_ABI_NAMESPACE_END }
+
 #endif

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 1
+#define MCX_ABI_VERSION 2
 
 typedef enum mcx_status {
   MCX_OK = 0,
@@ -165,6 +165,8 @@ typedef struct mcx_counters {
   uint64_t remote_steps, remote_passes; /* genRemote calls / rejection passes */
   uint64_t exchanges;
   uint64_t kernel_launches;
+  uint64_t remote_pairs; /* (chain, Q_i) pairs evaluated by the Murray sweeps: sum over passes of n_active * N,
+                            plus n * N per genRemote call for the cfac numerator (src/mcpar.cc:367-395, 421-437) */
 } mcx_counters;
 int mcx_get_counters(mcx_engine *e, mcx_counters *c);
 
@@ -212,7 +214,11 @@ int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed, uint32_t t
 
 /* ---- profiling (MCX_OPT_PROFILE) ---------------------------------------------------------- */
 enum { MCX_K_FUSED_BURN = 0, MCX_K_FUSED_MAIN, MCX_K_PROPOSE, MCX_K_EVAL, MCX_K_ACCEPT,
-       MCX_K_REMOTE, MCX_K_TUNER, MCX_K_MISC, MCX_K_COUNT };
+       MCX_K_REMOTE,       /* a whole genRemote call: draws, sweeps, decisions and the host's survivor counts */
+       MCX_K_TUNER, MCX_K_MISC,
+       MCX_K_REMOTE_SWEEP, /* the all-pairs sweep kernels alone (inside MCX_K_REMOTE); chain_steps = pairs */
+       MCX_K_GEN_NORMALS,  /* small-n mode: the random-number generator kernel (inside MCX_K_FUSED_*) */
+       MCX_K_COUNT = 12 };
 typedef struct mcx_profile {
   double ms[MCX_K_COUNT];
   uint64_t launches[MCX_K_COUNT];
@@ -231,6 +237,9 @@ int mcx_abi_version(void);
 int mcx_device_info(char *name, size_t namelen, int *cu_count, size_t *hbm_bytes);
 int mcx_set_device(int device);
 int mcx_device_count(int *n);
+/* PCI bus id of the calling thread's current device ("0000:05:00.0"): lets a multi-process launcher see
+ * whether two ranks share a GPU (RCCL refuses such a communicator) */
+int mcx_device_pci_bus_id(char *buf, size_t len);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:
  * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
  * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf,

@@ -23,10 +23,12 @@ class VLFunc(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("naccept_burn", "naccept_main", "nsteps_burn", "nsteps_main",
-                                          "remote_steps", "remote_passes", "exchanges", "kernel_launches")]
+                                          "remote_steps", "remote_passes", "exchanges", "kernel_launches",
+                                          "remote_pairs")]
 
 
-K_NAMES = ("fused_burn", "fused_main", "propose", "eval", "accept", "remote", "tuner", "misc")
+K_NAMES = ("fused_burn", "fused_main", "propose", "eval", "accept", "remote", "tuner", "misc", "remote_sweep",
+           "gen_normals", "reserved10", "reserved11")
 
 
 class PlanItem(C.Structure):
@@ -34,7 +36,7 @@ class PlanItem(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("chain_steps", C.c_uint64 * 8)]
+    _fields_ = [("ms", C.c_double * 12), ("launches", C.c_uint64 * 12), ("chain_steps", C.c_uint64 * 12)]
 
 
 def lib_path():
@@ -86,6 +88,7 @@ def load():
         "mcx_device_info": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
         "mcx_set_device": [C.c_int],
         "mcx_device_count": [C.POINTER(C.c_int)],
+        "mcx_device_pci_bus_id": [C.c_char_p, C.c_size_t],
         "mcx_rccl_available": [],
         "mcx_rccl_unique_id": [vp],
         "mcx_exchange_rccl_init": [vp, vp],

@@ -8,6 +8,8 @@
 #include "../../include/mcpar/mcpar.hh"
 #include "../../include/mcpar/mcutil.hh"
 
+#include <unistd.h>
+
 #include <cassert>
 #include <cstdio>
 #include <cstring>
@@ -135,11 +137,65 @@ const std::vector<float> &MCout::maxlike(float *lmax)
 // ---------------------------------------------------------------------------------------------
 // MCPar (src/mcpar.cc)
 // ---------------------------------------------------------------------------------------------
+// The duplicated communicator of src/mcpar.cc:228 and the exchange that replaces its MPI_Allgather.
+struct MCPar::Comm {
+#ifdef MCX_WITH_MPI
+  MPI_Comm comm;
+  std::vector<float> host;  // staging of the MPI fallback
+#endif
+  bool rccl;
+  const char *backend;
+};
+
+#ifdef MCX_WITH_MPI
+namespace {
+
+// One MPI rank drives one GPU: ranks of a node take its devices round-robin by node-local rank
+// (MCPAR_DEVICE=<index> overrides).  Must run before mcx_create, which binds the engine to the current device.
+void bind_rank_to_device(MPI_Comm comm, int rank)
+{
+  int ndev = 0;
+  if (mcx_device_count(&ndev) != MCX_OK || ndev < 1) return;  // mcx_create reports the missing device
+  int dev = -1;
+  if (const char *ov = getenv("MCPAR_DEVICE")) dev = atoi(ov);
+  if (dev < 0) {
+    MPI_Comm node;
+    int local = 0;
+    if (MPI_Comm_split_type(comm, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node) == MPI_SUCCESS) {
+      MPI_Comm_rank(node, &local);
+      MPI_Comm_free(&node);
+    }
+    dev = local % ndev;
+  }
+  if (mcx_set_device(dev % ndev) != MCX_OK) die("MCPar::MCPar (device binding)");
+}
+
+// true when no two ranks of the communicator sit on the same GPU (RCCL refuses such a communicator)
+bool one_gpu_per_rank(MPI_Comm comm, int size)
+{
+  char mine[96];
+  std::memset(mine, 0, sizeof mine);
+  if (gethostname(mine, 48) != 0) mine[0] = '?';
+  mine[47] = 0;
+  const size_t hl = std::strlen(mine);
+  mine[hl] = '/';
+  if (mcx_device_pci_bus_id(mine + hl + 1, sizeof mine - hl - 1) != MCX_OK) return false;
+  std::vector<char> all((size_t)size * sizeof mine);
+  if (MPI_Allgather(mine, (int)sizeof mine, MPI_CHAR, all.data(), (int)sizeof mine, MPI_CHAR, comm) != MPI_SUCCESS) return false;
+  for (int a = 0; a < size; ++a)
+    for (int b = a + 1; b < size; ++b)
+      if (std::memcmp(&all[(size_t)a * sizeof mine], &all[(size_t)b * sizeof mine], sizeof mine) == 0) return false;
+  return true;
+}
+
+}  // namespace
+#endif
+
 MCPar::MCPar(int np, int nc, int mpisiz, int mpirank, float pl, float armin, float armax, float dfac,
              float ifac, int sync)
     : TGT_ARATE_MIN(armin), TGT_ARATE_MAX(armax), SCALE_DEC(dfac), SCALE_INC(ifac), PLOCAL(pl),
       SYNCSTEP(sync), logging(false), logstep(1000), nparam(np), nchain(nc), rank(mpirank),
-      size(mpisiz), rng_t(0), eng(0)
+      size(mpisiz), rng_t(0), eng(0), comm(0)
 {
   ntot = np * nc;
   ncov = np * np;
@@ -147,15 +203,23 @@ MCPar::MCPar(int np, int nc, int mpisiz, int mpirank, float pl, float armin, flo
   mpi = mpisiz > 1;
   std::memset(&counters, 0, sizeof counters);
 #ifdef MCX_WITH_MPI
-  if (mpi && MPI_Comm_dup(MPI_COMM_WORLD, &mcparComm) != MPI_SUCCESS) {
-    std::cerr << "rank = " << rank << ":  Unable to create mcpar communicator (fatal)\n";
-    MPI_Abort(MPI_COMM_WORLD, 3);
+  if (mpi) {
+    comm = new Comm();
+    comm->rccl = false;
+    comm->backend = "mpi-staged";
+    if (MPI_Comm_dup(MPI_COMM_WORLD, &comm->comm) != MPI_SUCCESS) {
+      std::cerr << "rank = " << rank << ":  Unable to create mcpar communicator (fatal)\n";
+      MPI_Abort(MPI_COMM_WORLD, 3);
+    }
+    bind_rank_to_device(comm->comm, rank);
   }
 #else
   if (mpi) throw("MCPar built without MPI: mpisiz must be 1 (rebuild with -DMCX_WITH_MPI)");
 #endif
   create(8675309u);  // the reference's seed literal (src/mcpar.cc:271)
 }
+
+const char *MCPar::exchange_backend() const { return comm ? comm->backend : "none"; }
 
 void MCPar::create(uint32_t seed)
 {
@@ -165,6 +229,39 @@ void MCPar::create(uint32_t seed)
                             SCALE_DEC, SCALE_INC, SYNCSTEP, seed);
   if (st == MCX_ERR_INVALID || st == MCX_ERR_UNSUPPORTED) throw("Invalid MCPar configuration");
   if (st != MCX_OK) die("MCPar::MCPar");
+#ifdef MCX_WITH_MPI
+  // Exchange of the (mu, sig^2) slots (src/mcpar.cc:127-140).  Preferred: the library's in-place
+  // ncclAllGather on device memory (RCCL over xGMI) -- MPI only ships the communicator id, once, here
+  // (collective, like the MPI_Comm_dup above).  Fallback, decided collectively: MPI_Allgather through host
+  // memory, when two ranks share a GPU, RCCL is not loadable, its initialisation fails on any rank, or the
+  // user asks for it (MCPAR_EXCHANGE=mpi).
+  if (comm) {
+    comm->rccl = false;
+    comm->backend = "mpi-staged";
+    const char *want = getenv("MCPAR_EXCHANGE");
+    int ok = !(want && std::strcmp(want, "mpi") == 0) && mcx_rccl_available();
+    int all_ok = 0;
+    MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, comm->comm);
+    if (all_ok && one_gpu_per_rank(comm->comm, size)) {
+      unsigned char id[MCX_RCCL_ID_BYTES];
+      std::memset(id, 0, sizeof id);
+      ok = rank != 0 || mcx_rccl_unique_id(id) == MCX_OK;
+      MPI_Bcast(id, (int)sizeof id, MPI_BYTE, 0, comm->comm);
+      MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, comm->comm);
+      if (all_ok) {
+        ok = mcx_exchange_rccl_init(eng, id) == MCX_OK && mcx_debug_exchange(eng) == MCX_OK;
+        if (!ok) std::cerr << "rank = " << rank << ":  RCCL exchange unavailable (" << mcx_last_error() << "), using MPI\n";
+        MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, comm->comm);
+        if (all_ok) {
+          comm->rccl = true;
+          comm->backend = "rccl";
+        } else {
+          mcx_exchange_rccl_destroy(eng);
+        }
+      }
+    }
+  }
+#endif
 }
 
 void MCPar::set_seed_and_recreate(uint32_t seed) { create(seed); }
@@ -172,6 +269,10 @@ void MCPar::set_seed_and_recreate(uint32_t seed) { create(seed); }
 MCPar::~MCPar()
 {
   if (eng) mcx_destroy(eng);
+#ifdef MCX_WITH_MPI
+  if (comm) MPI_Comm_free(&comm->comm);
+#endif
+  delete comm;
 }
 
 void MCPar::covar_setup(const float *incov, float *restrict cov)
@@ -259,9 +360,9 @@ int output_hook(void *vctx, int steps_done)
 #ifdef MCX_WITH_MPI
 struct XchgCtx {
   MPI_Comm comm;
-  std::vector<float> host;
+  std::vector<float> &host;
 };
-// MPI_Allgather of src/mcpar.cc:127-140, staged through host memory
+// MPI_Allgather of src/mcpar.cc:127-140, staged through host memory (the fallback: see MCPar::create)
 int mpi_exchange(void *vctx, int phase, void *dev, size_t slot, int shard, int nshards, void *stream)
 {
   if (phase != MCX_XCHG_BEGIN) return 0;
@@ -306,11 +407,10 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
                 logging, mpi,        logstep,  SYNCSTEP, 0,          outsamples.size()};
   mcx_set_output_hook(eng, output_hook, &ctx);
 #ifdef MCX_WITH_MPI
-  XchgCtx xc;
-  if (mpi) {
-    xc.comm = mcparComm;
-    mcx_set_exchange(eng, mpi_exchange, &xc);
-  }
+  std::vector<float> nohost;
+  XchgCtx xc = {comm ? comm->comm : MPI_COMM_WORLD, comm ? comm->host : nohost};
+  const bool staged = mpi && comm && !comm->rccl;
+  if (staged) mcx_set_exchange(eng, mpi_exchange, &xc);
 #endif
   logfile << "Starting burn-in.  Samples = " << nburn << std::endl;  // src/mcpar.cc:56
   const int outstep = nsamp > 50 ? nsamp / 10 : 5;
@@ -319,6 +419,9 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
 
   const int st = mcx_run(eng, nsamp, nburn, pinit, &f, incov);
   mcx_set_output_hook(eng, 0, 0);
+#ifdef MCX_WITH_MPI
+  if (staged) mcx_set_exchange(eng, 0, 0);  // its context lives on this stack frame
+#endif
   if (st == MCX_ERR_ALLOC) {
     logfile << "Unable to allocate space for output samples.  Exiting.\n";
     exit(2);

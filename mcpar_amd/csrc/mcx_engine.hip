@@ -434,7 +434,10 @@ static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t 
   MCXCHK(e->trash.alloc(4 * (size_t)a.n * lpc));
   for (int c0 = 0; c0 < a.nsteps; c0 += SPLIT_CHUNK) {
     const int ns = std::min(SPLIT_CHUNK, a.nsteps - c0);
-    HIPCHK(mcxk_launch_gen(lpc, e->zpre.p, e->upre.p, a.n, a.d, ns, a.t0 + (uint32_t)c0, a.g0, a.seed, st));
+    {
+      ProfScope pg(e, MCX_K_GEN_NORMALS, (uint64_t)ns * (uint64_t)a.n);
+      HIPCHK(mcxk_launch_gen(lpc, e->zpre.p, e->upre.p, a.n, a.d, ns, a.t0 + (uint32_t)c0, a.g0, a.seed, st));
+    }
     SegArgs b = a;
     b.nsteps = ns;
     b.t0 = a.t0 + (uint32_t)c0;
@@ -448,7 +451,7 @@ static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t 
     b.upre = e->upre.p;
     b.trash = e->trash.p;
     HIPCHK(mcxk_launch_fast_pregen(lpc, lik, main, b, st));
-    e->cnt.kernel_launches += 2;
+    e->cnt.kernel_launches += 1;  // (the generator's scope counted itself)
   }
   return MCX_OK;
 }
@@ -699,6 +702,7 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     hipLaunchKernelGGL(k_remote_cmax_big, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, pvals, e->winvall.p,
                        e->cmax.p, n, d, N);
   } else {
+    ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)n * (uint64_t)N);
     if (d == dm) {
       DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, true>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
                                            0, st, pvals, (const int *)nullptr, n, e->winvall.p,
@@ -708,9 +712,10 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
                                            0, st, pvals, (const int *)nullptr, n, e->winvall.p,
                                            (float *)nullptr, e->pmax.p, d, N, S));
     }
-    hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S);
   }
+  if (!big) hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S);
   HIPCHK(hipGetLastError());
+  e->cnt.remote_pairs += (uint64_t)n * (uint64_t)N;
   int nact = n, pass = 0;
   int *ain = nullptr, *aout = e->active0.p;
   while (nact > 0) {
@@ -726,6 +731,8 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
       hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
     } else {
       DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
+      {
+      ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)nact * (uint64_t)N);
       if (d == dm) {
         DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, true>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
                                              0, st, ptrial, (const int *)ain, nact, e->winvall.p,
@@ -735,15 +742,17 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
                                              0, st, ptrial, (const int *)ain, nact, e->winvall.p,
                                              e->psum.p, e->pmax.p, d, N, S));
       }
+      }
       hipLaunchKernelGGL(k_remote_decide, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
     }
     HIPCHK(hipGetLastError());
+    e->cnt.remote_pairs += (uint64_t)nact * (uint64_t)N;
     HIPCHK(hipMemcpyAsync(&nact, e->nact.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     ain = aout;
     aout = (aout == e->active0.p) ? e->active1.p : e->active0.p;
     ++pass;
-    e->cnt.kernel_launches += big ? 1 : 3;
+    e->cnt.kernel_launches += big ? 1 : 2;  // (+1: the sweep's own scope)
   }
   hipLaunchKernelGGL(k_square, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, sigtrial, (size_t)e->ntot);
   HIPCHK(hipGetLastError());
@@ -955,6 +964,16 @@ extern "C" int mcx_device_count(int *n)
   *n = 0;
   MCXCHK(need_device());
   HIPCHK(hipGetDeviceCount(n));
+  return MCX_OK;
+}
+
+extern "C" int mcx_device_pci_bus_id(char *buf, size_t len)
+{
+  if (!buf || len < 16) return fail(MCX_ERR_INVALID, "buffer too small");
+  MCXCHK(need_device());
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetPCIBusId(buf, (int)len, dev));
   return MCX_OK;
 }
 

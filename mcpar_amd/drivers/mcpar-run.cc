@@ -85,7 +85,7 @@ int main(int argc, char *argv[])
       std::cerr << "chains " << nc << " x np " << np << "  burn " << nburn << " + samples " << nsamp
                 << ": accept rate (main) " << (double)mcpar.naccept_main() / ((double)nc * nsamp)
                 << ", remote passes " << mcpar.remote_passes() << ", " << (double)nc * (nburn + nsamp) / dt
-                << " chain-steps/s incl. output\n";
+                << " chain-steps/s incl. output, exchange: " << mcpar.exchange_backend() << "\n";
   } catch (const char *msg) {
     std::cerr << msg << "\n";
     return 2;

@@ -145,6 +145,9 @@ class Engine:
         self._keep.append(unique_id)
         check(load().mcx_exchange_rccl_init(self.h, C.c_char_p(unique_id)))
 
+    def rccl_init_raw(self, ptr):
+        check(load().mcx_exchange_rccl_init(self.h, ptr))
+
     def rccl_destroy(self):
         check(load().mcx_exchange_rccl_destroy(self.h))
 
@@ -257,6 +260,18 @@ class Engine:
             check(load().mcx_samples_copy(self.h, 0, ns.value, _fp(out)))
         return out
 
+    def samples_into(self, out, first_step=0, nsteps=None):
+        """copy sample rows into a caller-owned float32 array of (nsteps*nc, np+1) elements"""
+        if nsteps is None:
+            ns = C.c_int(0)
+            check(load().mcx_samples_steps(self.h, C.byref(ns)))
+            nsteps = ns.value - first_step
+        if out.dtype != np.float32 or not out.flags.c_contiguous or out.size < nsteps * self.nc * (self.np + 1):
+            raise ValueError("out must be a C-contiguous float32 array of nsteps*nc*(np+1) elements")
+        if nsteps:
+            check(load().mcx_samples_copy(self.h, first_step, nsteps, _fp(out)))
+        return nsteps
+
     def samples_range(self, first_step, nsteps):
         out = np.empty((nsteps * self.nc, self.np + 1), np.float32)
         if nsteps:
@@ -274,4 +289,4 @@ class Engine:
         p = Profile()
         check(load().mcx_get_profile(self.h, C.byref(p)))
         return {K_NAMES[i]: dict(ms=p.ms[i], launches=int(p.launches[i]), chain_steps=int(p.chain_steps[i]))
-                for i in range(8)}
+                for i in range(len(K_NAMES))}

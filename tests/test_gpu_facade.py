@@ -121,6 +121,10 @@ def test_two_mpi_ranks_through_the_facade(tmp_path):
                         "--nc", str(nc), "--nsamp", str(nsamp), "--nburn", str(nburn), "--pl", str(pl)],
                        cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+    # one GPU: the two ranks share it, RCCL refuses such a communicator and the facade falls back (collectively)
+    # to the host-staged MPI_Allgather; with two GPUs the ranks bind to one each and the exchange is RCCL
+    import mcpar_amd as M
+    assert ("exchange: rccl" if M.engine.device_count() >= 2 else "exchange: mpi-staged") in r.stderr, r.stderr[-500:]
     vl, keep = O.make_vlfunc(O.VL_ROSENBROCK1, np_)
     engs = [O.Engine(np_, nc, nshards=2, shard=s, pl=pl) for s in range(2)]
     O.run_all(engs, nsamp, nburn, [O.default_pinit(np_, nc, g0=s * nc) for s in range(2)], vl)

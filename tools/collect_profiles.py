@@ -1,35 +1,78 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 output of a round (gpurun_out/<prefix>_{kt,fetch,write,sq,grbm}) into the tracked
-summaries under profiles/.  usage: tools/collect_profiles.py prof3 r01"""
-import collections, csv, glob, json, os, shutil, sys
-pre, rnd = sys.argv[1], sys.argv[2]
+"""Turn a round's rocprofv3 output under gpurun_out/ into the tracked summaries under profiles/.
+
+  tools/collect_profiles.py r02
+
+expects (all optional, per configuration C in c2 c3 c5 c3-murray):
+  gpurun_out/<rnd>_bench_C.json   the JSON line of `bench.py --config C [--keep-pmc gpurun_out/<rnd>_pmc_C]`
+  gpurun_out/<rnd>_pmc_C/<COUNTERS>/**/*counter_collection.csv   the live PMC passes bench.py kept
+  gpurun_out/<rnd>_kt_C/**/*kernel_stats.csv    `rocprofv3 --kernel-trace --stats -- python3 bench.py --config C ...`
+and writes
+  profiles/<rnd>_bench_C.json, profiles/<rnd>_C_kernel_stats.csv,
+  profiles/<rnd>_C_pmc_counters.json  (per kernel: mean per dispatch of every collected counter, second job only),
+  profiles/<rnd>_C_fused_kernel_counters.json  (what bench.py falls back to when it cannot run rocprofv3 itself).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+rnd = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-go = os.path.join(root, "gpurun_out"); pr = os.path.join(root, "profiles")
-shutil.copy(glob.glob(f"{go}/{pre}_kt/*/*_kernel_stats.csv")[0], f"{pr}/{rnd}_bench_kernel_stats.csv")
-def counters(tag):
-    f = glob.glob(f"{go}/{pre}_{tag}/*/*_counter_collection.csv")[0]
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: dict(dispatches=len(v), mean=sum(v) / len(v), max=max(v)) for c, v in cs.items()} for k, cs in agg.items()}
-fetch, write = counters("fetch"), counters("write")
-json.dump({"unit": "KB per dispatch", "FETCH_SIZE": {k: v["FETCH_SIZE"] for k, v in fetch.items()},
-           "WRITE_SIZE": {k: v["WRITE_SIZE"] for k, v in write.items()}}, open(f"{pr}/{rnd}_bench_pmc_fetch_write.json", "w"), indent=1)
-main = [k for k in fetch if "k_fused_fast<4, true" in k][0]
-burn = [k for k in fetch if "k_fused_fast<4, false" in k][0]
-var = [k for k in fetch if "k_variance" in k][0]
-t = lambda k: (2 * fetch[k]["FETCH_SIZE"]["mean"] + write[k]["WRITE_SIZE"]["mean"]) * 1024
-json.dump({"round": rnd, "source": f"profiles/{rnd}_bench_pmc_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0)",
-           "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; the factor 2 on FETCH_SIZE is the gfx950 correction (MI355X_MICROARCH.md, HBM), calibrated in the same run: "
-                         "k_variance reads 4 MiB and reports %.1f KB, writes 4 MiB and reports %.1f KB" % (fetch[var]["FETCH_SIZE"]["mean"], write[var]["WRITE_SIZE"]["mean"]),
-           "k_fused_steps_main_bytes_per_launch": t(main), "k_fused_steps_burn_bytes_per_launch": t(burn), "kernel_main": main},
-          open(f"{pr}/pmc_traffic.json", "w"), indent=1)
-sq = counters("sq")[main]; grbm = counters("grbm")[main]
-res = {c: v["mean"] for c, v in sq.items()}
-res["GRBM_GUI_ACTIVE"] = grbm["GRBM_GUI_ACTIVE"]["mean"]
-res["valu_busy_fraction"] = 4 * res["SQ_ACTIVE_INST_VALU"] / 1024 / (res["GRBM_GUI_ACTIVE"] / 8)
-res["valu_instructions_per_wave_step"] = res["SQ_INSTS_VALU"] / (4096 * 250.0)
-res["_note"] = (main + ": mean per launch (250 steps x 65536 chains, 4096 waves); SQ_* busy/wait counters are in quad-cycles; "
-                "GRBM_GUI_ACTIVE is summed over the 8 XCDs. valu_busy_fraction = 4*SQ_ACTIVE_INST_VALU/1024 SIMDs over GRBM_GUI_ACTIVE/8 kernel cycles.")
-json.dump(res, open(f"{pr}/{rnd}_fused_kernel_sq_counters.json", "w"), indent=1)
-print(json.dumps({k: res[k] for k in ("valu_busy_fraction", "valu_instructions_per_wave_step")}), t(main))
+go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+os.makedirs(pr, exist_ok=True)
+KT_DIR = {"c3": "c3", "c2": "c2", "c5": "c5", "c3-murray": "c3m"}
+
+
+def lpc_for(d):
+    nb, l = (d + 3) // 4, 1
+    while l < nb:
+        l <<= 1
+    return l
+
+
+for cfg in ("c3", "c2", "c5", "c3-murray"):
+    bj = os.path.join(go, "%s_bench_%s.json" % (rnd, cfg))
+    line = None
+    if os.path.exists(bj):
+        line = json.load(open(bj))
+        json.dump(line, open(os.path.join(pr, "%s_bench_%s.json" % (rnd, cfg)), "w"), indent=1)
+    ks = glob.glob(os.path.join(go, "%s_kt_%s" % (rnd, KT_DIR[cfg]), "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(pr, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
+    table = collections.defaultdict(dict)
+    for f in glob.glob(os.path.join(go, "%s_pmc_%s" % (rnd, cfg), "*", "**", "*counter_collection.csv"), recursive=True):
+        acc = collections.defaultdict(list)
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            dur[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        for (k, c), v in acc.items():
+            h = v[len(v) // 2:]
+            dd = dur[(k, c)][len(v) // 2:]
+            table[k][c] = dict(dispatches_of_measured_job=len(h), mean=sum(h) / len(h), max=max(h),
+                               mean_duration_ns_under_profiler=sum(dd) / len(dd))
+    if not table:
+        continue
+    json.dump({"source": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --pmc-child --config %s (one pass per counter "
+                         "group: FETCH_SIZE | WRITE_SIZE | SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES | GRBM_GUI_ACTIVE), spawned "
+                         "by bench.py itself; FETCH_SIZE/WRITE_SIZE in KB" % cfg, "kernels": table},
+              open(os.path.join(pr, "%s_%s_pmc_counters.json" % (rnd, cfg)), "w"), indent=1)
+    d = line["config"]["nparam"] if line else 16
+    main = [k for k in table if "k_fused_fast<%d, true" % lpc_for(d) in k]
+    if not main:
+        continue
+    m = table[main[0]]
+    res = {"kernel": main[0], "round": rnd, "config": cfg}
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        res["traffic_bytes_per_launch"] = (2 * m["FETCH_SIZE"]["mean"] + m["WRITE_SIZE"]["mean"]) * 1024
+        res["traffic_formula"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM)"
+    if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m:
+        res["valu_busy_fraction"] = 4 * m["SQ_ACTIVE_INST_VALU"]["mean"] / (1024 * m["GRBM_GUI_ACTIVE"]["mean"] / 8)
+        res["valu_formula"] = "4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8)"
+        res["SQ_INSTS_VALU"] = m.get("SQ_INSTS_VALU", {}).get("mean")
+    json.dump(res, open(os.path.join(pr, "%s_%s_fused_kernel_counters.json" % (rnd, cfg)), "w"), indent=1)
+    print(cfg, {k: v for k, v in res.items() if k in ("traffic_bytes_per_launch", "valu_busy_fraction")})
