@@ -8,7 +8,7 @@
  * shims over these functions.  See INTEGRATION.md for the binding a maintainer would add.
  *
  * Plain pointers and sizes only.  Unless a parameter says "device", pointers are host memory.
- * All arithmetic is float32 ("MCX arithmetic v1"); accept decisions are bit-exact
+ * All arithmetic is float32 ("MCX arithmetic v2"); accept decisions are bit-exact
  * against oracle/mcx_oracle.c for a fixed seed.
  *
  * Every function returns MCX_OK (0) or an mcx_status; mcx_last_error() gives the message.
@@ -243,7 +243,8 @@ int mcx_device_pci_bus_id(char *buf, size_t len);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:
  * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
  * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf,
- * 9/10 packed expf lane 0/1, 11 packed logf, 12/13 packed/scalar sincos hash */
+ * 9/10 packed expf lane 0/1, 11 packed logf, 12/13 packed/scalar sincos hash, 14/15 scalar/packed log of
+ * the acceptance draw */
 int mcx_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out_bits);
 /* number of float bit patterns in [lo_bits, hi_bits) where the kernels' lean sqrt (valid for +-0 and
  * positive normal floats) differs from IEEE sqrtf, and the smallest such pattern */

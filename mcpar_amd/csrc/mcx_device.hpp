@@ -132,7 +132,7 @@ struct Lik<LIK_MIX, LPC> {  // log sum_c w_c exp(-|x-m_c|^2/2); lik = means[K*d]
       float s = 0.0f;
 #pragma unroll
       for (int c = 0; c < 8; ++c)
-        if (c < K) s = s + expf_v1(e[c] - emax);
+        if (c < K) s = s + expf_v2(e[c] - emax);
       return emax + logf_v1(s);
     }
     float emax = comp(xb, nv, 0);
@@ -141,7 +141,7 @@ struct Lik<LIK_MIX, LPC> {  // log sum_c w_c exp(-|x-m_c|^2/2); lik = means[K*d]
       emax = e > emax ? e : emax;
     }
     float s = 0.0f;
-    for (int c = 0; c < K; ++c) s = s + expf_v1(comp(xb, nv, c) - emax);
+    for (int c = 0; c < K; ++c) s = s + expf_v2(comp(xb, nv, c) - emax);
     return emax + logf_v1(s);
   }
 };
@@ -267,12 +267,14 @@ __device__ __forceinline__ void propose_block(const float x[4], float pt[4], con
   }
 }
 
-// accept test (src/mcpar.cc:66-69, 166-169): u < exp(ly' - ly) * cfac
+// accept test of a Murray step (src/mcpar.cc:166-169): u < exp(ly' - ly) * cfac
 __device__ __forceinline__ bool accept_decision(float lytrial, float ly, float cfac, uint32_t word)
 {
-  const float pacpt = expf_v1(lytrial - ly) * cfac;
+  const float pacpt = expf_v2(lytrial - ly) * cfac;
   return u24(word) < pacpt;
 }
+// accept test of a local step (cfac = 1; src/mcpar.cc:66-69, 166-169) in the log domain: lu = accept_lu(word)
+__device__ __forceinline__ bool accept_local(float lytrial, float ly, float lu) { return lu < lytrial - ly; }
 
 // Welford update of one block (src/mcpar.cc:199-202)
 __device__ __forceinline__ void welford_block(const float x[4], float mu[4], float ps[4],
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
   L.init(a.lik, d, k0, nv, a.ncomp);
 
   uint32_t cnt = 0, wacc = 0;
-  u32x4 aw = {0, 0, 0, 0};
+  float alu[4] = {0, 0, 0, 0};  // log of the four acceptance draws of the current ACCEPT block
   uint32_t ablk = 0xffffffffu;
   float winv = 1.0f;
 
@@ -364,9 +366,12 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
     const float lyt = L.eval(pt, nv);
     if ((t >> 2) != ablk) {  // one Philox block serves four consecutive steps
       ablk = t >> 2;
-      aw = philox4x32_10(ablk, g, 0u, 0u, a.seed, ST_ACCEPT);
+      const u32x4 aw = philox4x32_10(ablk, g, 0u, 0u, a.seed, ST_ACCEPT);
+      const f32x2 l01 = accept_lu_x2(aw.x, aw.y), l23 = accept_lu_x2(aw.z, aw.w);
+      alu[0] = l01.x; alu[1] = l01.y; alu[2] = l23.x; alu[3] = l23.y;
     }
-    const bool take = accept_decision(lyt, ly, 1.0f, pick_word(aw, t & 3u));
+    const uint32_t wi = t & 3u;
+    const bool take = accept_local(lyt, ly, wi == 0u ? alu[0] : (wi == 1u ? alu[1] : (wi == 2u ? alu[2] : alu[3])));
     if (take) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = pt[k];
@@ -425,8 +430,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
 //   * 1/pwgt comes from a host-built table through a scalar load instead of a VALU division.
 // ---------------------------------------------------------------------------------------------
 // Random numbers of nsteps consecutive local steps for every chain of the shard (small-n mode):
-// Z[s][chain][k] = the normal of parameter k at step t0+s (LOCAL stream), U[s][chain] = the accept
-// threshold (ACCEPT stream; one Philox block serves steps 4b..4b+3, drawn by the lane of the first of
+// Z[s][chain][k] = the normal of parameter k at step t0+s (LOCAL stream), U[s][chain] = the log of the
+// acceptance draw (ACCEPT stream; one Philox block serves steps 4b..4b+3, drawn by the lane of the first of
 // them that lies in this launch).  One lane per (step, chain, 4-parameter block): fully parallel.
 template <int LPC>
 __global__ __launch_bounds__(BLOCK) void k_gen_normals(float *__restrict__ Z, float *__restrict__ U, int n,
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_normals(float *__restrict__ Z, fl
     const u32x4 aw = philox4x32_10(t >> 2, g, 0u, 0u, seed, ST_ACCEPT);
     for (uint32_t w = t & 3u; w < 4u; ++w) {
       const int s2 = s + (int)(w - (t & 3u));
-      if (s2 < nsteps) U[(size_t)s2 * n + chain] = u24(pick_word(aw, w));
+      if (s2 < nsteps) U[(size_t)s2 * n + chain] = accept_lu(pick_word(aw, w));
     }
   }
 }
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
   }
   float ly = a.ly[chain];
   uint32_t cnt = 0, wacc = 0;
-  u32x4 aw = {0, 0, 0, 0};
+  f32x2 al01 = {0, 0}, al23 = {0, 0};  // log of the four acceptance draws of this lane's current ACCEPT block
   uint32_t ablk = 0xffffffffu;
   float *sx = a.samp_x ? a.samp_x + off : nullptr;
   float *sl = a.samp_x ? a.samp_ly + chain : nullptr;
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
   float *sxv = (PREGEN && a.samp_x) ? (live ? a.samp_x + off : a.trash + 4 * gid) : nullptr;  // per-lane pointer
   const size_t sxv_stride = live ? sx_stride : 0;
 
-  // one Metropolis step given this lane's four normals (ze = z0,z2; zo = z1,z3) and the accept threshold
+  // one Metropolis step given this lane's four normals (ze = z0,z2; zo = z1,z3) and the log of the acceptance draw
   auto step = [&](int s, f32x2 ze, f32x2 zo, float u, float winv_s) {
     const f32x2 pe = fma2(te, ze, xe), po = fma2(to, zo, xo);  // src/mcpar.cc:302-312
     float acc = 0.0f;
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
 #pragma unroll
       for (int c = 0; c < 8; c += 2) {  // exp two components at a time, add them in component order
         if (c < K) {
-          const f32x2 ex = expf_v1x2(f32x2{e[c] - emax, e[c + 1] - emax});
+          const f32x2 ex = expf_v2x2(f32x2{e[c] - emax, e[c + 1] - emax});
           ssum = ssum + ex.x;
           if (c + 1 < K) ssum = ssum + ex.y;
         }
@@ -596,8 +601,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
     } else {
       lyt = 0.0f - group_sum<LPC>(acc);
     }
-    // src/mcpar.cc:62-75 (cfac = 1 for local proposals)
-    const bool take = u < (PREGEN ? expf_v1_sel(lyt - ly) : expf_v1(lyt - ly));
+    // src/mcpar.cc:62-75 (cfac = 1 for local proposals): log u < ly' - ly
+    const bool take = accept_local(lyt, ly, u);
     xe = take ? pe : xe;
     xo = take ? po : xo;
     ly = take ? lyt : ly;
@@ -646,12 +651,16 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
       // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
       // lanes of a chain split the work: lane q draws block b for b % LPC == q, once per 4*LPC steps.
       const uint32_t blk = t >> 2;
-      if ((blk & ~(uint32_t)(LPC - 1)) != ablk) {
+      if ((blk & ~(uint32_t)(LPC - 1)) != ablk) {  // the four logs are taken here, once per 4*LPC steps per lane
         ablk = blk & ~(uint32_t)(LPC - 1);
-        aw = philox4x32_10(ablk + (uint32_t)q, g, 0u, 0u, a.seed, ST_ACCEPT);
+        const u32x4 aw = philox4x32_10(ablk + (uint32_t)q, g, 0u, 0u, a.seed, ST_ACCEPT);
+        al01 = accept_lu_x2(aw.x, aw.y);
+        al23 = accept_lu_x2(aw.z, aw.w);
       }
-      const uint32_t word = group_bcast<LPC>(pick_word(aw, t & 3u), blk & (uint32_t)(LPC - 1), q);
-      step(s, ze, zo, u24(word), MAIN ? a.winv[a.isamp0 + s] : 1.0f);
+      const uint32_t wi = t & 3u;
+      const float mine = wi == 0u ? al01.x : (wi == 1u ? al01.y : (wi == 2u ? al23.x : al23.y));
+      const float lu = as_f32(group_bcast<LPC>(as_u32(mine), blk & (uint32_t)(LPC - 1), q));
+      step(s, ze, zo, lu, MAIN ? a.winv[a.isamp0 + s] : 1.0f);
     }
   } else {
     // Batches of P steps, double buffered: at the top of a batch every load of it (issued one whole
@@ -818,7 +827,8 @@ __global__ __launch_bounds__(BLOCK) void k_accept(const StepArgs a)
   float ly = a.ly[chain];
   const float lyt = a.lytrial[chain];
   const u32x4 aw = philox4x32_10(a.t >> 2, g, 0u, 0u, a.seed, ST_ACCEPT);
-  const bool take = accept_decision(lyt, ly, a.cfac[chain], pick_word(aw, a.t & 3u));
+  const uint32_t aword = pick_word(aw, a.t & 3u);
+  const bool take = a.remote ? accept_decision(lyt, ly, a.cfac[chain], aword) : accept_local(lyt, ly, accept_lu(aword));
   if (take) {
     load_block(a.ptrial, chain, d, k0, nv, vec4, x);
     ly = lyt;
@@ -949,13 +959,16 @@ static __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsi
 // genRemote (src/mcpar.cc:315-451).  One lane per chain, chain vector in registers, the N
 // per-chain Gaussians Q_i streamed through wave-uniform (scalar) loads.
 // ---------------------------------------------------------------------------------------------
-// qpar[i] = (mu_i, 1/sig2_i): one Q_i is 2d contiguous floats, fetched with wide scalar loads
+// qpar[i] = (m'_i, s_i) with s = sqrt(1/sig2), m' = mu s: sum_k (mu_k - x_k)^2 / sig2_k (src/mcpar.cc:369-383)
+// is then sum_k t_k^2 with t_k = fma(-x_k, s_k, m'_k) -- two operations per pair-dimension.  One Q_i is 2d
+// contiguous floats, fetched with wide scalar loads.
 static __global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ qpar, size_t nd)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nd) {
     const float2 ms = reinterpret_cast<const float2 *>(musigall)[i];
-    reinterpret_cast<float2 *>(qpar)[i] = make_float2(ms.x, 1.0f / ms.y);
+    const float sq = __builtin_sqrtf(1.0f / ms.y);
+    reinterpret_cast<float2 *>(qpar)[i] = make_float2(ms.x * sq, sq);
   }
 }
 
@@ -967,11 +980,65 @@ __device__ __forceinline__ float q_arg(const float *__restrict__ qp, const float
 #pragma unroll
   for (int k = 0; k < DMAX; ++k)
     if (EXACT || k < d) {
-      const float xm = qp[2 * k] - x[k];
-      arg = __builtin_fmaf(xm * xm, qp[2 * k + 1], arg);
+      const float t = __builtin_fmaf(-x[k], qp[2 * k + 1], qp[2 * k]);
+      arg = __builtin_fmaf(t, t, arg);
     }
   return arg;
 }
+
+// The sweep loop of one block of Gaussians [q0, q1) with wave-uniform early outs.  The partial sums of arg
+// only grow (every term is a square), so once every chain of the wavefront has `arg > bound(lane)` after a
+// group of dimensions the remaining dimensions cannot bring any of them back under its bound, and this Q_i
+// is dropped for the whole wavefront; completed sums are the same bits as q_arg's.  One Q_i against 64
+// chains is mostly far away from all of them, so most of the sweep ends after the first
+// group: only that group's (m', s) pairs are fetched up front (one iteration ahead), the rest of a Q_i
+// only when some chain is still in range.  use(arg) consumes a completed sum; bound() is re-read per Q_i.
+template <int DMAX, bool EXACT, typename Bound, typename Use>
+__device__ __forceinline__ void sweep_block(const float *__restrict__ qpar, const float x[DMAX], int DD, int q0,
+                                            int q1, Bound bound, Use use)
+{
+  constexpr int G = DMAX >= 16 ? DMAX / 4 : DMAX;  // dimensions per group: 4 groups from 16-D up
+  const float *qp = qpar + 2 * (size_t)q0 * DD;
+  float cur[2 * G];
+#pragma unroll
+  for (int k = 0; k < 2 * G; ++k) cur[k] = (EXACT || k < 2 * DD) ? qp[k] : 0.0f;
+  for (int qi = q0; qi < q1; ++qi, qp += 2 * DD) {
+    const float *qn = qi + 1 < q1 ? qp + 2 * DD : qp;  // wave-uniform: scalar loads
+    float nxt[2 * G];
+#pragma unroll
+    for (int k = 0; k < 2 * G; ++k) nxt[k] = (EXACT || k < 2 * DD) ? qn[k] : 0.0f;
+    float arg = 0.0f;
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (EXACT || k < DD) {
+        const float t = __builtin_fmaf(-x[k], cur[2 * k + 1], cur[2 * k]);
+        arg = __builtin_fmaf(t, t, arg);
+      }
+    const float b = bound();
+    bool live = !__all(arg > b);
+    if (live && G < DMAX) {
+#pragma unroll
+      for (int c = G; c < DMAX; c += G) {
+#pragma unroll
+        for (int k = c; k < c + G; ++k)
+          if (EXACT || k < DD) {
+            const float t = __builtin_fmaf(-x[k], qp[2 * k + 1], qp[2 * k]);
+            arg = __builtin_fmaf(t, t, arg);
+          }
+        if (__all(arg > b)) {  // also after the last group: the consumer's exp is skipped
+          live = false;
+          break;
+        }
+      }
+    }
+    if (live) use(arg);
+#pragma unroll
+    for (int k = 0; k < 2 * G; ++k) cur[k] = nxt[k];
+  }
+}
+
+// arg > ZERO_ARG  =>  expf_v2(-arg/2) == 0 exactly: -arg/2 < -88 gives n = floor(-88 log2(e) + 1/2) <= -127 < -125
+constexpr float ZERO_ARG = 176.0f;
 
 constexpr int QBLOCK = 256;  // block length of the qisum summation order
 
@@ -980,7 +1047,7 @@ struct RemoteArgs {
   int nact;
   int *active_out;
   int *nact_out;
-  const float *musigall, *winv, *cmax;  // winv = qpar: (mu, 1/sig2) pairs
+  const float *musigall, *winv, *cmax;  // winv = qpar: (m', s) pairs
   float *ptrial, *mutrial, *sigtrial, *cfac;
   float *racpt;        // [n] rejection threshold of this pass, by chain
   float *psum, *pmax;  // [nact][S] per-block partial sums / maxima, by position in the active list
@@ -1020,14 +1087,16 @@ __global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
 
 // The all-pairs sweep (src/mcpar.cc:367-395 for ptrial, :421-437 for pvals): lanes = chains (vector
 // in registers), blockIdx.y = one block of QBLOCK consecutive Q_i, streamed through wave-uniform
-// (scalar) loads so that one 128-byte fetch serves 64 chain-Q pairs.  Writes the block's partial
-// sum and maximum; blocks are combined in index order by k_remote_decide (fixed summation order).
+// (scalar) loads so that one 128-byte fetch serves 64 chain-Q pairs.  SUMS: writes the block's partial
+// sum and maximum of Q = exp(-arg/2); blocks are combined in index order by k_remote_decide (fixed
+// summation order).  !SUMS (the cfac numerator max_i Q_i = exp(-min_i arg_i / 2)): writes the block's
+// minimum of arg -- no exp per pair; k_remote_cmax_combine takes the one exp per chain.
 template <int DMAX, bool SUMS, bool EXACT>
 __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict__ xrows,
                                                         const int *__restrict__ active, int nact,
                                                         const float *__restrict__ qpar,
                                                         float *__restrict__ psum,
-                                                        float *__restrict__ pmax, int d, int N, int S)
+                                                        float *__restrict__ pmax, int d, int N, int S, int own0)
 {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= nact) return;
@@ -1038,27 +1107,49 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
 #pragma unroll
   for (int k = 0; k < DMAX; ++k) x[k] = k < DD ? xrows[(size_t)j * DD + k] : 0.0f;
   const int q0 = sb * QBLOCK, q1 = (q0 + QBLOCK < N) ? q0 + QBLOCK : N;
-  float part = 0.0f, m = 0.0f;
-  for (int qi = q0; qi < q1; ++qi) {
-    const float gv = expf_v1(-0.5f * q_arg<DMAX, EXACT>(qpar + 2 * (size_t)qi * DD, x, DD));
-    if (SUMS) part = part + gv;
-    m = gv > m ? gv : m;
+  if (SUMS) {
+    float part = 0.0f, m = 0.0f;
+    // a dropped Q_i is +0 for every chain of the wavefront: part + 0 = part, m unchanged
+    sweep_block<DMAX, EXACT>(qpar, x, DD, q0, q1, [] { return ZERO_ARG; }, [&](float av) {
+      const float gv = expf_v2(-0.5f * av);
+      part = part + gv;
+      m = gv > m ? gv : m;
+    });
+    psum[(size_t)i * S + sb] = part;
+    pmax[(size_t)i * S + sb] = m;
+  } else {
+    // min_i arg_i.  Every block starts from the chain's arg against its OWN Gaussian (global index own0 + j,
+    // one of the N: the combined minimum over the blocks is unchanged), which is small -- the chain sits inside
+    // its own running posterior -- so nearly every other Q_i is abandoned after its first group of dimensions.
+    float amin = __builtin_inff();
+    if (own0 >= 0) {
+      const float *qo = qpar + 2 * (size_t)(own0 + j) * DD;
+      float a0 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < DMAX; ++k)
+        if (EXACT || k < DD) {
+          const float t = __builtin_fmaf(-x[k], qo[2 * k + 1], qo[2 * k]);
+          a0 = __builtin_fmaf(t, t, a0);
+        }
+      amin = a0 < amin ? a0 : amin;  // a NaN stays out, like below
+    }
+    // an arg equal to the bound cannot lower it either: `>` serves both sweeps
+    sweep_block<DMAX, EXACT>(qpar, x, DD, q0, q1, [&] { return amin; }, [&](float av) { amin = av < amin ? av : amin; });
+    pmax[(size_t)i * S + sb] = amin;
   }
-  if (SUMS) psum[(size_t)i * S + sb] = part;
-  pmax[(size_t)i * S + sb] = m;
 }
 
-// numerator of cfac: max_i Q_i(pvals_j) (src/mcpar.cc:421-437); does not depend on the pass
-static __global__ void k_remote_cmax_combine(const float *__restrict__ pmax, float *__restrict__ cmax, int n, int S)
+// numerator of cfac: max_i Q_i(pvals_j) = exp(-min_i arg_i / 2) (src/mcpar.cc:421-437); does not depend on the pass
+static __global__ void k_remote_cmax_combine(const float *__restrict__ pmin, float *__restrict__ cmax, int n, int S)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  float cm = 0.0f;
+  float amin = __builtin_inff();
   for (int sb = 0; sb < S; ++sb) {
-    const float v = pmax[(size_t)j * S + sb];
-    cm = v > cm ? v : cm;
+    const float v = pmin[(size_t)j * S + sb];
+    amin = v < amin ? v : amin;
   }
-  cmax[j] = cm;
+  cmax[j] = expf_v2(-0.5f * amin);
 }
 
 // rejection test of the pass (src/mcpar.cc:397-441); survivors are compacted for the next pass
@@ -1088,8 +1179,8 @@ __device__ __forceinline__ float q_arg_mem(const float *__restrict__ qp, const f
 {
   float arg = 0.0f;
   for (int k = 0; k < d; ++k) {
-    const float xm = qp[2 * k] - x[k];
-    arg = __builtin_fmaf(xm * xm, qp[2 * k + 1], arg);
+    const float t = __builtin_fmaf(-x[k], qp[2 * k + 1], qp[2 * k]);
+    arg = __builtin_fmaf(t, t, arg);
   }
   return arg;
 }
@@ -1101,12 +1192,12 @@ static __global__ __launch_bounds__(BLOCK) void k_remote_cmax_big(const float *_
   const int j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= n) return;
   const float *x = pvals + (size_t)j * d;
-  float cm = 0.0f;
+  float amin = __builtin_inff();
   for (int qi = 0; qi < N; ++qi) {
-    const float gv = expf_v1(-0.5f * q_arg_mem(qpar + 2 * (size_t)qi * d, x, d));
-    cm = gv > cm ? gv : cm;
+    const float av = q_arg_mem(qpar + 2 * (size_t)qi * d, x, d);
+    amin = av < amin ? av : amin;
   }
-  cmax[j] = cm;
+  cmax[j] = expf_v2(-0.5f * amin);
 }
 
 static __global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteArgs a)
@@ -1137,7 +1228,7 @@ static __global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteAr
   for (int b0 = 0; b0 < a.N; b0 += QBLOCK) {  // blocked summation order, DESIGN.md §3.5
     float part = 0.0f;
     for (int qi = b0; qi < a.N && qi < b0 + QBLOCK; ++qi) {
-      const float gv = expf_v1(-0.5f * q_arg_mem(a.winv + 2 * (size_t)qi * d, x, d));
+      const float gv = expf_v2(-0.5f * q_arg_mem(a.winv + 2 * (size_t)qi * d, x, d));
       part = part + gv;
       qm = gv > qm ? gv : qm;
     }
@@ -1181,7 +1272,7 @@ static __global__ void k_debug_numerics(int what, int n, const uint32_t *in, uin
   uint32_t r = 0;
   switch (what) {
   case 0: r = as_u32(logf_v1(as_f32(w))); break;
-  case 1: r = as_u32(expf_v1(as_f32(w))); break;
+  case 1: r = as_u32(expf_v2(as_f32(w))); break;
   case 2: sincos2pi_v1(w, s, c); r = as_u32(s); break;
   case 3: sincos2pi_v1(w, s, c); r = as_u32(c); break;
   case 4: r = as_u32(u24(w)); break;
@@ -1189,11 +1280,13 @@ static __global__ void k_debug_numerics(int what, int n, const uint32_t *in, uin
   case 6: r = philox4x32_10(w, 0, 0, 0, 0, 0).x; break;
   case 7: r = as_u32(sqrt_rn_pos(as_f32(w))); break;
   case 8: r = as_u32(__builtin_sqrtf(as_f32(w))); break;
-  case 9: r = as_u32(expf_v1x2(f32x2{as_f32(w), 1.0f}).x); break;
-  case 10: r = as_u32(expf_v1x2(f32x2{-3.0f, as_f32(w)}).y); break;
+  case 9: r = as_u32(expf_v2x2(f32x2{as_f32(w), 1.0f}).x); break;
+  case 10: r = as_u32(expf_v2x2(f32x2{-3.0f, as_f32(w)}).y); break;
   case 11: r = as_u32(logf_v1x2(f32x2{as_f32(w), 0.5f}).x); break;
   case 12: { f32x2 s2, c2; sincos2pi_v1x2(w, w ^ 0x9e3779b9u, s2, c2); r = as_u32(s2.x) ^ (as_u32(c2.x) << 1); } break;
   case 13: { float s1, c1; sincos2pi_v1(w, s1, c1); r = as_u32(s1) ^ (as_u32(c1) << 1); } break;
+  case 14: r = as_u32(accept_lu(w)); break;
+  case 15: r = as_u32(accept_lu_x2(w ^ 0x5bd1e995u, w).y); break;
   default: break;
   }
   out[i] = r;

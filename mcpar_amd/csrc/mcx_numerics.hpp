@@ -1,4 +1,4 @@
-// mcx_numerics.hpp -- "MCX arithmetic v1"  for gfx950 and for the engine's host
+// mcx_numerics.hpp -- "MCX arithmetic v2"  for gfx950 and for the engine's host
 // control code.  fp32 only, round-to-nearest-even, explicit fma; this translation unit must be
 // built with -ffp-contract=off and without fast-math so that the device result of every function
 // is a pure function of its input bits.
@@ -77,10 +77,11 @@ MCX_HD float logf_v1(float x)
   return r;
 }
 
-MCX_HD float expf_v1(float x)
+// exp = 2^n e^r, n = floor(x log2(e) + 1/2).  n > 127 -> +inf, n < -125 -> 0: results are normal or zero,
+// never denormal, so the scaling is an exact integer add to the exponent field.  NaN in, NaN out (the
+// acceptance test then fails: src/mcpar.cc:66-69).
+MCX_HD float expf_v2(float x)
 {
-  if (x > 88.72283f) return __builtin_inff();
-  if (x < -87.33654f) return 0.0f;
   const float fn = __builtin_floorf(__builtin_fmaf(x, 1.44269504f, 0.5f));
   float r = __builtin_fmaf(fn, -0.693359375f, x);
   r = __builtin_fmaf(fn, 2.12194440e-4f, r);
@@ -93,13 +94,25 @@ MCX_HD float expf_v1(float x)
   const float z = r * r;
   float y = __builtin_fmaf(p, z, r);
   y = y + 1.0f;
-  if (!(x == x)) return y;  // NaN in, NaN out (acceptance test then fails: src/mcpar.cc:66-69)
-  const int n = (int)fn;
-  const int n1 = n >> 1;
-  const int n2 = n - n1;
-  y = y * as_f32((uint32_t)(n1 + 127) << 23);
-  y = y * as_f32((uint32_t)(n2 + 127) << 23);
-  return y;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int n = (int)fn;  // v_cvt_i32_f32: saturates, NaN -> 0 (a NaN y stays NaN)
+#else
+  if (!(x == x)) return y;
+  const int n = (int)(fn > 200.0f ? 200.0f : (fn < -200.0f ? -200.0f : fn));
+#endif
+  float s = as_f32(as_u32(y) + ((uint32_t)n << 23));
+  s = fn < -125.0f ? 0.0f : s;
+  s = fn > 127.0f ? __builtin_inff() : s;
+  return s;
+}
+
+// log of the acceptance draw u24(w) in [0, 1): -inf at 0.  Local steps (cfac = 1) test u < exp(ly' - ly)
+// (src/mcpar.cc:66-69,166-169) in the log domain, log u < ly' - ly: the transcendental then depends on the
+// random draw alone and comes off the chain-state critical path.
+MCX_HD float accept_lu(uint32_t w)
+{
+  const float l = logf_v1(u24(w));
+  return (w >> 8) == 0u ? -__builtin_inff() : l;
 }
 
 MCX_HD void sincos2pi_v1(uint32_t w, float &s, float &c)
@@ -195,30 +208,8 @@ __device__ __forceinline__ void sincos2pi_v1x2(uint32_t wa, uint32_t wb, f32x2 &
   c = f32x2{(ka == 1u || ka == 2u) ? -cv.x : cv.x, (kb == 1u || kb == 2u) ? -cv.y : cv.y};
 }
 
-// expf_v1 with the range checks as selects instead of branches (same bits; for latency-bound code)
-__device__ __forceinline__ float expf_v1_sel(float x)
-{
-  const float fn = __builtin_floorf(__builtin_fmaf(x, 1.44269504f, 0.5f));
-  float r = __builtin_fmaf(fn, -0.693359375f, x);
-  r = __builtin_fmaf(fn, 2.12194440e-4f, r);
-  float p = 1.9875691500e-4f;
-  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
-  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
-  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
-  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
-  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
-  const float z = r * r;
-  float y = __builtin_fmaf(p, z, r);
-  y = y + 1.0f;
-  const int n = (int)fn;
-  const int n1 = n >> 1;
-  y = y * as_f32((uint32_t)(n1 + 127) << 23);
-  y = y * as_f32((uint32_t)(n - n1 + 127) << 23);
-  return x > 88.72283f ? __builtin_inff() : (x < -87.33654f ? 0.0f : y);  // NaN falls through as NaN
-}
-
-// expf_v1 on two values: same operations in the same order; the range checks are selects
-__device__ __forceinline__ f32x2 expf_v1x2(f32x2 x)
+// expf_v2 on two values: same operations in the same order
+__device__ __forceinline__ f32x2 expf_v2x2(f32x2 x)
 {
   const f32x2 fn = {__builtin_floorf(__builtin_fmaf(x.x, 1.44269504f, 0.5f)),
                     __builtin_floorf(__builtin_fmaf(x.y, 1.44269504f, 0.5f))};
@@ -234,13 +225,21 @@ __device__ __forceinline__ f32x2 expf_v1x2(f32x2 x)
   f32x2 y = fma2(p, z, r);
   y = y + splat2(1.0f);
   const int na = (int)fn.x, nb = (int)fn.y;
-  const int na1 = na >> 1, nb1 = nb >> 1;
-  y = y * f32x2{as_f32((uint32_t)(na1 + 127) << 23), as_f32((uint32_t)(nb1 + 127) << 23)};
-  y = y * f32x2{as_f32((uint32_t)(na - na1 + 127) << 23), as_f32((uint32_t)(nb - nb1 + 127) << 23)};
   f32x2 o;
-  o.x = x.x > 88.72283f ? __builtin_inff() : (x.x < -87.33654f ? 0.0f : y.x);
-  o.y = x.y > 88.72283f ? __builtin_inff() : (x.y < -87.33654f ? 0.0f : y.y);
+  o.x = as_f32(as_u32(y.x) + ((uint32_t)na << 23));
+  o.y = as_f32(as_u32(y.y) + ((uint32_t)nb << 23));
+  o.x = fn.x < -125.0f ? 0.0f : o.x;
+  o.y = fn.y < -125.0f ? 0.0f : o.y;
+  o.x = fn.x > 127.0f ? __builtin_inff() : o.x;
+  o.y = fn.y > 127.0f ? __builtin_inff() : o.y;
   return o;
+}
+
+// accept_lu of two draws at once (same bits)
+__device__ __forceinline__ f32x2 accept_lu_x2(uint32_t wa, uint32_t wb)
+{
+  const f32x2 l = logf_v1x2(f32x2{u24(wa), u24(wb)});
+  return f32x2{(wa >> 8) == 0u ? -__builtin_inff() : l.x, (wb >> 8) == 0u ? -__builtin_inff() : l.y};
 }
 
 // Correctly rounded sqrt for x = +-0 or x >= 2^-96: the raw v_sqrt_f32 (<= 1 ulp) plus

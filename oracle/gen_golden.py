@@ -107,7 +107,7 @@ def gen_oracle_runs():
     w = np.array([5, 1, 1, 1, 1, 1, 1, 1], np.float32)
     one("mix_c5_small", O.VL_GAUSSMIX, 32, 32, 60, 30, 0.8, params=np.concatenate([means.ravel(), w]),
         ncomp=8)
-    return dict(source="oracle/mcx_oracle.c (MCX arithmetic v1), seed 8675309", runs=runs)
+    return dict(source="oracle/mcx_oracle.c (MCX arithmetic v2), seed 8675309", runs=runs)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 /*
  * mcx_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See mcx_oracle.h.
  *
- * Every function cites the reference lines it restates.  "MCX arithmetic v1" 
+ * Every function cites the reference lines it restates.  "MCX arithmetic v2" 
  * is restated here independently of mcpar_amd/csrc/: nothing is shared with the product
  * except the written specification.
  *
@@ -82,11 +82,10 @@ float mcxo_logf(float x)
   return r;
 }
 
-/* exp.  >88.72283 -> +inf; < -87.33654 -> 0 (no denormal results); NaN propagates. */
+/* exp = 2^n * e^r, n = floor(x log2(e) + 1/2).  n > 127 -> +inf; n < -125 -> 0 (results are normal or
+ * zero, never denormal, so the scaling is an exact add to the exponent field); NaN propagates. */
 float mcxo_expf(float x)
 {
-  if (x > 88.72283f) return INFINITY;
-  if (x < -87.33654f) return 0.0f;
   float fn = floorf(fmaf(x, 1.44269504f, 0.5f));
   float r = fmaf(fn, -0.693359375f, x);
   r = fmaf(fn, 2.12194440e-4f, r);
@@ -100,13 +99,13 @@ float mcxo_expf(float x)
   float y = fmaf(p, z, r);
   y = y + 1.0f;
   if (!(x == x)) return y; /* NaN: (int)fn is undefined in C, skip the scaling */
-  int n = (int)fn;
-  int n1 = n >> 1;
-  int n2 = n - n1;
-  y = y * bits2f((uint32_t)(n1 + 127) << 23);
-  y = y * bits2f((uint32_t)(n2 + 127) << 23);
-  return y;
+  if (fn > 127.0f) return INFINITY;
+  if (fn < -125.0f) return 0.0f;
+  return bits2f(f2bits(y) + ((uint32_t)(int)fn << 23));
 }
+
+/* log of the acceptance draw u24(w) in [0,1): -inf at 0 (local steps test log u < ly' - ly) */
+float mcxo_accept_lu(uint32_t w) { return (w >> 8) == 0u ? -INFINITY : mcxo_logf(mcxo_u24(w)); }
 
 /* sin/cos of 2*pi*w/2^32 by quadrant reduction on the integer + Cephes sinf/cosf kernels */
 void mcxo_sincos2pi(uint32_t w, float *s, float *c)
@@ -362,7 +361,7 @@ mcxo_engine *mcxo_create(int np, int nc, int nshards, int shard, float pl, float
   e->sig = zalloc(4 * nt); e->mutrial = zalloc(4 * nt); e->sigtrial = zalloc(4 * nt);
   e->psum2 = zalloc(4 * nt);
   e->musigall = zalloc(8 * (size_t)e->tchains * np);
-  e->winvall = zalloc(4 * (size_t)e->tchains * np);
+  e->winvall = zalloc(8 * (size_t)e->tchains * np); /* (m', s) pairs of the Murray sweep */
   e->lylast = zalloc(4 * n); e->lytrial = zalloc(4 * n); e->cfac = zalloc(4 * n);
   e->pacpt = zalloc(4 * n); e->acpt = zalloc(4 * n); e->qisum = zalloc(4 * n);
   e->qimax = zalloc(4 * n); e->cmax = zalloc(4 * n);
@@ -427,36 +426,47 @@ int mcxo_gen_local(const mcxo_engine *e, uint32_t t, const float *pvals, float *
   return 0;
 }
 
-/* sum_k (mu_qk - x_k)^2 / sig2_qk with the reciprocal precomputed (src/mcpar.cc:369-383) */
-static inline float qarg(int d, const float *ms, const float *winv, const float *x)
+/* sum_k (mu_qk - x_k)^2 / sig2_qk (src/mcpar.cc:369-383) as sum_k t_k^2, t_k = s_qk (mu_qk - x_k) evaluated
+ * as fma(-x_k, s_qk, m'_qk) with s = sqrt(1/sig2) and m' = mu s precomputed per Gaussian: two operations per
+ * pair-dimension.  qp = the Gaussian's (m', s) pairs. */
+static inline float qarg(int d, const float *qp, const float *x)
 {
   float arg = 0.0f;
   for (int k = 0; k < d; ++k) {
-    float xm = ms[2 * k] - x[k];
-    arg = fmaf(xm * xm, winv[k], arg);
+    float t = fmaf(-x[k], qp[2 * k + 1], qp[2 * k]);
+    arg = fmaf(t, t, arg);
   }
   return arg;
 }
 
 /* The all-pairs sweep of one chain vector x over the N per-chain Gaussians (src/mcpar.cc:367-395 for
- * ptrial, :421-437 for pvals): Q_i = exp(-arg_i/2), running maximum from qm0, and -- when qs_out is
- * given -- the sum in the order of DESIGN.md §3.5: the N terms in blocks of QBLOCK consecutive Q_i,
- * each block summed left to right from 0, block sums added left to right onto FPEPS (so that a GPU
- * can sweep the blocks in parallel and still be bit-exact).  Plain scalar statement. */
-static void sweep_scalar(int d, int N, const float *musigall, const float *winvall, const float *x,
-                         float qm0, float *qs_out, float *qm_out)
+ * ptrial): Q_i = exp(-arg_i/2), running maximum from FPEPS, and the sum in the order of DESIGN.md §3.5: the
+ * N terms in blocks of QBLOCK consecutive Q_i, each block summed left to right from 0, block sums added left
+ * to right onto FPEPS (so that a GPU can sweep the blocks in parallel and still be bit-exact).
+ * qs_out == NULL (src/mcpar.cc:421-437, the numerator of cfac): only max_i Q_i is wanted, which is
+ * exp(-min_i arg_i / 2) -- one exp per chain instead of one per pair.  Plain scalar statement. */
+static void sweep_scalar(int d, int N, const float *qpar, const float *x, float *qs_out, float *qm_out)
 {
-  float qs = FPEPS, qm = qm0;
+  if (!qs_out) {
+    float amin = INFINITY;
+    for (int qi = 0; qi < N; ++qi) {
+      float a = qarg(d, qpar + 2 * (size_t)qi * d, x);
+      amin = a < amin ? a : amin;
+    }
+    *qm_out = mcxo_expf(-0.5f * amin);
+    return;
+  }
+  float qs = FPEPS, qm = FPEPS;
   for (int b0 = 0; b0 < N; b0 += QBLOCK) {
     float part = 0.0f;
     for (int qi = b0; qi < N && qi < b0 + QBLOCK; ++qi) {
-      float gv = mcxo_expf(-0.5f * qarg(d, musigall + 2 * (size_t)qi * d, winvall + (size_t)qi * d, x));
+      float gv = mcxo_expf(-0.5f * qarg(d, qpar + 2 * (size_t)qi * d, x));
       part = part + gv;
       qm = gv > qm ? gv : qm;
     }
     qs = qs + part;
   }
-  if (qs_out) *qs_out = qs;
+  *qs_out = qs;
   *qm_out = qm;
 }
 
@@ -464,10 +474,10 @@ static void sweep_scalar(int d, int N, const float *musigall, const float *winva
 #include <immintrin.h>
 #define MCXO_HAVE_AVX2 1
 /* The same sweep, eight Q_i at a time: every lane performs exactly the scalar sequence of IEEE
- * operations (sub, mul, fma, the mcxo_expf polynomial), the eight results are then added / compared
+ * operations (two fma per dimension, the mcxo_expf polynomial), the eight results are then added / compared
  * one by one in index order -- same bits as sweep_scalar (tests/test_oracle_numerics.py checks it),
  * ~8x faster, which is what makes oracle comparisons at 32 768 - 65 536 chains affordable.
- * qt = (mu, 1/sig^2) of the Gaussians regrouped in blocks of 8: qt[(b*d + k)*16 + {0..7 | 8..15}]. */
+ * qt = (m', s) of the Gaussians regrouped in blocks of 8: qt[(b*d + k)*16 + {0..7 | 8..15}]. */
 __attribute__((target("avx2,fma"))) static inline __m256 expf8(__m256 x)
 {
   const __m256 fn = _mm256_floor_ps(_mm256_fmadd_ps(x, _mm256_set1_ps(1.44269504f), _mm256_set1_ps(0.5f)));
@@ -483,26 +493,43 @@ __attribute__((target("avx2,fma"))) static inline __m256 expf8(__m256 x)
   __m256 y = _mm256_fmadd_ps(p, z, r);
   y = _mm256_add_ps(y, _mm256_set1_ps(1.0f));
   const __m256i n = _mm256_cvttps_epi32(fn);
-  const __m256i n1 = _mm256_srai_epi32(n, 1), n2 = _mm256_sub_epi32(n, n1);
-  const __m256i b127 = _mm256_set1_epi32(127);
-  __m256 ys = _mm256_mul_ps(y, _mm256_castsi256_ps(_mm256_slli_epi32(_mm256_add_epi32(n1, b127), 23)));
-  ys = _mm256_mul_ps(ys, _mm256_castsi256_ps(_mm256_slli_epi32(_mm256_add_epi32(n2, b127), 23)));
+  __m256 ys = _mm256_castsi256_ps(_mm256_add_epi32(_mm256_castps_si256(y), _mm256_slli_epi32(n, 23)));
   const __m256 isnan = _mm256_cmp_ps(x, x, _CMP_UNORD_Q);
-  const __m256 big = _mm256_cmp_ps(x, _mm256_set1_ps(88.72283f), _CMP_GT_OQ);
-  const __m256 small = _mm256_cmp_ps(x, _mm256_set1_ps(-87.33654f), _CMP_LT_OQ);
+  const __m256 big = _mm256_cmp_ps(fn, _mm256_set1_ps(127.0f), _CMP_GT_OQ);
+  const __m256 small = _mm256_cmp_ps(fn, _mm256_set1_ps(-125.0f), _CMP_LT_OQ);
   ys = _mm256_blendv_ps(ys, y, isnan); /* NaN: unscaled, like the scalar early return */
   ys = _mm256_blendv_ps(ys, _mm256_setzero_ps(), small);
   ys = _mm256_blendv_ps(ys, _mm256_set1_ps(INFINITY), big);
   return ys;
 }
 
-__attribute__((target("avx2,fma"))) static void sweep_avx2(int d, int N, const float *musigall,
-                                                            const float *winvall, const float *qt,
-                                                            const float *x, float qm0, float *qs_out,
-                                                            float *qm_out)
+__attribute__((target("avx2,fma"))) static void sweep_avx2(int d, int N, const float *qpar, const float *qt,
+                                                            const float *x, float *qs_out, float *qm_out)
 {
-  float qs = FPEPS, qm = qm0;
   const __m256 mhalf = _mm256_set1_ps(-0.5f);
+  if (!qs_out) { /* min_i arg_i: exact in any order */
+    __m256 vmin = _mm256_set1_ps(INFINITY);
+    int qi = 0;
+    for (; qi + 8 <= N; qi += 8) {
+      const float *q = qt + (size_t)(qi >> 3) * d * 16;
+      __m256 arg = _mm256_setzero_ps();
+      for (int k = 0; k < d; ++k) {
+        const __m256 t = _mm256_fnmadd_ps(_mm256_set1_ps(x[k]), _mm256_loadu_ps(q + 16 * k + 8), _mm256_loadu_ps(q + 16 * k));
+        arg = _mm256_fmadd_ps(t, t, arg);
+      }
+      vmin = _mm256_min_ps(arg, vmin); /* a NaN arg leaves vmin as it is, like `a < amin ? a : amin` */
+    }
+    float lanes[8], amin = INFINITY;
+    _mm256_storeu_ps(lanes, vmin);
+    for (int l = 0; l < 8; ++l) amin = lanes[l] < amin ? lanes[l] : amin;
+    for (; qi < N; ++qi) {
+      float a = qarg(d, qpar + 2 * (size_t)qi * d, x);
+      amin = a < amin ? a : amin;
+    }
+    *qm_out = mcxo_expf(-0.5f * amin);
+    return;
+  }
+  float qs = FPEPS, qm = FPEPS;
   for (int b0 = 0; b0 < N; b0 += QBLOCK) {
     float part = 0.0f;
     const int b1 = b0 + QBLOCK < N ? b0 + QBLOCK : N;
@@ -511,8 +538,8 @@ __attribute__((target("avx2,fma"))) static void sweep_avx2(int d, int N, const f
       const float *q = qt + (size_t)(qi >> 3) * d * 16;
       __m256 arg = _mm256_setzero_ps();
       for (int k = 0; k < d; ++k) {
-        const __m256 xm = _mm256_sub_ps(_mm256_loadu_ps(q + 16 * k), _mm256_set1_ps(x[k]));
-        arg = _mm256_fmadd_ps(_mm256_mul_ps(xm, xm), _mm256_loadu_ps(q + 16 * k + 8), arg);
+        const __m256 t = _mm256_fnmadd_ps(_mm256_set1_ps(x[k]), _mm256_loadu_ps(q + 16 * k + 8), _mm256_loadu_ps(q + 16 * k));
+        arg = _mm256_fmadd_ps(t, t, arg);
       }
       float gv[8];
       _mm256_storeu_ps(gv, expf8(_mm256_mul_ps(mhalf, arg)));
@@ -522,13 +549,13 @@ __attribute__((target("avx2,fma"))) static void sweep_avx2(int d, int N, const f
       }
     }
     for (; qi < b1; ++qi) {
-      float gv = mcxo_expf(-0.5f * qarg(d, musigall + 2 * (size_t)qi * d, winvall + (size_t)qi * d, x));
+      float gv = mcxo_expf(-0.5f * qarg(d, qpar + 2 * (size_t)qi * d, x));
       part = part + gv;
       qm = gv > qm ? gv : qm;
     }
     qs = qs + part;
   }
-  if (qs_out) *qs_out = qs;
+  *qs_out = qs;
   *qm_out = qm;
 }
 #endif
@@ -554,7 +581,12 @@ int mcxo_gen_remote(mcxo_engine *e, uint32_t t, const float *pvals, const float 
                     float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
 {
   const int d = e->nparam, n = e->nchain, N = e->tchains, nb = (d + 3) / 4;
-  for (size_t i = 0; i < (size_t)N * d; ++i) e->winvall[i] = 1.0f / musigall[2 * i + 1];
+  float *qpar = e->winvall; /* (m', s) pairs: s = sqrt(1/sig2), m' = mu s */
+  for (size_t i = 0; i < (size_t)N * d; ++i) {
+    const float sq = sqrtf(1.0f / musigall[2 * i + 1]);
+    qpar[2 * i] = musigall[2 * i] * sq;
+    qpar[2 * i + 1] = sq;
+  }
   const int vec = use_avx2();
   float *qt = NULL;
 #ifdef MCXO_HAVE_AVX2
@@ -564,22 +596,22 @@ int mcxo_gen_remote(mcxo_engine *e, uint32_t t, const float *pvals, const float 
     for (int b = 0; b < N / 8; ++b)
       for (int k = 0; k < d; ++k)
         for (int l = 0; l < 8; ++l) {
-          qt[((size_t)b * d + k) * 16 + l] = musigall[2 * ((size_t)(8 * b + l) * d + k)];
-          qt[((size_t)b * d + k) * 16 + 8 + l] = e->winvall[(size_t)(8 * b + l) * d + k];
+          qt[((size_t)b * d + k) * 16 + l] = qpar[2 * ((size_t)(8 * b + l) * d + k)];
+          qt[((size_t)b * d + k) * 16 + 8 + l] = qpar[2 * ((size_t)(8 * b + l) * d + k) + 1];
         }
   }
-#define SWEEP(x, qm0, qs, qm)                                                          \
-  do {                                                                                 \
-    if (qt) sweep_avx2(d, N, musigall, e->winvall, qt, (x), (qm0), (qs), (qm));        \
-    else sweep_scalar(d, N, musigall, e->winvall, (x), (qm0), (qs), (qm));             \
+#define SWEEP(x, qs, qm)                                       \
+  do {                                                         \
+    if (qt) sweep_avx2(d, N, qpar, qt, (x), (qs), (qm));       \
+    else sweep_scalar(d, N, qpar, (x), (qs), (qm));            \
   } while (0)
 #else
   (void)vec;
-#define SWEEP(x, qm0, qs, qm) sweep_scalar(d, N, musigall, e->winvall, (x), (qm0), (qs), (qm))
+#define SWEEP(x, qs, qm) sweep_scalar(d, N, qpar, (x), (qs), (qm))
 #endif
   /* numerator of cfac, max_i Q_i(pvals): independent of the pass (src/mcpar.cc:421-437) */
 #pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
-  for (int j = 0; j < n; ++j) SWEEP(pvals + (size_t)j * d, 0.0f, NULL, &e->cmax[j]);
+  for (int j = 0; j < n; ++j) SWEEP(pvals + (size_t)j * d, NULL, &e->cmax[j]);
   for (int j = 0; j < n; ++j) e->rjct[j] = 1; /* :329-331 */
   int anyrjct, pass = 0;
   do {
@@ -601,7 +633,7 @@ int mcxo_gen_remote(mcxo_engine *e, uint32_t t, const float *pvals, const float 
       }
       /* :355-395, qisum / qimax seeded with FPEPS */
       float qs, qm;
-      SWEEP(ptrial + (size_t)j * d, FPEPS, &qs, &qm);
+      SWEEP(ptrial + (size_t)j * d, &qs, &qm);
       e->qisum[j] = qs; e->qimax[j] = qm;
       e->pacpt[j] = qm / qs;        /* :397-398 */
       e->acpt[j] = mcxo_u24(w[1]);  /* :401 */
@@ -629,7 +661,9 @@ static void ensure_rows(mcxo_engine *e, size_t add)
 }
 
 /* accept / reject (src/mcpar.cc:62-75, 162-175); returns number accepted */
-static uint64_t accept_all(mcxo_engine *e, uint32_t t, size_t maskrow)
+/* Local steps (cfac = 1) test the same inequality in the log domain, log u < ly' - ly, so that the only
+ * transcendental of the test depends on the random draw alone; Murray steps keep u < exp(ly' - ly) cfac. */
+static uint64_t accept_all(mcxo_engine *e, uint32_t t, size_t maskrow, int remotep)
 {
   const int d = e->nparam, n = e->nchain;
   uint64_t nacc = 0;
@@ -637,9 +671,14 @@ static uint64_t accept_all(mcxo_engine *e, uint32_t t, size_t maskrow)
   for (int j = 0; j < n; ++j) {
     uint32_t ctr[4] = {t >> 2, gchain(e, j), 0, 0}, key[2] = {e->seed, ST_ACCEPT}, w[4];
     mcxo_philox4x32_10(ctr, key, w);
-    e->acpt[j] = mcxo_u24(w[t & 3u]);
-    e->pacpt[j] = mcxo_expf(e->lytrial[j] - e->lylast[j]) * e->cfac[j];
-    int take = e->acpt[j] < e->pacpt[j];
+    int take;
+    if (remotep) {
+      e->acpt[j] = mcxo_u24(w[t & 3u]);
+      e->pacpt[j] = mcxo_expf(e->lytrial[j] - e->lylast[j]) * e->cfac[j];
+      take = e->acpt[j] < e->pacpt[j];
+    } else {
+      take = mcxo_accept_lu(w[t & 3u]) < e->lytrial[j] - e->lylast[j];
+    }
     e->take[j] = (uint8_t)take;
     if (take) {
       e->lylast[j] = e->lytrial[j];
@@ -676,7 +715,7 @@ static void burn_step(mcxo_engine *e, int isamp)
   mcxo_gen_local(e, t, e->pvals, e->ptrial, e->cfac);
   mcxo_vlfunc_eval(e->L, e->nchain, e->ptrial, e->lytrial);
   e->tun_ntrial += (uint64_t)e->nchain;
-  uint64_t na = accept_all(e, t, (size_t)isamp);
+  uint64_t na = accept_all(e, t, (size_t)isamp, 0);
   e->tun_naccept += na; e->nacc_burn += na;
   if (isamp > e->irate) { /* :78 */
     float arate = (float)e->tun_naccept / (float)e->tun_ntrial;
@@ -723,7 +762,7 @@ static void main_step(mcxo_engine *e, int isamp)
     e->nremote_steps += 1; e->nremote_passes += (uint64_t)npass;
   }
   mcxo_vlfunc_eval(e->L, n, e->ptrial, e->lytrial); /* :160 */
-  e->nacc_main += accept_all(e, t, (size_t)e->nburn + (size_t)isamp);
+  e->nacc_main += accept_all(e, t, (size_t)e->nburn + (size_t)isamp, remotep);
   /* :177-182 (the discarded single-set L call at :180 has no effect and is not made) */
   if (e->keep_samples) {
     float *row = e->samples + e->nrows * (size_t)(d + 1);

@@ -6,7 +6,7 @@
  * :454-484 covar_setup; src/rosenbrock.cc likelihoods), with the MKL VSL RNG
  * replaced by the counter-based Philox4x32-10 streams that the north star asks
  * for, and every transcendental replaced by a fixed fp32 polynomial so that a
- * CPU run and a gfx950 run are bit-identical ("MCX arithmetic v1").
+ * CPU run and a gfx950 run are bit-identical ("MCX arithmetic v2").
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product (libmcx.so) never links or calls it.
@@ -54,6 +54,7 @@ typedef struct {
 void mcxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 float mcxo_logf(float x);
 float mcxo_expf(float x);
+float mcxo_accept_lu(uint32_t w); /* log of the acceptance draw, -inf at 0 */
 void mcxo_sincos2pi(uint32_t w, float *s, float *c);
 float mcxo_u24(uint32_t w);
 float mcxo_uopen(uint32_t w);

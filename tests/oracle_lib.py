@@ -46,6 +46,8 @@ def lib():
     L.mcxo_logf.argtypes = [C.c_float]
     L.mcxo_expf.restype = C.c_float
     L.mcxo_expf.argtypes = [C.c_float]
+    L.mcxo_accept_lu.restype = C.c_float
+    L.mcxo_accept_lu.argtypes = [C.c_uint32]
     L.mcxo_sincos2pi.argtypes = [C.c_uint32, fp, fp]
     L.mcxo_u24.restype = C.c_float
     L.mcxo_u24.argtypes = [C.c_uint32]

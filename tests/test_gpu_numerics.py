@@ -35,7 +35,10 @@ def test_log_exp_sincos_uniform_bits():
     assert np.array_equal(M.debug_numerics(0, xs.view(np.uint32)), exp.view(np.uint32))
     # expf incl. clamps, +-0, NaN, inf
     xe = np.concatenate([rng.uniform(-100, 95, 20000), [0.0, -0.0, 88.72283, 88.7229, -87.33654, -87.3366,
-                                                        np.inf, -np.inf, np.nan, 1e-30, -1e-30]]).astype(np.float32)
+                                                        np.inf, -np.inf, np.nan, 1e-30, -1e-30, 1e30, -1e30, 3e38],
+                         # both sides of every clamp: n = -126/-125 and n = 127/128 (n = floor(x log2 e + 1/2))
+                         np.float32(-125.5 * np.log(2.0)) + np.arange(-40, 41) * np.float32(2.0 ** -17),
+                         np.float32(127.5 * np.log(2.0)) + np.arange(-40, 41) * np.float32(2.0 ** -17)]).astype(np.float32)
     exp = np.array([L.mcxo_expf(float(x)) for x in xe], np.float32)
     got = M.debug_numerics(1, xe.view(np.uint32)).view(np.float32)
     assert np.array_equal(np.isnan(got), np.isnan(exp))
@@ -54,6 +57,12 @@ def test_log_exp_sincos_uniform_bits():
     assert np.array_equal(M.debug_numerics(2, ww), np.array(es, np.float32).view(np.uint32))
     assert np.array_equal(M.debug_numerics(3, ww), np.array(ec, np.float32).view(np.uint32))
     assert np.array_equal(M.debug_numerics(4, ww), np.array([L.mcxo_u24(int(x)) for x in ww], np.float32).view(np.uint32))
+    # log of the acceptance draw (local steps test log u < ly' - ly): -inf at u = 0, scalar and packed forms
+    wa = np.concatenate([ww, np.array([0x00, 0xff, 0x100, 0x1ff, 0x200, 0xffffff00], np.uint32)])
+    elu = np.array([L.mcxo_accept_lu(int(x)) for x in wa], np.float32)
+    assert elu[-6] == -np.inf and elu[-5] == -np.inf and np.isfinite(elu[-4])
+    assert np.array_equal(M.debug_numerics(14, wa), elu.view(np.uint32))
+    assert np.array_equal(M.debug_numerics(15, wa), elu.view(np.uint32))
 
 
 def test_normals_bit_exact_all_streams():

@@ -27,6 +27,11 @@ def test_log_exp_sincos_accuracy():
         assert abs(L.mcxo_expf(float(x)) - ref) <= 3e-7 * ref
     assert L.mcxo_expf(0.0) == 1.0
     assert L.mcxo_expf(-100.0) == 0.0 and L.mcxo_expf(89.0) == float("inf")
+    # results are normal floats or exactly 0: n = floor(x log2(e) + 1/2) < -125 flushes
+    tiny = [L.mcxo_expf(float(x)) for x in np.linspace(-90, -86, 4001).astype(np.float32)]
+    assert all(v == 0.0 or v >= 2.0 ** -126 for v in tiny) and tiny[0] == 0.0 and tiny[-1] > 0.0
+    assert L.mcxo_accept_lu(0) == float("-inf") and L.mcxo_accept_lu(255) == float("-inf")
+    assert abs(L.mcxo_accept_lu(0x80000000) - np.log(0.5)) < 1e-7 and L.mcxo_accept_lu(0xffffffff) < 0.0
     assert np.isnan(L.mcxo_expf(float("nan")))
     s, c = C.c_float(), C.c_float()
     for w in rng.integers(0, 2 ** 32, 4000, dtype=np.uint64):
