@@ -9,11 +9,11 @@ HIPFLAGS  = -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-f
 all: lib oracle
 
 lib:
-	$(MAKE) -j5 mcpar_amd/libmcx.so
+	$(MAKE) -j6 mcpar_amd/libmcx.so
 
 OBJS = $(CSRC)/mcx_engine.o $(CSRC)/mcx_k_fast.o $(CSRC)/mcx_k_pregen.o $(CSRC)/mcx_k_generic_burn.o \
-       $(CSRC)/mcx_k_generic_main.o
-HDRS = $(CSRC)/mcx_device.hpp $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_launch.hpp include/mcx.h
+       $(CSRC)/mcx_k_generic_main.o $(CSRC)/mcx_k_persist.o
+HDRS = $(CSRC)/mcx_device.hpp $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_launch.hpp $(CSRC)/mcx_persist.hpp include/mcx.h
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<

@@ -409,17 +409,34 @@ def main():
     roofline = murray = cpu = end_to_end = None
     others = {}
     if rank == 0:
-        fm, fb = prof["fused_main"], prof["fused_burn"]
+        fm, fb, rs = prof["fused_main"], prof["fused_burn"], prof["run_small"]
         split = prof["gen_normals"]["launches"] > 0
         lpc = lpc_for(d)
         likname = {1: "LIK_ROSEN1", 5: "LIK_MIX"}[cfg["lik"]]
-        kname = "k_fused_fast<%d, true, %d, %s>" % (lpc, cfg["lik"], "true" if split else "false")
-        if fm["launches"] > 0 and fm["ms"] > 0:
+        if rs["launches"] > 0 and rs["ms"] > 0:
+            # small-n mode: burn-in and main-loop steps run in ONE launch of k_run_small (mcx_persist.hpp)
+            kmatch = "k_run_small<%d, %d" % (lpc, cfg["lik"])
+            t_launch = rs["ms"] * 1e-3 / rs["launches"]
+            abytes = float(n) * (nburn * alg_bytes_per_chain_step(d, False, False) + nsamp * alg_bytes_per_chain_step(d, True, emit))
+            frac_local = rs["chain_steps"] / float(n * (nburn + nsamp))  # launches cover this share of the job's local steps
+            alg = abytes * frac_local / (rs["ms"] * 1e-3)
+            roofline = dict(
+                bound="valu", kernel=kmatch + ", ...> (%s; small-n mode: owner / recorder / generator wavefronts, one launch)" % likname,
+                kernel_match=kmatch, avg_launch_ms=t_launch * 1e3, launches=rs["launches"],
+                chain_steps_per_launch=rs["chain_steps"] / rs["launches"],
+                timing="HIP events on the engine's stream around each launch, this run (MCX_OPT_PROFILE)",
+                hbm_alg=dict(achieved=alg / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=alg / HBM_PEAK,
+                             formula="SURVEY §8d bytes (burn-in 8d+8, main 24d+8 + sample row 4(d+1) per chain-step) / launch duration / 8 TB/s",
+                             note="NOT a fraction of a physical bound (state stays in registers, random numbers in LDS); "
+                                  "hbm_measured is what the memory system sees"))
+        elif fm["launches"] > 0 and fm["ms"] > 0:
+            kname = "k_fused_fast<%d, true, %d, %s>" % (lpc, cfg["lik"], "true" if split else "false")
             bpc = alg_bytes_per_chain_step(d, True, emit)
             t_launch = fm["ms"] * 1e-3 / fm["launches"]
             alg = fm["chain_steps"] * bpc / (fm["ms"] * 1e-3)
             roofline = dict(
                 bound="valu", kernel=kname + " (%s%s)" % (likname, ", small-n mode: includes k_gen_normals" if split else ""),
+                kernel_match="k_fused_fast<%d, true" % lpc,
                 avg_launch_ms=t_launch * 1e3, launches=fm["launches"], chain_steps_per_launch=fm["chain_steps"] / fm["launches"],
                 timing="HIP events on the engine's stream around each launch, this run (MCX_OPT_PROFILE)",
                 hbm_alg=dict(achieved=alg / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=alg / HBM_PEAK,
@@ -501,7 +518,7 @@ def main():
             note = "--no-pmc"
             if not args.no_pmc:
                 pmc, pdur, note = collect_pmc(args.config, n, keep_dir=args.keep_pmc or None)
-            kk = find_kernel(pmc, "k_fused_fast<%d, true" % lpc_for(d))
+            kk = find_kernel(pmc, roofline["kernel_match"])
             t_launch = roofline["avg_launch_ms"] * 1e-3
             if kk and all(c in pmc[kk] for c in ("FETCH_SIZE", "WRITE_SIZE")):
                 traffic = (2.0 * pmc[kk]["FETCH_SIZE"] + pmc[kk]["WRITE_SIZE"]) * 1024.0
@@ -512,7 +529,7 @@ def main():
                     frac=traffic / t_launch / HBM_PEAK, source=src,
                     formula="bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (FETCH_SIZE doubled: gfx950 correction for 16-B/lane "
                             "streaming reads, MI355X_MICROARCH.md HBM section); frac = bytes / avg launch duration (HIP events) / 8 TB/s",
-                    unavoidable_bytes=fm_unavoidable(d, n, roofline["chain_steps_per_launch"], emit))
+                    unavoidable_bytes=fm_unavoidable(d, n, roofline["chain_steps_per_launch"] * (nsamp / float(nburn + nsamp) if "k_run_small" in roofline["kernel_match"] else 1.0), emit))
                 roofline["traffic"] = traffic
             if kk and all(c in pmc[kk] for c in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
                 busy, insts, gui = pmc[kk]["SQ_ACTIVE_INST_VALU"], pmc[kk]["SQ_INSTS_VALU"], pmc[kk]["GRBM_GUI_ACTIVE"]
@@ -520,6 +537,8 @@ def main():
                 dur_ns = (pdur.get(kk) or {}).get("GRBM_GUI_ACTIVE")
                 waves = (n * lpc_for(d) + 63) // 64
                 steps_per_launch = roofline["chain_steps_per_launch"] / n
+                if "k_run_small" in roofline["kernel_match"]:
+                    waves = 16 * min(waves, 256)  # every wavefront of the grid: owners, recorders, generators
                 roofline.update(
                     achieved=4.0 * busy / cyc, peak=float(N_SIMD), unit="VALU-busy SIMDs (of 1024)", frac=4.0 * busy / (N_SIMD * cyc),
                     valu=dict(SQ_ACTIVE_INST_VALU=busy, SQ_INSTS_VALU=insts, GRBM_GUI_ACTIVE=gui,

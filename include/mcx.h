@@ -152,6 +152,11 @@ enum {
   MCX_OPT_SPLIT_RNG = 9,   /* small-n mode: random numbers of 32-256 steps at a time from a separate, fully parallel
                               kernel, streamed into the step kernel (same bits).  -1 auto [default: when the
                               chains fill fewer than 640 wavefronts], 0 off, 1 on */
+  MCX_OPT_PERSIST = 10,    /* small-n mode, one launch per stretch of local steps: the burn-in with its tuner, the start of
+                              the main loop and the local main-loop steps run in ONE kernel whose owner wavefronts keep
+                              the chains while the other wavefronts of each CU generate their random numbers into LDS
+                              (same bits).  -1 auto [default: when the chains fill at most 4 wavefronts per CU and
+                              SPLIT_RNG is not 0], 0 off, 1 on */
   MCX_OPT_EAGER_EXCHANGE = 7 /* 0 [default]: gather the latest sync-point snapshot only when a Murray step (or
                               the end of the run) will read it -- bit-identical to 1: gather at every sync
                               point like the reference (src/mcpar.cc:127-140), overlapped with compute */
@@ -218,6 +223,7 @@ enum { MCX_K_FUSED_BURN = 0, MCX_K_FUSED_MAIN, MCX_K_PROPOSE, MCX_K_EVAL, MCX_K_
        MCX_K_TUNER, MCX_K_MISC,
        MCX_K_REMOTE_SWEEP, /* the all-pairs sweep kernels alone (inside MCX_K_REMOTE); chain_steps = pairs */
        MCX_K_GEN_NORMALS,  /* small-n mode: the random-number generator kernel (inside MCX_K_FUSED_*) */
+       MCX_K_RUN_SMALL,    /* small-n mode: k_run_small, burn-in and main-loop steps of one launch together */
        MCX_K_COUNT = 12 };
 typedef struct mcx_profile {
   double ms[MCX_K_COUNT];

@@ -28,7 +28,7 @@ class Counters(C.Structure):
 
 
 K_NAMES = ("fused_burn", "fused_main", "propose", "eval", "accept", "remote", "tuner", "misc", "remote_sweep",
-           "gen_normals", "reserved10", "reserved11")
+           "gen_normals", "run_small", "reserved11")
 
 
 class PlanItem(C.Structure):

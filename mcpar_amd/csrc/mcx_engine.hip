@@ -6,6 +6,7 @@
 #include "../../include/mcx.h"
 #include "mcx_device.hpp"
 #include "mcx_launch.hpp"
+#include "mcx_persist.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: librccl.so.1 is loaded at run time (mcx_rccl_*), never linked
@@ -359,6 +360,8 @@ struct mcx_engine {
   bool own_stream = false;
   int opt_stride = 1;
   int opt_split = -1;  // small-n mode: -1 auto, 0 off, 1 on (when the hot-path kernel applies)
+  int opt_persist = -1;  // small-n mode, one launch per stretch of local steps (k_run_small): -1 auto, 0 off, 1 on
+  int ncu = 0;           // compute units of the device (the persistent grid must be resident at once)
   int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0;
   int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
   bool have_run = false, diag = true, xchg_pending = false;
@@ -486,6 +489,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   MCXCHK(need_device());
   mcx_engine *e = new mcx_engine();
   if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
+  if (hipDeviceGetAttribute(&e->ncu, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) e->ncu = 0;
   e->nparam = np; e->nchain = nc; e->ntot = np * nc; e->ncov = np * np;
   e->size = nshards; e->rank = shard; e->tchains = nshards * nc;
   e->PLOCAL = pl; e->TGT_ARATE_MIN = armin; e->TGT_ARATE_MAX = armax;
@@ -499,7 +503,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   A(e->psum2.alloc(nt)); A(e->mutrial.alloc(nt)); A(e->sigtrial.alloc(nt));
   A(e->musigall.alloc(2 * (size_t)e->tchains * np)); A(e->winvall.alloc(2 * (size_t)e->tchains * np));
   A(e->lylast.alloc(n)); A(e->lytrial.alloc(n)); A(e->cfac.alloc(n)); A(e->cmax.alloc(n));
-  A(e->cov.alloc((size_t)e->ncov)); A(e->trace.alloc(256)); A(e->acc_cnt.alloc(n)); A(e->ctr.alloc(8));
+  A(e->cov.alloc((size_t)e->ncov)); A(e->trace.alloc(256)); A(e->acc_cnt.alloc(n)); A(e->ctr.alloc(8 + PEVENTS));
   e->nslots = (int)(((size_t)nc * e->lpc + 63) / 64);
   A(e->acc_slots.alloc((size_t)e->nslots));
   A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(1)); A(e->ntrace.alloc(1));
@@ -577,6 +581,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
   case MCX_OPT_PROFILE: e->opt_profile = value ? 1 : 0; break;
   case MCX_OPT_EAGER_EXCHANGE: e->opt_eager = value ? 1 : 0; break;
   case MCX_OPT_SPLIT_RNG: e->opt_split = value < 0 ? -1 : (value ? 1 : 0); break;
+  case MCX_OPT_PERSIST: e->opt_persist = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_STREAM:
     if (e->own_stream && e->stream) {
       (void)hipStreamSynchronize(e->stream);
@@ -1115,7 +1120,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   }
   e->cnt = mcx_counters{};
   e->published_steps = 0;
-  HIPCHK(hipMemsetAsync(e->ctr.p, 0, 8 * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(e->ctr.p, 0, (8 + PEVENTS) * sizeof(unsigned long long), st));
   HIPCHK(hipMemsetAsync(e->acc_slots.p, 0, (size_t)e->nslots * sizeof(uint32_t), st));
   HIPCHK(hipMemsetAsync(e->ntrace.p, 0, sizeof(int), st));
   HIPCHK(hipMemsetAsync(e->acc_cnt.p, 0, (size_t)n * sizeof(uint32_t), st));
@@ -1140,8 +1145,75 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   const PlanCfg cfg = {nsamp, nburn, e->SYNCSTEP, e->PLOCAL, e->seed, e->tbase, e->size > 1, e->opt_eager != 0,
                        fused, e->ofn != nullptr, e->opt_maxseg};
   const std::vector<mcx_plan_item> plan = build_plan(cfg);
-  for (const mcx_plan_item &it : plan) {
+  // Small-n mode, one launch per stretch of local steps (mcx_persist.hpp): the whole burn-in with its tuner
+  // events, the start of the main loop and every run of consecutive local main-loop segments go to k_run_small
+  // when the chains fill at most POWN_MAX wavefronts per CU and the hot-path kernel applies.
+  const int nown = (int)(((size_t)n * e->lpc + 63) / 64);
+  const bool fast_lik = e->lik.kind == LIK_ROSEN1 || e->lik.kind == LIK_GAUSS || (e->lik.kind == LIK_MIX && e->lik.ncomp <= 8);
+  const bool persist = fused && e->lpc <= 8 && fast_lik && e->diag && e->vec4 && !e->opt_mask && e->ncu > 0 &&
+                       nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
+                       mcxk_persist_lds_bytes(e->lpc, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
+                       (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0));
+  bool sig_done = false, slots_used = false;
+  for (size_t pi = 0; pi < plan.size(); ++pi) {
+    const mcx_plan_item &it = plan[pi];
+    if (persist && (it.kind == MCX_PLAN_BURN_SEGMENT || it.kind == MCX_PLAN_INIT_MOMENTS || it.kind == MCX_PLAN_MAIN_SEGMENT)) {
+      size_t pj = pi;
+      int pb = 0, pm = 0, init = 0, is0 = 0, snap = -1;
+      while (pj < plan.size() && (plan[pj].kind == MCX_PLAN_BURN_SEGMENT || plan[pj].kind == MCX_PLAN_TUNER)) {
+        if (plan[pj].kind == MCX_PLAN_BURN_SEGMENT) pb += plan[pj].nsteps;
+        ++pj;
+      }
+      if (pj + 1 < plan.size() && plan[pj].kind == MCX_PLAN_INIT_MOMENTS && plan[pj + 1].kind == MCX_PLAN_MAIN_SEGMENT) {
+        init = 1;
+        ++pj;
+      }
+      if (pj < plan.size() && plan[pj].kind == MCX_PLAN_MAIN_SEGMENT) {
+        is0 = plan[pj].first;
+        while (pj < plan.size() && plan[pj].kind == MCX_PLAN_MAIN_SEGMENT && plan[pj].first == is0 + pm) {
+          if (plan[pj].aux >= 0) snap = pm + plan[pj].aux;  // the last sync point inside the stretch
+          pm += plan[pj].nsteps;
+          ++pj;
+        }
+      }
+      if (pb + pm > 0) {
+        RunArgs ra;
+        ra.x = e->pvals.p; ra.ly = e->lylast.p; ra.mu = e->mu.p; ra.psum2 = e->psum2.p; ra.sig = e->sig.p;
+        ra.acc_cnt = e->acc_cnt.p; ra.T = e->cov.p;
+        ra.samp_x = e->opt_samples ? e->samp_x.p : nullptr; ra.samp_ly = e->opt_samples ? e->samp_ly.p : nullptr;
+        ra.samp_stride = e->opt_stride;
+        MCXCHK(e->trash.alloc(4 * (size_t)PBLOCK * (size_t)std::max(e->ncu, 1)));
+        ra.trash = e->trash.p;
+        ra.lik = e->lik.params.p; ra.ncomp = e->lik.ncomp; ra.n = n; ra.d = d; ra.g0 = g0; ra.seed = e->seed;
+        ra.t0 = pb > 0 ? e->tbase : e->tbase + (uint32_t)nburn + (uint32_t)is0;
+        ra.nburn = pb; ra.nmain = pm; ra.isamp0 = is0; ra.init_moments = init;
+        ra.winv = e->winv_tab.p; ra.musig_own = sa.musig_own; ra.snap_after = snap;
+        ra.final_publish = (e->size == 1 && pm > 0 && is0 + pm == nsamp) ? 1 : 0;
+        ra.armin = e->TGT_ARATE_MIN; ra.armax = e->TGT_ARATE_MAX; ra.dfac = e->SCALE_DEC; ra.ifac = e->SCALE_INC;
+        ra.ctr = e->ctr.p; ra.bar = e->ctr.p + 8; ra.trace = e->trace.p; ra.ntrace = e->ntrace.p;
+        ra.nown = nown;
+        ra.dbg = getenv("MCX_PERSIST_DEBUG") ? atoi(getenv("MCX_PERSIST_DEBUG")) : 0;
+        const int nwg = std::min(nown, e->ncu);
+        ra.own = (nown + nwg - 1) / nwg;
+        if (snap >= 0) {  // the kernel rewrites this shard's slot: no gather may still be reading it
+          MCXCHK(exchange_wait(e));
+          e->published_steps = is0 + snap + 1;
+        }
+        if (ra.final_publish) {
+          MCXCHK(exchange_wait(e));
+          e->published_steps = nsamp;
+          sig_done = true;
+        }
+        {
+          ProfScope ps(e, MCX_K_RUN_SMALL, (uint64_t)(pb + pm) * n);
+          HIPCHK(mcxk_launch_persist(e->lpc, e->lik.kind, ra, st));
+        }
+        pi = pj - 1;
+        continue;
+      }
+    }
     const int isamp = it.first, steps = it.nsteps;
+    if (it.kind == MCX_PLAN_BURN_SEGMENT || it.kind == MCX_PLAN_MAIN_SEGMENT || it.kind == MCX_PLAN_REMOTE_STEP) slots_used = true;
     switch (it.kind) {
     case MCX_PLAN_BURN_SEGMENT: {  // src/mcpar.cc:58-75
       const uint32_t t0 = e->tbase + (uint32_t)isamp;
@@ -1228,13 +1300,15 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   }
   e->cnt.nsteps_burn = (uint64_t)nburn;
   e->cnt.nsteps_main = (uint64_t)nsamp;
-  if (nsamp > 0) {
+  if (nsamp > 0 && !sig_done) {
     hipLaunchKernelGGL(k_variance, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->psum2.p,
                        e->sig.p, (size_t)e->ntot, 1.0f / (float)nsamp);
     HIPCHK(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, e->ctr.p + 4);
-  HIPCHK(hipGetLastError());
+  if (slots_used) {
+    hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, e->ctr.p + 4);
+    HIPCHK(hipGetLastError());
+  }
   unsigned long long hctr[8];
   HIPCHK(hipMemcpyAsync(hctr, e->ctr.p, sizeof hctr, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

@@ -11,3 +11,9 @@ hipError_t mcxk_launch_gen(int lpc, float *Z, float *U, int n, int d, int nsteps
                            uint32_t seed, hipStream_t st);                                             // mcx_k_pregen.hip
 hipError_t mcxk_launch_generic_burn(int lpc, int lik, const mcx::SegArgs &a, hipStream_t st);      // mcx_k_generic_burn.hip
 hipError_t mcxk_launch_generic_main(int lpc, int lik, const mcx::SegArgs &a, hipStream_t st);      // mcx_k_generic_main.hip
+// small-n mode, one launch per stretch of local steps (mcx_persist.hpp); every workgroup must be resident:
+// ceil(a.nown / a.own) <= number of CUs, 1 <= a.own <= POWN_MAX
+namespace mcx { struct RunArgs; }
+hipError_t mcxk_launch_persist(int lpc, int lik, const mcx::RunArgs &a, hipStream_t st);                // mcx_k_persist.hip
+size_t mcxk_persist_lds_bytes(int lpc, int own);
+constexpr size_t MCXK_PERSIST_LDS_LIMIT = (size_t)152 << 10;  // dynamic LDS a launch may ask for (160 KB per CU less the static part)

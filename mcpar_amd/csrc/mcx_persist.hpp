@@ -1,0 +1,495 @@
+// mcx_persist.hpp -- small-n mode, one launch per run: k_run_small<LPC, LIK>.
+//
+// With few chains (fewer wavefronts than SIMDs) a Metropolis step is bound by the latency of ONE wave's
+// instruction stream, and every kernel boundary (tuner checks, chunk changes) costs more than the steps it
+// separates.  This kernel runs a whole stretch of the schedule -- burn-in with the acceptance-rate tuner
+// (src/mcpar.cc:55-97), the start of the main loop (:99-104) and the local main-loop steps (:152-209) -- in one
+// launch of one 1024-thread workgroup per CU:
+//
+//   * OWN (1..4) "owner" wavefronts per workgroup hold the chains (x, ly) in registers, in the lane layout of
+//     k_fused_fast, and do only what the NEXT step depends on: proposal = x + T z, likelihood,
+//     log u < ly' - ly.  A lone wave pays 4-8 cycles per instruction, so the owner's loop is kept to the bare
+//     dependent chain (measured: ~85 instructions and 690 cycles per step with the moments and the sample
+//     emission in it);
+//   * OWN "recorder" wavefronts, one per owner, follow one phase behind: they read the owner's post-step
+//     (x, ly) from LDS and do the Welford moments (src/mcpar.cc:184-209), the exchange snapshot and the sample
+//     emission (:176-182) -- everything that consumes the state without feeding the next step;
+//   * the remaining 16 - 2 OWN "generator" wavefronts (and the recorders when they have nothing to record)
+//     produce the owners' random numbers -- Philox4x32-10 + Box-Muller normals and the logs of the acceptance
+//     draws, two thirds of a step's instructions, none of which depend on the chain state -- K = 16 - 2 OWN
+//     steps at a time into a double buffer in the CU's own LDS (items pulled from an LDS counter; one
+//     s_barrier per K steps).  Nothing random ever touches L2 or HBM, and the SIMDs the owners leave idle
+//     do the bulk of the arithmetic;
+//   * the tuner's decision needs the accept count of ALL chains: at its check steps the workgroups meet at a
+//     counter in global memory (one 64-bit atomic per workgroup: arrivals << 40 | accepts), every owner then
+//     takes the same decision from the same integers and rescales its own copy of the Cholesky diagonal.
+//
+// Same functions, same bits as the per-segment kernels (tests/test_gpu_run_parity.py, test_gpu_fuzz.py).
+// Every workgroup of the grid must be resident at once (grid <= number of CUs, checked by the launcher).
+#pragma once
+#include "mcx_device.hpp"
+
+namespace mcx {
+
+constexpr int PBLOCK = 1024;          // 16 wavefronts: 4 per SIMD of one CU
+constexpr int PWAVES = PBLOCK / 64;
+constexpr int POWN_MAX = 4;
+constexpr int PEVENTS = 64;           // tuner events (steps 51, 101, ... and the end of the burn-in) one launch can hold
+
+struct RunArgs {
+  float *x, *ly, *mu, *psum2, *sig;
+  uint32_t *acc_cnt;
+  float *T;                 // [d][d] Cholesky factor, diagonal here; rescaled in place when the launch ends
+  float *samp_x, *samp_ly;  // sample store of the run (row 0 = main step 0 / kept step 0), or null
+  float *trash;             // 16 B per thread of the grid: where lanes that own no parameters dump their stores
+  int samp_stride;
+  const float *lik;
+  int ncomp;
+  int n, d;
+  uint32_t g0, t0, seed;    // t0 = RNG step index of this launch's first step
+  int nburn;                // burn-in steps of this launch: the whole burn-in (steps 0 .. nburn-1) or none
+  int nmain, isamp0;        // then nmain main-loop steps isamp0 .. isamp0+nmain-1
+  int init_moments;         // the main part opens the main loop: mu = 0, psum2 = FPEPS (src/mcpar.cc:99-104)
+  const float *winv;        // winv[i] = 1/(i+1)
+  float *musig_own;         // this shard's musigall slot
+  int snap_after;           // main step (relative to isamp0) after which the slot is snapshot, or -1
+  int final_publish;        // 1: the launch ends the run of a single shard: slot and sig from the final moments
+  float armin, armax, dfac, ifac;
+  unsigned long long *ctr;  // [1] tuner naccept [2] tuner ntrial [3] burn-in accepts [4] main-loop accepts
+  unsigned long long *bar;  // one word per tuner event of this launch (<= PEVENTS), zero at launch
+  float *trace;
+  int *ntrace;
+  int nown;                 // owner wavefronts in the whole grid = ceil(n * LPC / 64)
+  int own;                  // owner wavefronts per workgroup (1..POWN_MAX)
+  int dbg;                  // timing experiments only (wrong results): 1 owners idle, 2 generators idle
+};
+
+// all owners of the grid meet; returns the sum of `mine` over the workgroups.  One atomic per workgroup:
+// the owner waves of a workgroup first add up in LDS.  word = arrivals << 40 | sum.
+__device__ __forceinline__ unsigned long long owners_meet(unsigned long long *word, unsigned mine, int own, int nwg,
+                                                         unsigned *lds_sum, unsigned *lds_cnt, unsigned long long *lds_out)
+{
+  // (lanes of a wave are in step; only lane 0 talks)
+  unsigned long long total = 0;
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(lds_sum, mine);
+    __threadfence_block();
+    const unsigned arrived = atomicAdd(lds_cnt, 1u) + 1u;
+    if (arrived == (unsigned)own) {  // last owner of this workgroup: speak for it
+      const unsigned s = atomicExch(lds_sum, 0u);
+      atomicExch(lds_cnt, 0u);
+      // the word is the only thing the workgroups share: relaxed device-scope atomics, no cache maintenance
+      // (the returned value is consumed: an atomic whose result is never read would stay "pending" for the
+      // compiler's s_waitcnt bookkeeping and put vmcnt waits -- on the previous step's stores -- into the step loop)
+      const unsigned long long add = (1ull << 40) | (unsigned long long)s;
+      unsigned long long v = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+      while ((int)(v >> 40) < nwg) {
+        __builtin_amdgcn_s_sleep(4);
+        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      total = v & ((1ull << 40) - 1ull);
+      __hip_atomic_store(lds_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      for (;;) {
+        total = __hip_atomic_load(lds_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (total != ~0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  // broadcast lane 0's value to the wave
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)total), hi = __builtin_amdgcn_readfirstlane((unsigned)(total >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int LPC, int LIK, bool REC>
+__global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
+{
+  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX, "hot-path likelihoods only");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ __attribute__((aligned(16))) float lds_means[LIK == LIK_MIX ? 8 * MAXD_LDS : 4];
+  __shared__ float lds_logw[8];
+  __shared__ unsigned lds_sum, lds_cnt;
+  __shared__ unsigned long long lds_out[PEVENTS];  // one result word per tuner event (never reused within a launch)
+  __shared__ float wbuf[4 * PWAVES];  // 1/pwgt of a phase's main-loop steps, by phase % 4 (written 1 ahead, read 1 behind)
+  if (LIK == LIK_MIX) {
+    const int kd = a.ncomp * a.d;
+    for (int i = threadIdx.x; i < kd; i += PBLOCK) lds_means[i] = a.lik[i];
+    if (threadIdx.x < (unsigned)a.ncomp) lds_logw[threadIdx.x] = a.lik[kd + threadIdx.x];
+  }
+  if (threadIdx.x == 0) { lds_sum = 0; lds_cnt = 0; }
+  if (threadIdx.x < PEVENTS) lds_out[threadIdx.x] = ~0ull;
+  const int OWN = a.own, NREC = REC ? OWN : 0, K = PWAVES - OWN - NREC;
+  const int T = a.nburn + a.nmain;
+  const int nphase = (T + K - 1) / K;
+  const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const bool owner = wv < OWN, recorder = REC && !owner && wv < 2 * OWN;
+  // LDS double buffers, by phase parity: zbuf / xbuf [2][K][OWN][64] float4, ubuf / lbuf [2][K][OWN][64/LPC] float
+  constexpr int CPW = 64 / LPC;  // chains per owner wavefront
+  const size_t nz = (size_t)2 * K * OWN * 64, nu = (size_t)2 * K * OWN * CPW;
+  float4 *zbuf = reinterpret_cast<float4 *>(lds_raw);
+  float4 *xbuf = zbuf + nz;  // (REC only)
+  float *ubuf = reinterpret_cast<float *>(zbuf + (REC ? 2 : 1) * nz);
+  float *lbuf = ubuf + nu;   // (REC only)
+  const int d = a.d;
+
+  // ---- generator side -------------------------------------------------------------------------------------
+  // The work of one phase is a list of items dealt round-robin to the `nfill` waves that fill in this
+  // iteration (a counter in LDS was measured slower: ~40 same-address atomics per phase serialise): item
+  // i < ns * OWN = the 64 lanes' normals of owner i % OWN at step i / OWN of the phase; the next OWN items =
+  // the logs of the phase's acceptance draws of one owner; the last item = the 1/pwgt values of the phase's
+  // main-loop steps.
+  auto fill = [&](int phase, int me_fill, int nfill) {
+    const int buf = phase & 1, tau0 = phase * K;
+    const int ns = T - tau0 < K ? T - tau0 : K;  // steps [tau0, tau0 + ns)
+    const int nitems = ns * OWN + OWN + 1;
+    for (int i = me_fill; i < nitems; i += nfill) {
+      if (a.dbg & 2) continue;
+      if (i < ns * OWN) {
+        const int g = i / OWN, o = i - g * OWN;
+        const uint32_t t = a.t0 + (uint32_t)(tau0 + g);
+        const size_t gid = ((size_t)blockIdx.x * OWN + o) * 64 + lane;
+        const size_t chain = gid / LPC;
+        const int q = (int)(gid % LPC);
+        if (chain < (size_t)a.n && 4 * q < d) {
+          f32x2 ze, zo;
+          normal4_packed(philox4x32_10(t, a.g0 + (uint32_t)chain, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
+          zbuf[((size_t)(buf * K + g) * OWN + o) * 64 + lane] = make_float4(ze.x, ze.y, zo.x, zo.y);  // (even pair, odd pair)
+        }
+      } else if (i < ns * OWN + OWN) {  // one Philox block of the ACCEPT stream serves 4 steps
+        const int o = i - ns * OWN;
+        const uint32_t tf = a.t0 + (uint32_t)tau0, tl = tf + (uint32_t)ns - 1u;
+        const uint32_t bf = tf >> 2, bl = tl >> 2;
+        const int c = lane % CPW;
+        const size_t chain = ((size_t)blockIdx.x * OWN + o) * CPW + c;
+        if (chain < (size_t)a.n)
+          for (uint32_t b = bf + (uint32_t)(lane / CPW); b <= bl; b += (uint32_t)LPC) {
+            const u32x4 aw = philox4x32_10(b, a.g0 + (uint32_t)chain, 0u, 0u, a.seed, ST_ACCEPT);
+            const f32x2 l01 = accept_lu_x2(aw.x, aw.y), l23 = accept_lu_x2(aw.z, aw.w);
+            const float l[4] = {l01.x, l01.y, l23.x, l23.y};
+#pragma unroll
+            for (uint32_t wi = 0; wi < 4u; ++wi) {
+              const uint32_t t = (b << 2) + wi;
+              if (t >= tf && t <= tl) ubuf[((size_t)(buf * K + (int)(t - tf)) * OWN + o) * CPW + c] = l[wi];
+            }
+          }
+      } else if (lane < ns) {  // 1/pwgt (src/mcpar.cc:186-187), from the host-built table
+        const int im = tau0 + lane - a.nburn;
+        wbuf[(phase & 3) * PWAVES + lane] = (im >= 0 && im < a.nmain) ? a.winv[a.isamp0 + im] : 1.0f;
+      }
+    }
+  };
+
+  // ---- this wave's chains (the lane layout of k_fused_fast); recorder o + OWN mirrors owner o ---------------
+  const int slot_o = owner ? wv : (recorder ? wv - OWN : 0);
+  const size_t gid = ((size_t)blockIdx.x * OWN + slot_o) * 64 + lane;
+  const size_t chain = gid / LPC;
+  const int q = (int)(gid % LPC);
+  const int k0 = 4 * q;
+  const bool mine = (owner || recorder) && chain < (size_t)a.n;
+  const bool live = mine && k0 < d;
+  const bool working = (owner || recorder) && (int)blockIdx.x * OWN + slot_o < a.nown;
+  const size_t off = chain * (size_t)d + k0;
+  f32x2 xe = {0, 0}, xo = {0, 0}, me = {0, 0}, mo = {0, 0}, se = {0, 0}, so = {0, 0}, te = {0, 0}, to = {0, 0};
+  f32x2 gme = {0, 0}, gmo = {0, 0};
+  float gs0 = 0, gs1 = 0, gs2 = 0, gs3 = 0, ly = __builtin_inff();
+  if (live && owner) {
+    const float4 f = *reinterpret_cast<const float4 *>(a.x + off);
+    xe = f32x2{f.x, f.z}; xo = f32x2{f.y, f.w};
+    te = f32x2{a.T[(k0 + 0) * d + k0 + 0], a.T[(k0 + 2) * d + k0 + 2]};
+    to = f32x2{a.T[(k0 + 1) * d + k0 + 1], a.T[(k0 + 3) * d + k0 + 3]};
+    if (LIK == LIK_GAUSS) {
+      gme = f32x2{a.lik[k0 + 0], a.lik[k0 + 2]}; gmo = f32x2{a.lik[k0 + 1], a.lik[k0 + 3]};
+      gs0 = a.lik[d + k0 + 0]; gs1 = a.lik[d + k0 + 1]; gs2 = a.lik[d + k0 + 2]; gs3 = a.lik[d + k0 + 3];
+    }
+  }
+  if (live && (REC ? recorder : owner) && a.nmain > 0 && !a.init_moments) {
+    const float4 m = *reinterpret_cast<const float4 *>(a.mu + off);
+    const float4 p = *reinterpret_cast<const float4 *>(a.psum2 + off);
+    me = f32x2{m.x, m.z}; mo = f32x2{m.y, m.w};
+    se = f32x2{p.x, p.z}; so = f32x2{p.y, p.w};
+  }
+  // owner lanes that hold no chain never accept: log u < ly' - (+inf) is false for every ly'
+  if (mine && owner) ly = a.ly[chain];
+  // Every load of the chain state is awaited here, once, on every path (the compiler's s_waitcnt bookkeeping
+  // is path-insensitive): inside the step loops the only vector-memory operations are stores, and no
+  // s_waitcnt vmcnt may end up there -- it would wait for the previous step's stores.
+  asm volatile("" ::"v"(xe), "v"(xo), "v"(te), "v"(to), "v"(me), "v"(mo), "v"(se), "v"(so), "v"(gme), "v"(gmo), "v"(gs0),
+               "v"(gs1), "v"(gs2), "v"(gs3), "v"(ly));
+  if (owner) __builtin_amdgcn_s_setprio(3);  // the owners' dependent instruction stream goes first on its SIMD
+  else if (recorder) __builtin_amdgcn_s_setprio(1);
+  uint32_t cnt = 0, wacc = 0;
+  unsigned long long macc = 0;  // accepted main-loop proposals of this wave
+
+  // likelihood of the proposal (pe, po), same arithmetic as k_fused_fast
+  auto loglike = [&](f32x2 pe, f32x2 po) -> float {
+    float acc = 0.0f;
+    if (LIK == LIK_ROSEN1) {
+      const f32x2 t1 = splat2(1.0f) - pe;
+      const f32x2 t2 = fma2(-pe, pe, po);
+      const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
+      if (live) acc = term.x + term.y;
+    } else if (LIK == LIK_GAUSS) {
+      const f32x2 ae = pe - gme, ao = po - gmo;
+      const f32x2 he = (splat2(0.5f) * ae) * ae, ho = (splat2(0.5f) * ao) * ao;
+      if (live) {
+        acc = __builtin_fmaf(he.x, gs0, 0.0f);
+        acc = __builtin_fmaf(ho.x, gs1, acc);
+        acc = __builtin_fmaf(he.y, gs2, acc);
+        acc = __builtin_fmaf(ho.y, gs3, acc);
+      }
+    }
+    if (LIK == LIK_MIX) {
+      const int Kc = a.ncomp;
+      float e[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        e[c] = 0.0f;
+        if (c < Kc) {
+          float s2 = 0.0f;
+          if (live) {
+            const float4 m = *reinterpret_cast<const float4 *>(&lds_means[c * d + k0]);
+            const f32x2 ae = pe - f32x2{m.x, m.z}, ao = po - f32x2{m.y, m.w};
+            s2 = __builtin_fmaf(ae.x, ae.x, 0.0f);
+            s2 = __builtin_fmaf(ao.x, ao.x, s2);
+            s2 = __builtin_fmaf(ae.y, ae.y, s2);
+            s2 = __builtin_fmaf(ao.y, ao.y, s2);
+          }
+          e[c] = __builtin_fmaf(-0.5f, group_sum<LPC>(s2), lds_logw[c]);
+        }
+      }
+      float emax = e[0];
+#pragma unroll
+      for (int c = 1; c < 8; ++c)
+        if (c < Kc) emax = e[c] > emax ? e[c] : emax;
+      float ssum = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; c += 2) {
+        if (c < Kc) {
+          const f32x2 ex = expf_v2x2(f32x2{e[c] - emax, e[c + 1] - emax});
+          ssum = ssum + ex.x;
+          if (c + 1 < Kc) ssum = ssum + ex.y;
+        }
+      }
+      return emax + logf_v1(ssum);
+    }
+    return 0.0f - group_sum<LPC>(acc);
+  };
+
+  // tuner state (src/mcpar.cc:77-96), identical in every owner wave
+  unsigned long long tun_na = a.ctr[1], tun_nt = a.ctr[2], burn_acc = 0;
+  int irate = 50, seg_start = 0, nevent = 0, ntrace_local = 0;
+  const int nwg = (int)gridDim.x;
+  const int own_here = a.nown - (int)blockIdx.x * OWN < OWN ? a.nown - (int)blockIdx.x * OWN : OWN;
+  int next_event = a.nburn > 0 ? (51 < a.nburn ? 51 : a.nburn - 1) : -1;  // burn-in step of the next tuner event
+
+  // recorder: sample store through per-lane pointers that advance by one row per kept step; lanes that own
+  // nothing store to a trash slot with stride 0, so the stores need no exec-mask regions
+  const size_t rowx = (size_t)a.n * d, rowl = (size_t)a.n;
+  const bool emit = a.samp_x != nullptr;
+  const int sstride = a.samp_stride > 1 ? a.samp_stride : 1;
+  float *sxv = nullptr, *slv = nullptr;
+  size_t sxs = 0, sls = 0;
+  int kmod = 0;  // isamp % samp_stride of the next main-loop step
+  if (emit) {
+    kmod = a.isamp0 % sstride;
+    const size_t row0 = (size_t)((a.isamp0 + sstride - 1) / sstride);  // row of the first kept step >= isamp0
+    float *dump = a.trash + 4 * ((size_t)blockIdx.x * PBLOCK + threadIdx.x);
+    const bool rec = REC ? recorder : owner;
+    sxv = (live && rec) ? a.samp_x + row0 * rowx + off : dump;
+    slv = (mine && rec) ? a.samp_ly + row0 * rowl + chain : dump;
+    sxs = (live && rec) ? rowx : 0;
+    sls = (mine && rec) ? rowl : 0;
+  }
+
+  const int NG = PWAVES - OWN - NREC;  // pure generator waves (= K)
+  __syncthreads();
+  if (!owner) fill(0, wv - OWN, PWAVES - OWN);  // (nobody has anything to record yet)
+  __syncthreads();
+  // iteration p: owners run phase p, recorders digest phase p - 1, everybody else fills phase p + 1
+  for (int p = 0; p < nphase + (REC ? 1 : 0); ++p) {
+    const int buf = p & 1;
+    if (owner) {
+      if (working && p < nphase && !(a.dbg & 1)) {
+        const int tau0 = p * K;
+        const int ns = T - tau0 < K ? T - tau0 : K;
+        const int nb = a.nburn - tau0 < 0 ? 0 : (a.nburn - tau0 < ns ? a.nburn - tau0 : ns);  // burn-in steps of this phase
+        const float4 *zp = zbuf + ((size_t)(buf * K) * OWN + wv) * 64 + lane;
+        const float *up = ubuf + ((size_t)(buf * K) * OWN + wv) * CPW + lane / LPC;
+        float4 *xq = xbuf + ((size_t)(buf * K) * OWN + wv) * 64 + lane;
+        float *lq = lbuf + ((size_t)(buf * K) * OWN + wv) * CPW + lane / LPC;
+        float4 zn = *zp;
+        float lun = *up;
+        for (int s = 0; s < ns; ++s) {
+          const float4 z = zn;
+          const float lu = lun;
+          if (s + 1 < ns) {  // the next step's numbers are on their way while this one computes
+            zp += (size_t)OWN * 64;
+            up += (size_t)OWN * CPW;
+            zn = *zp;
+            lun = *up;
+          }
+          // proposal, likelihood, acceptance (src/mcpar.cc:302-312, 62-75)
+          const f32x2 pe = fma2(te, f32x2{z.x, z.y}, xe), po = fma2(to, f32x2{z.z, z.w}, xo);
+          const float lyt = loglike(pe, po);
+          const bool take = accept_local(lyt, ly, lu);
+          xe = take ? pe : xe;
+          xo = take ? po : xo;
+          ly = take ? lyt : ly;
+          cnt += take ? 1u : 0u;
+          const uint32_t wa = (uint32_t)__popcll(__ballot(take && q == 0));
+          if (s >= nb) {
+            macc += wa;
+            if (REC) {  // main-loop step: hand the state to the recorder (every lane of a chain writes the same ly)
+              *xq = make_float4(xe.x, xe.y, xo.x, xo.y);
+              *lq = ly;
+              xq += (size_t)OWN * 64;
+              lq += (size_t)OWN * CPW;
+            } else {  // no recorders (the run is bound by the generators' throughput, not by this wave's latency)
+              if (s == nb && tau0 + s == a.nburn && a.init_moments) {  // src/mcpar.cc:99-104
+                me = mo = splat2(0.0f);
+                se = so = splat2(FPEPS);
+              }
+              const f32x2 w2 = splat2(wbuf[(p & 3) * PWAVES + s]);  // 1/pwgt, src/mcpar.cc:186-187
+              const f32x2 de = xe - me, dO = xo - mo;               // src/mcpar.cc:199-202
+              me = fma2(de, w2, me);
+              mo = fma2(dO, w2, mo);
+              se = fma2(de, xe - me, se);
+              so = fma2(dO, xo - mo, so);
+              if (tau0 + s - a.nburn == a.snap_after && live) {  // snapshot for the next exchange (src/mcpar.cc:202-208)
+                const f32x2 ve = se * w2, vo = so * w2;
+                float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
+                slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
+                slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
+              }
+              if (emit) {  // src/mcpar.cc:177-182
+                if (kmod == 0) {
+                  *reinterpret_cast<float4 *>(sxv) = make_float4(xe.x, xo.x, xe.y, xo.y);
+                  *slv = ly;  // every lane of the chain stores the same value
+                  sxv += sxs;
+                  slv += sls;
+                }
+                kmod = kmod + 1 == sstride ? 0 : kmod + 1;
+              }
+            }
+          } else {
+            wacc += wa;
+            xq += (size_t)OWN * 64;
+            lq += (size_t)OWN * CPW;
+            if (tau0 + s == next_event) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
+              const int last = next_event;
+              const int steps = last - seg_start + 1, check = last > irate ? 1 : 0;
+              const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent]);
+              ++nevent;
+              wacc = 0;
+              tun_na += seg;
+              tun_nt += (unsigned long long)steps * (unsigned long long)a.n;
+              burn_acc += seg;
+              if (check) {
+                const float arate = (float)tun_na / (float)tun_nt;
+                float f = 1.0f;
+                if (arate < a.armin) { tun_na = tun_nt = 0; f = a.dfac; }
+                else if (arate > a.armax) { tun_na = tun_nt = 0; f = a.ifac; }
+                if (f != 1.0f) { te = te * splat2(f); to = to * splat2(f); }
+                if (blockIdx.x == 0 && wv == 0 && lane == 0) {  // lane 0 of the grid holds T[0][0]
+                  const int kk = *a.ntrace + ntrace_local;
+                  if (kk < 256) a.trace[kk] = te.x;
+                }
+                ++ntrace_local;
+                irate += 50;
+              }
+              seg_start = last + 1;
+              next_event = irate + 1 < a.nburn ? irate + 1 : a.nburn - 1;
+            }
+          }
+        }
+      }
+    } else {
+      if (recorder && working && p >= 1 && !(a.dbg & 1)) {  // Welford, snapshot, emit of phase p - 1 (src/mcpar.cc:176-209)
+        const int pb = buf ^ 1, tau0 = (p - 1) * K;
+        const int ns = T - tau0 < K ? T - tau0 : K;
+        const int nb = a.nburn - tau0 < 0 ? 0 : (a.nburn - tau0 < ns ? a.nburn - tau0 : ns);
+        if (nb < ns) {
+          if (tau0 + nb == a.nburn && a.init_moments) {  // src/mcpar.cc:99-104
+            me = mo = splat2(0.0f);
+            se = so = splat2(FPEPS);
+          }
+          const float4 *xq = xbuf + ((size_t)(pb * K + nb) * OWN + slot_o) * 64 + lane;
+          const float *lq = lbuf + ((size_t)(pb * K + nb) * OWN + slot_o) * CPW + lane / LPC;
+          const float *wq = wbuf + ((p - 1) & 3) * PWAVES;
+          for (int s = nb; s < ns; ++s) {
+            const float4 xv = *xq;
+            const float lyv = *lq;
+            const f32x2 w2 = splat2(wq[s]);  // 1/pwgt, src/mcpar.cc:186-187
+            xq += (size_t)OWN * 64;
+            lq += (size_t)OWN * CPW;
+            const f32x2 ce = {xv.x, xv.y}, co = {xv.z, xv.w};
+            const f32x2 de = ce - me, dO = co - mo;  // src/mcpar.cc:199-202
+            me = fma2(de, w2, me);
+            mo = fma2(dO, w2, mo);
+            se = fma2(de, ce - me, se);
+            so = fma2(dO, co - mo, so);
+            if (tau0 + s - a.nburn == a.snap_after && live) {  // snapshot for the next exchange (src/mcpar.cc:202-208)
+              const f32x2 ve = se * w2, vo = so * w2;
+              float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
+              slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
+              slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
+            }
+            if (emit) {  // src/mcpar.cc:177-182
+              if (kmod == 0) {
+                *reinterpret_cast<float4 *>(sxv) = make_float4(ce.x, co.x, ce.y, co.y);
+                *slv = lyv;  // every lane of the chain stores the same value
+                sxv += sxs;
+                slv += sls;
+              }
+              kmod = kmod + 1 == sstride ? 0 : kmod + 1;
+            }
+          }
+        }
+      }
+      // the recorders fill too when the phase they would digest held no main-loop step (the whole burn-in)
+      const bool rec_busy = REC && p >= 1 && (p - 1) * K + K > a.nburn && a.nmain > 0;
+      if (p + 1 < nphase) {
+        if (!recorder) fill(p + 1, wv - OWN - NREC, (rec_busy || !REC) ? NG : NG + OWN);
+        else if (!rec_busy) fill(p + 1, NG + (wv - OWN), NG + OWN);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------
+  if (owner) {
+    if (live) {
+      *reinterpret_cast<float4 *>(a.x + off) = make_float4(xe.x, xo.x, xe.y, xo.y);
+      if (a.nburn > 0 && chain == 0) {  // the rescaled diagonal (off-diagonal entries are zero on this path)
+        a.T[(k0 + 0) * d + k0 + 0] = te.x; a.T[(k0 + 2) * d + k0 + 2] = te.y;
+        a.T[(k0 + 1) * d + k0 + 1] = to.x; a.T[(k0 + 3) * d + k0 + 3] = to.y;
+      }
+    }
+    if (mine && q == 0) {
+      a.ly[chain] = ly;
+      a.acc_cnt[chain] += cnt;
+    }
+    if (lane == 0 && macc) atomicAdd(a.ctr + 4, macc);
+  }
+  if ((REC ? recorder : owner) && live && a.nmain > 0) {
+    *reinterpret_cast<float4 *>(a.mu + off) = make_float4(me.x, mo.x, me.y, mo.y);
+    *reinterpret_cast<float4 *>(a.psum2 + off) = make_float4(se.x, so.x, se.y, so.y);
+    if (a.final_publish) {  // src/mcpar.cc:202-208 after the last step
+      const f32x2 w2 = splat2(a.winv[a.isamp0 + a.nmain - 1]);
+      const f32x2 ve = se * w2, vo = so * w2;
+      *reinterpret_cast<float4 *>(a.sig + off) = make_float4(ve.x, vo.x, ve.y, vo.y);
+      float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
+      slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
+      slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.ctr[1] = tun_na;
+    a.ctr[2] = tun_nt;
+    a.ctr[3] += burn_acc;
+    *a.ntrace += ntrace_local;
+  }
+}
+
+}  // namespace mcx

@@ -10,6 +10,7 @@ VL_DEVICE = 101
 OPT_SAMPLES, OPT_ACCEPT_MASK, OPT_FUSE, OPT_MAX_SEGMENT, OPT_PROFILE, OPT_STREAM, OPT_EAGER_EXCHANGE = 1, 2, 3, 4, 5, 6, 7
 OPT_SAMPLE_STRIDE = 8
 OPT_SPLIT_RNG = 9
+OPT_PERSIST = 10
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 

@@ -244,13 +244,16 @@ def test_degenerate_sizes(d, n, nburn, nsamp, pl):
     assert_same(eo, eg, "degenerate")
 
 
-@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("split,persist", [(0, 0), (1, 0), (1, 1)], ids=["fused", "pregen", "persistent"])
 @pytest.mark.parametrize("kind,d,n,nburn,nsamp,pl", [(O.VL_ROSENBROCK1, 16, 333, 120, 150, 0.9), (O.VL_ROSENBROCK1, 8, 70, 59, 66, 1.0),
                                                      (O.VL_GAUSSIAN, 12, 40, 110, 129, 0.8), (O.VL_GAUSSMIX, 32, 64, 60, 70, 0.9),
-                                                     (O.VL_ROSENBROCK1, 4, 1, 130, 3, 1.0)])
-def test_small_n_mode_split_rng(split, kind, d, n, nburn, nsamp, pl):
-    """MCX_OPT_SPLIT_RNG on/off: pre-generated normals streamed into the step kernel vs generated in it;
-    segment lengths straddle the 64-step chunk and the 4-step accept blocks"""
+                                                     (O.VL_ROSENBROCK1, 4, 1, 130, 3, 1.0), (O.VL_ROSENBROCK1, 16, 5000, 230, 77, 1.0),
+                                                     (O.VL_ROSENBROCK1, 8, 9000, 52, 40, 0.9)])
+def test_small_n_mode_split_rng(split, persist, kind, d, n, nburn, nsamp, pl):
+    """The three forms of a stretch of local steps: random numbers generated in the step kernel (fused), by a
+    separate kernel and streamed in (MCX_OPT_SPLIT_RNG), or by the generator wavefronts of the one-launch
+    kernel k_run_small into LDS (MCX_OPT_PERSIST, 1-3 owner wavefronts per workgroup here).  Segment lengths
+    straddle the chunks, the LDS phases and the 4-step accept blocks"""
     import mcpar_amd as M
     from mcpar_amd import engine as E
     p = O.default_pinit(d, n)
@@ -266,11 +269,13 @@ def test_small_n_mode_split_rng(split, kind, d, n, nburn, nsamp, pl):
     vg, _k2 = M.make_vlfunc(kind, d, params, K)
     eg = M.Engine(d, n, pl=pl)
     eg.set_option(E.OPT_SPLIT_RNG, split)
+    eg.set_option(E.OPT_PERSIST, persist)
     eg.set_option(E.OPT_SAMPLE_STRIDE, 1 + split)  # also the thinned store through the chunked launches
     eg.run(nsamp, nburn, p, vg)
     c = eg.counters
     assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
     np.testing.assert_array_equal(eg.accept_counts, eo.accept_counts)
+    assert np.array_equal(eg.tuner_trace, eo.tuner_trace)
     for name in ("state", "loglike", "mean", "var", "musigall", "chol"):
         assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
     want = eo.samples.reshape(nsamp, n, d + 1)[::1 + split].reshape(-1, d + 1)
