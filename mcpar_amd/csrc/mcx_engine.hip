@@ -193,8 +193,7 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   if (!f) return fail(MCX_ERR_INVALID, "vlfunc is NULL");
   if (f->d != np) return fail(MCX_ERR_INVALID, "vlfunc.d = %d but engine np = %d", f->d, np);
   const int d = f->d;
-  std::vector<float> &h = L.host;
-  h.clear();
+  std::vector<float> h;
   L.fn = nullptr;
   L.ctx = nullptr;
   L.ncomp = 0;
@@ -250,9 +249,12 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   default:
     return fail(MCX_ERR_INVALID, "unknown vlfunc kind %d", f->kind);
   }
-  MCXCHK(L.params.alloc(h.size()));
-  if (!h.empty())
-    HIPCHK(hipMemcpyAsync(L.params.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  if (L.params.p && h.size() == L.host.size() && (h.empty() || std::memcmp(h.data(), L.host.data(), h.size() * sizeof(float)) == 0))
+    return MCX_OK;  // same parameters as the last call: they are on the device already
+  L.host.swap(h);
+  MCXCHK(L.params.alloc(L.host.size()));
+  if (!L.host.empty())
+    HIPCHK(hipMemcpyAsync(L.params.p, L.host.data(), L.host.size() * sizeof(float), hipMemcpyHostToDevice, st));
   return MCX_OK;
 }
 
@@ -328,6 +330,9 @@ static int eval_device(const LikDev &L, const float *x, float *y, int n, int d, 
 // ---------------------------------------------------------------------------------------------
 // the engine
 // ---------------------------------------------------------------------------------------------
+// counters of one run: [0..7] tuner / accept totals, [8..] the tuner events' meeting words of k_run_small
+constexpr int CTR_WORDS = 8 + PEVENTS, CTR_RING = 16;
+
 struct EvPair {
   hipEvent_t a, b;
   int kind;
@@ -344,7 +349,7 @@ struct mcx_engine {
   int device = 0;  // the HIP device the engine lives on (current device at mcx_create)
   // device state (src/mcpar.hh:61-88)
   DevBuf<float> pvals, ptrial, mu, sig, psum2, mutrial, sigtrial, musigall, winvall;
-  DevBuf<float> lylast, lytrial, cfac, cmax, cov, trace;
+  DevBuf<float> lylast, lytrial, cfac, cmax, cov, cov0, trace;  // cov0 = the factor as installed (cov is rescaled by the tuner)
   DevBuf<uint32_t> acc_cnt, acc_slots;
   int nslots = 0;
   DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
@@ -354,7 +359,9 @@ struct mcx_engine {
   DevBuf<uint8_t> mask;
   // host staging
   PinBuf<float> h_ptrial, h_lytrial;
-  std::vector<float> h_cov, h_winv;
+  std::vector<float> h_cov, h_cov_dev, h_winv;  // h_cov_dev = what cov0 holds
+  bool cov_pending = false;  // cov has not been reset to cov0 for the current run yet
+  int ctr_set = 0;           // counter block of the current run (ring of CTR_RING blocks, zeroed when it wraps)
   // run bookkeeping
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -503,7 +510,8 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   A(e->psum2.alloc(nt)); A(e->mutrial.alloc(nt)); A(e->sigtrial.alloc(nt));
   A(e->musigall.alloc(2 * (size_t)e->tchains * np)); A(e->winvall.alloc(2 * (size_t)e->tchains * np));
   A(e->lylast.alloc(n)); A(e->lytrial.alloc(n)); A(e->cfac.alloc(n)); A(e->cmax.alloc(n));
-  A(e->cov.alloc((size_t)e->ncov)); A(e->trace.alloc(256)); A(e->acc_cnt.alloc(n)); A(e->ctr.alloc(8 + PEVENTS));
+  A(e->cov.alloc((size_t)e->ncov)); A(e->cov0.alloc((size_t)e->ncov)); A(e->trace.alloc(256)); A(e->acc_cnt.alloc(n));
+  A(e->ctr.alloc((size_t)CTR_WORDS * CTR_RING));
   e->nslots = (int)(((size_t)nc * e->lpc + 63) / 64);
   A(e->acc_slots.alloc((size_t)e->nslots));
   A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(1)); A(e->ntrace.alloc(1));
@@ -516,10 +524,15 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   (void)hipMemsetAsync(e->sig.p, 0, nt * sizeof(float), e->stream);
   (void)hipMemsetAsync(e->psum2.p, 0, nt * sizeof(float), e->stream);
   (void)hipMemsetAsync(e->acc_cnt.p, 0, n * sizeof(uint32_t), e->stream);
+  (void)hipMemsetAsync(e->acc_slots.p, 0, (size_t)e->nslots * sizeof(uint32_t), e->stream);  // (every run leaves them zero)
+  (void)hipMemsetAsync(e->ntrace.p, 0, sizeof(int), e->stream);
   // identity factor until covar_setup / run installs one (src/mcpar.cc:460-467)
   std::vector<float> eye((size_t)e->ncov, 0.0f);
   for (int i = 0; i < np; ++i) eye[(size_t)i * (np + 1)] = 1.0f;
   (void)hipMemcpyAsync(e->cov.p, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice, e->stream);
+  (void)hipMemcpyAsync(e->cov0.p, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice, e->stream);
+  e->h_cov_dev = eye;
+  (void)hipMemsetAsync(e->ctr.p, 0, (size_t)CTR_WORDS * CTR_RING * sizeof(unsigned long long), e->stream);
   if (hipStreamSynchronize(e->stream) != hipSuccess) {
     mcx_destroy(e);
     return fail(MCX_ERR_HIP, "engine initialisation failed");
@@ -537,7 +550,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   (void)mcx_exchange_rccl_destroy(e);
   e->pvals.release(); e->ptrial.release(); e->mu.release(); e->sig.release(); e->psum2.release();
   e->mutrial.release(); e->sigtrial.release(); e->musigall.release(); e->winvall.release();
-  e->lylast.release(); e->lytrial.release(); e->cfac.release(); e->cmax.release(); e->cov.release();
+  e->lylast.release(); e->lytrial.release(); e->cfac.release(); e->cmax.release(); e->cov.release(); e->cov0.release();
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
@@ -610,9 +623,28 @@ static int covar_install(mcx_engine *e, const float *incov, float *cov_out, bool
   for (int i = 0; i < d; ++i)
     for (int j = 0; j < i; ++j)
       if (c[(size_t)i * d + j] != 0.0f) e->diag = false;
-  HIPCHK(hipMemcpyAsync(e->cov.p, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+  // cov0 keeps the factor as installed; cov (which the tuner rescales) is reset from it, on the device
+  if (e->h_cov_dev != c) {
+    if (!e->h_cov_dev.empty()) HIPCHK(hipStreamSynchronize(e->stream));  // the last upload may still read h_cov_dev
+    e->h_cov_dev = c;
+    HIPCHK(hipMemcpyAsync(e->cov0.p, e->h_cov_dev.data(), c.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  }
+  if (sync) {
+    HIPCHK(hipMemcpyAsync(e->cov.p, e->cov0.p, c.size() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->cov_pending = false;
+  } else {
+    e->cov_pending = true;  // the run resets it: k_run_small reads cov0 itself, every other path copies first
+  }
   if (cov_out) std::copy(c.begin(), c.end(), cov_out);
+  return MCX_OK;
+}
+
+static int cov_reset(mcx_engine *e)
+{
+  if (!e->cov_pending) return MCX_OK;
+  HIPCHK(hipMemcpyAsync(e->cov.p, e->cov0.p, (size_t)e->ncov * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+  e->cov_pending = false;
   return MCX_OK;
 }
 
@@ -1120,16 +1152,34 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   }
   e->cnt = mcx_counters{};
   e->published_steps = 0;
-  HIPCHK(hipMemsetAsync(e->ctr.p, 0, (8 + PEVENTS) * sizeof(unsigned long long), st));
-  HIPCHK(hipMemsetAsync(e->acc_slots.p, 0, (size_t)e->nslots * sizeof(uint32_t), st));
-  HIPCHK(hipMemsetAsync(e->ntrace.p, 0, sizeof(int), st));
-  HIPCHK(hipMemsetAsync(e->acc_cnt.p, 0, (size_t)n * sizeof(uint32_t), st));
-  // pinit is pageable caller memory: the runtime stages it before hipMemcpyAsync returns
-  if (pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
-  else HIPCHK(hipMemcpyAsync(e->pvals.p, e->pinit_dev.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToDevice, st));
-  MCXCHK(eval_trials(e, e->pvals.p, e->lylast.p, 0));  // :53
   const bool fused = e->opt_fuse && e->lik.fusable();
   const uint32_t g0 = (uint32_t)(e->rank * n);
+  // Small-n mode, one launch per stretch of local steps (mcx_persist.hpp): the whole burn-in with its tuner
+  // events, the start of the main loop and every run of consecutive local main-loop segments go to k_run_small
+  // when the chains fill at most POWN_MAX wavefronts per CU and the hot-path kernel applies.
+  const int nown = (int)(((size_t)n * e->lpc + 63) / 64);
+  const bool fast_lik = e->lik.kind == LIK_ROSEN1 || e->lik.kind == LIK_GAUSS || (e->lik.kind == LIK_MIX && e->lik.ncomp <= 8);
+  const bool persist = fused && e->lpc <= 8 && fast_lik && e->diag && e->vec4 && !e->opt_mask && e->ncu > 0 &&
+                       nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
+                       mcxk_persist_lds_bytes(e->lpc, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
+                       (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0));
+  // When the run opens with such a launch, the launch itself takes the initial state (and its likelihood,
+  // src/mcpar.cc:47-53) and the factor as installed, and starts its counters afresh: no reset kernels at all.
+  bool lead = persist && nburn + nsamp > 0;
+  // this run's counter block: a ring, zeroed as a whole when it wraps
+  e->ctr_set = (e->ctr_set + 1) % CTR_RING;
+  if (e->ctr_set == 0) HIPCHK(hipMemsetAsync(e->ctr.p, 0, (size_t)CTR_WORDS * CTR_RING * sizeof(unsigned long long), st));
+  unsigned long long *const ctrp = e->ctr.p + (size_t)e->ctr_set * CTR_WORDS;
+  // pinit is pageable caller memory: the runtime stages it before hipMemcpyAsync returns
+  if (pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
+  if (!lead) {
+    HIPCHK(hipMemsetAsync(e->acc_slots.p, 0, (size_t)e->nslots * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(e->ntrace.p, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(e->acc_cnt.p, 0, (size_t)n * sizeof(uint32_t), st));
+    if (!pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, e->pinit_dev.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToDevice, st));
+    MCXCHK(eval_trials(e, e->pvals.p, e->lylast.p, 0));  // :53
+    MCXCHK(cov_reset(e));
+  }
 
   SegArgs sa;
   sa.x = e->pvals.p; sa.ly = e->lylast.p; sa.mu = e->mu.p; sa.psum2 = e->psum2.p;
@@ -1145,15 +1195,6 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   const PlanCfg cfg = {nsamp, nburn, e->SYNCSTEP, e->PLOCAL, e->seed, e->tbase, e->size > 1, e->opt_eager != 0,
                        fused, e->ofn != nullptr, e->opt_maxseg};
   const std::vector<mcx_plan_item> plan = build_plan(cfg);
-  // Small-n mode, one launch per stretch of local steps (mcx_persist.hpp): the whole burn-in with its tuner
-  // events, the start of the main loop and every run of consecutive local main-loop segments go to k_run_small
-  // when the chains fill at most POWN_MAX wavefronts per CU and the hot-path kernel applies.
-  const int nown = (int)(((size_t)n * e->lpc + 63) / 64);
-  const bool fast_lik = e->lik.kind == LIK_ROSEN1 || e->lik.kind == LIK_GAUSS || (e->lik.kind == LIK_MIX && e->lik.ncomp <= 8);
-  const bool persist = fused && e->lpc <= 8 && fast_lik && e->diag && e->vec4 && !e->opt_mask && e->ncu > 0 &&
-                       nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
-                       mcxk_persist_lds_bytes(e->lpc, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
-                       (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0));
   bool sig_done = false, slots_used = false;
   for (size_t pi = 0; pi < plan.size(); ++pi) {
     const mcx_plan_item &it = plan[pi];
@@ -1190,9 +1231,14 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
         ra.winv = e->winv_tab.p; ra.musig_own = sa.musig_own; ra.snap_after = snap;
         ra.final_publish = (e->size == 1 && pm > 0 && is0 + pm == nsamp) ? 1 : 0;
         ra.armin = e->TGT_ARATE_MIN; ra.armax = e->TGT_ARATE_MAX; ra.dfac = e->SCALE_DEC; ra.ifac = e->SCALE_INC;
-        ra.ctr = e->ctr.p; ra.bar = e->ctr.p + 8; ra.trace = e->trace.p; ra.ntrace = e->ntrace.p;
+        ra.ctr = ctrp; ra.bar = ctrp + 8; ra.trace = e->trace.p; ra.ntrace = e->ntrace.p;
+        // the run's first launch takes the state where it lies, evaluates it, and starts the counters afresh
+        ra.x0 = lead ? (pinit ? e->pvals.p : e->pinit_dev.p) : nullptr;
+        ra.T0 = e->cov_pending ? e->cov0.p : nullptr;
+        ra.fresh = lead ? 1 : 0;
+        e->cov_pending = false;
+        lead = false;
         ra.nown = nown;
-        ra.dbg = getenv("MCX_PERSIST_DEBUG") ? atoi(getenv("MCX_PERSIST_DEBUG")) : 0;
         const int nwg = std::min(nown, e->ncu);
         ra.own = (nown + nwg - 1) / nwg;
         if (snap >= 0) {  // the kernel rewrites this shard's slot: no gather may still be reading it
@@ -1236,7 +1282,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     }
     case MCX_PLAN_TUNER: {  // src/mcpar.cc:77-96
       ProfScope ps(e, MCX_K_TUNER, 0);
-      hipLaunchKernelGGL(k_tuner, dim3(1), dim3(BLOCK), 0, st, e->ctr.p, e->cov.p, e->ncov,
+      hipLaunchKernelGGL(k_tuner, dim3(1), dim3(BLOCK), 0, st, ctrp, e->cov.p, e->ncov,
                          (unsigned long long)steps * (unsigned long long)n, it.aux, e->TGT_ARATE_MIN,
                          e->TGT_ARATE_MAX, e->SCALE_DEC, e->SCALE_INC, e->trace.p, e->ntrace.p, e->acc_slots.p,
                          e->nslots);
@@ -1306,11 +1352,12 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     HIPCHK(hipGetLastError());
   }
   if (slots_used) {
-    hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, e->ctr.p + 4);
+    hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, ctrp + 4);
     HIPCHK(hipGetLastError());
   }
   unsigned long long hctr[8];
-  HIPCHK(hipMemcpyAsync(hctr, e->ctr.p, sizeof hctr, hipMemcpyDeviceToHost, st));
+  MCXCHK(cov_reset(e));  // (a run without any step)
+  HIPCHK(hipMemcpyAsync(hctr, ctrp, sizeof hctr, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   e->cnt.naccept_burn = hctr[3];
   e->cnt.naccept_main = hctr[4];

@@ -7,13 +7,9 @@
 
 using namespace mcx;
 
-// recorders (one per owner) only where the owner's latency is the bound: one owner wavefront per workgroup
-bool mcxk_persist_recorders(int own)
-{
-  static const char *ov = getenv("MCX_PERSIST_REC");  // experiments: 0 / 1 force
-  if (ov) return ov[0] == '1';
-  return own == 1;
-}
+// recorders (one per owner) where the owner's latency is the bound, not the generators' throughput: measured
+// faster with one or two owner wavefronts per workgroup, equal with three, slower with four
+bool mcxk_persist_recorders(int own) { return own <= 2; }
 
 size_t mcxk_persist_lds_bytes(int lpc, int own)
 {

@@ -38,6 +38,10 @@ constexpr int PEVENTS = 64;           // tuner events (steps 51, 101, ... and th
 
 struct RunArgs {
   float *x, *ly, *mu, *psum2, *sig;
+  const float *x0;          // the run's first launch: initial state to start from (its likelihood is evaluated here,
+                            // src/mcpar.cc:47-53) instead of (x, ly); null otherwise
+  const float *T0;          // the factor as installed, when T has not been reset for this run yet; null otherwise
+  int fresh;                // the run's first launch: counters start from zero (acc_cnt, ctr, ntrace are overwritten)
   uint32_t *acc_cnt;
   float *T;                 // [d][d] Cholesky factor, diagonal here; rescaled in place when the launch ends
   float *samp_x, *samp_ly;  // sample store of the run (row 0 = main step 0 / kept step 0), or null
@@ -61,7 +65,6 @@ struct RunArgs {
   int *ntrace;
   int nown;                 // owner wavefronts in the whole grid = ceil(n * LPC / 64)
   int own;                  // owner wavefronts per workgroup (1..POWN_MAX)
-  int dbg;                  // timing experiments only (wrong results): 1 owners idle, 2 generators idle
 };
 
 // all owners of the grid meet; returns the sum of `mine` over the workgroups.  One atomic per workgroup:
@@ -135,34 +138,43 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
 
   // ---- generator side -------------------------------------------------------------------------------------
   // The work of one phase is a list of items dealt round-robin to the `nfill` waves that fill in this
-  // iteration (a counter in LDS was measured slower: ~40 same-address atomics per phase serialise): item
-  // i < ns * OWN = the 64 lanes' normals of owner i % OWN at step i / OWN of the phase; the next OWN items =
-  // the logs of the phase's acceptance draws of one owner; the last item = the 1/pwgt values of the phase's
-  // main-loop steps.
+  // iteration (a counter in LDS was measured slower: ~40 same-address atomics per phase serialise).
+  const int fq = lane % LPC, fcl = lane / LPC;  // this lane's parameter block and chain within an owner wavefront
   auto fill = [&](int phase, int me_fill, int nfill) {
     const int buf = phase & 1, tau0 = phase * K;
     const int ns = T - tau0 < K ? T - tau0 : K;  // steps [tau0, tau0 + ns)
-    const int nitems = ns * OWN + OWN + 1;
-    for (int i = me_fill; i < nitems; i += nfill) {
-      if (a.dbg & 2) continue;
-      if (i < ns * OWN) {
-        const int g = i / OWN, o = i - g * OWN;
-        const uint32_t t = a.t0 + (uint32_t)(tau0 + g);
-        const size_t gid = ((size_t)blockIdx.x * OWN + o) * 64 + lane;
-        const size_t chain = gid / LPC;
-        const int q = (int)(gid % LPC);
-        if (chain < (size_t)a.n && 4 * q < d) {
-          f32x2 ze, zo;
-          normal4_packed(philox4x32_10(t, a.g0 + (uint32_t)chain, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
-          zbuf[((size_t)(buf * K + g) * OWN + o) * 64 + lane] = make_float4(ze.x, ze.y, zo.x, zo.y);  // (even pair, odd pair)
-        }
-      } else if (i < ns * OWN + OWN) {  // one Philox block of the ACCEPT stream serves 4 steps
-        const int o = i - ns * OWN;
+    // normals: one item = TWO consecutive steps of one owner (two independent Philox / Box-Muller chains per
+    // lane: the lone instruction streams of 3-4 waves do not fill a SIMD otherwise)
+    const int npair = (ns + 1) >> 1, nz_items = npair * OWN;
+    const int dq = nfill / OWN, dr = nfill - dq * OWN;
+    int gp = me_fill / OWN, o = me_fill - gp * OWN;  // item i = (step pair gp, owner o), i = gp * OWN + o
+    for (int i = me_fill; i < nz_items; i += nfill) {
+      const int chain = ((int)blockIdx.x * OWN + o) * CPW + fcl;
+      if (chain < a.n && 4 * fq < d) {
+        const int g0s = 2 * gp;
+        const uint32_t t = a.t0 + (uint32_t)(tau0 + g0s), gch = a.g0 + (uint32_t)chain;
+        f32x2 ze, zo, ye, yo;
+        normal4_packed(philox4x32_10(t, gch, (uint32_t)fq, 0u, a.seed, ST_LOCAL), ze, zo);
+        normal4_packed(philox4x32_10(t + 1u, gch, (uint32_t)fq, 0u, a.seed, ST_LOCAL), ye, yo);
+        float4 *dst = zbuf + ((size_t)(buf * K + g0s) * OWN + o) * 64 + lane;
+        dst[0] = make_float4(ze.x, ze.y, zo.x, zo.y);  // (even pair, odd pair)
+        if (g0s + 1 < ns) dst[(size_t)OWN * 64] = make_float4(ye.x, ye.y, yo.x, yo.y);
+      }
+      gp += dq;
+      o += dr;
+      if (o >= OWN) { o -= OWN; ++gp; }
+    }
+    // then, dealt on from where the normals ended: OWN items = the logs of the phase's acceptance draws of one
+    // owner (one Philox block of the ACCEPT stream serves 4 steps), and one item = the 1/pwgt values
+    const int first = (me_fill - nz_items % nfill + nfill) % nfill;  // this wave's first index among the tail items
+    for (int j = first; j < OWN + 1; j += nfill) {
+      if (j < OWN) {
+        const int oo = j;
         const uint32_t tf = a.t0 + (uint32_t)tau0, tl = tf + (uint32_t)ns - 1u;
         const uint32_t bf = tf >> 2, bl = tl >> 2;
         const int c = lane % CPW;
-        const size_t chain = ((size_t)blockIdx.x * OWN + o) * CPW + c;
-        if (chain < (size_t)a.n)
+        const int chain = ((int)blockIdx.x * OWN + oo) * CPW + c;
+        if (chain < a.n)
           for (uint32_t b = bf + (uint32_t)(lane / CPW); b <= bl; b += (uint32_t)LPC) {
             const u32x4 aw = philox4x32_10(b, a.g0 + (uint32_t)chain, 0u, 0u, a.seed, ST_ACCEPT);
             const f32x2 l01 = accept_lu_x2(aw.x, aw.y), l23 = accept_lu_x2(aw.z, aw.w);
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
 #pragma unroll
             for (uint32_t wi = 0; wi < 4u; ++wi) {
               const uint32_t t = (b << 2) + wi;
-              if (t >= tf && t <= tl) ubuf[((size_t)(buf * K + (int)(t - tf)) * OWN + o) * CPW + c] = l[wi];
+              if (t >= tf && t <= tl) ubuf[((size_t)(buf * K + (int)(t - tf)) * OWN + oo) * CPW + c] = l[wi];
             }
           }
       } else if (lane < ns) {  // 1/pwgt (src/mcpar.cc:186-187), from the host-built table
@@ -194,10 +206,11 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   f32x2 gme = {0, 0}, gmo = {0, 0};
   float gs0 = 0, gs1 = 0, gs2 = 0, gs3 = 0, ly = __builtin_inff();
   if (live && owner) {
-    const float4 f = *reinterpret_cast<const float4 *>(a.x + off);
+    const float4 f = *reinterpret_cast<const float4 *>((a.x0 ? a.x0 : a.x) + off);
     xe = f32x2{f.x, f.z}; xo = f32x2{f.y, f.w};
-    te = f32x2{a.T[(k0 + 0) * d + k0 + 0], a.T[(k0 + 2) * d + k0 + 2]};
-    to = f32x2{a.T[(k0 + 1) * d + k0 + 1], a.T[(k0 + 3) * d + k0 + 3]};
+    const float *Tsrc = a.T0 ? a.T0 : a.T;
+    te = f32x2{Tsrc[(k0 + 0) * d + k0 + 0], Tsrc[(k0 + 2) * d + k0 + 2]};
+    to = f32x2{Tsrc[(k0 + 1) * d + k0 + 1], Tsrc[(k0 + 3) * d + k0 + 3]};
     if (LIK == LIK_GAUSS) {
       gme = f32x2{a.lik[k0 + 0], a.lik[k0 + 2]}; gmo = f32x2{a.lik[k0 + 1], a.lik[k0 + 3]};
       gs0 = a.lik[d + k0 + 0]; gs1 = a.lik[d + k0 + 1]; gs2 = a.lik[d + k0 + 2]; gs3 = a.lik[d + k0 + 3];
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
     se = f32x2{p.x, p.z}; so = f32x2{p.y, p.w};
   }
   // owner lanes that hold no chain never accept: log u < ly' - (+inf) is false for every ly'
-  if (mine && owner) ly = a.ly[chain];
+  if (mine && owner && !a.x0) ly = a.ly[chain];
   // Every load of the chain state is awaited here, once, on every path (the compiler's s_waitcnt bookkeeping
   // is path-insensitive): inside the step loops the only vector-memory operations are stores, and no
   // s_waitcnt vmcnt may end up there -- it would wait for the previous step's stores.
@@ -276,8 +289,13 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
     return 0.0f - group_sum<LPC>(acc);
   };
 
+  __syncthreads();  // the mixture's means and log-weights are staged
+  if (owner && a.x0) {  // L(pinit) (src/mcpar.cc:53); every lane of a chain gets the chain's value
+    const float l0 = loglike(xe, xo);
+    ly = mine ? l0 : __builtin_inff();
+  }
   // tuner state (src/mcpar.cc:77-96), identical in every owner wave
-  unsigned long long tun_na = a.ctr[1], tun_nt = a.ctr[2], burn_acc = 0;
+  unsigned long long tun_na = a.fresh ? 0ull : a.ctr[1], tun_nt = a.fresh ? 0ull : a.ctr[2], burn_acc = 0;
   int irate = 50, seg_start = 0, nevent = 0, ntrace_local = 0;
   const int nwg = (int)gridDim.x;
   const int own_here = a.nown - (int)blockIdx.x * OWN < OWN ? a.nown - (int)blockIdx.x * OWN : OWN;
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   for (int p = 0; p < nphase + (REC ? 1 : 0); ++p) {
     const int buf = p & 1;
     if (owner) {
-      if (working && p < nphase && !(a.dbg & 1)) {
+      if (working && p < nphase) {
         const int tau0 = p * K;
         const int ns = T - tau0 < K ? T - tau0 : K;
         const int nb = a.nburn - tau0 < 0 ? 0 : (a.nburn - tau0 < ns ? a.nburn - tau0 : ns);  // burn-in steps of this phase
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
                 else if (arate > a.armax) { tun_na = tun_nt = 0; f = a.ifac; }
                 if (f != 1.0f) { te = te * splat2(f); to = to * splat2(f); }
                 if (blockIdx.x == 0 && wv == 0 && lane == 0) {  // lane 0 of the grid holds T[0][0]
-                  const int kk = *a.ntrace + ntrace_local;
+                  const int kk = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
                   if (kk < 256) a.trace[kk] = te.x;
                 }
                 ++ntrace_local;
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
         }
       }
     } else {
-      if (recorder && working && p >= 1 && !(a.dbg & 1)) {  // Welford, snapshot, emit of phase p - 1 (src/mcpar.cc:176-209)
+      if (recorder && working && p >= 1) {  // Welford, snapshot, emit of phase p - 1 (src/mcpar.cc:176-209)
         const int pb = buf ^ 1, tau0 = (p - 1) * K;
         const int ns = T - tau0 < K ? T - tau0 : K;
         const int nb = a.nburn - tau0 < 0 ? 0 : (a.nburn - tau0 < ns ? a.nburn - tau0 : ns);
@@ -447,11 +465,11 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
           }
         }
       }
-      // the recorders fill too when the phase they would digest held no main-loop step (the whole burn-in)
-      const bool rec_busy = REC && p >= 1 && (p - 1) * K + K > a.nburn && a.nmain > 0;
+      // the recorders fill too, after their recording: they sit at the end of the round-robin deal, where the
+      // shares are smallest
       if (p + 1 < nphase) {
-        if (!recorder) fill(p + 1, wv - OWN - NREC, (rec_busy || !REC) ? NG : NG + OWN);
-        else if (!rec_busy) fill(p + 1, NG + (wv - OWN), NG + OWN);
+        if (!recorder) fill(p + 1, wv - OWN - NREC, NG + NREC);
+        else fill(p + 1, NG + (wv - OWN), NG + NREC);
       }
     }
     __syncthreads();
@@ -461,14 +479,14 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   if (owner) {
     if (live) {
       *reinterpret_cast<float4 *>(a.x + off) = make_float4(xe.x, xo.x, xe.y, xo.y);
-      if (a.nburn > 0 && chain == 0) {  // the rescaled diagonal (off-diagonal entries are zero on this path)
+      if ((a.nburn > 0 || a.T0) && chain == 0) {  // the (rescaled) diagonal; off-diagonal entries are zero on this path
         a.T[(k0 + 0) * d + k0 + 0] = te.x; a.T[(k0 + 2) * d + k0 + 2] = te.y;
         a.T[(k0 + 1) * d + k0 + 1] = to.x; a.T[(k0 + 3) * d + k0 + 3] = to.y;
       }
     }
     if (mine && q == 0) {
       a.ly[chain] = ly;
-      a.acc_cnt[chain] += cnt;
+      a.acc_cnt[chain] = a.fresh ? cnt : a.acc_cnt[chain] + cnt;
     }
     if (lane == 0 && macc) atomicAdd(a.ctr + 4, macc);
   }
@@ -487,8 +505,8 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.ctr[1] = tun_na;
     a.ctr[2] = tun_nt;
-    a.ctr[3] += burn_acc;
-    *a.ntrace += ntrace_local;
+    a.ctr[3] = (a.fresh ? 0ull : a.ctr[3]) + burn_acc;
+    *a.ntrace = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
   }
 }
 

@@ -12,7 +12,7 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, vlspec=None):
+def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, vlspec=None, opts=None):
     import mcpar_amd as M
     from mcpar_amd import engine as E
     hip = C.CDLL("libamdhip64.so")
@@ -45,6 +45,8 @@ def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, v
         try:
             engs[s].set_option(E.OPT_ACCEPT_MASK, mask)
             engs[s].set_option(E.OPT_EAGER_EXCHANGE, eager)
+            for k, v in (opts or {}).items():
+                engs[s].set_option(k, v)
             engs[s].set_exchange(make_hook(s))
             engs[s].run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
         except Exception as ex:  # pragma: no cover
@@ -109,6 +111,30 @@ def test_multishard_hot_path_kernel(pl, eager):
         assert c["naccept_main"] == eo.naccept_main and c["remote_passes"] == eo.remote_passes
         for name in ("state", "mean", "var", "samples", "musigall"):
             assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("mode", ["pregen", "persistent"])
+def test_small_n_modes_two_shards_long_segments(mode, stride):
+    """Two shards of 8192 x 16-D chains, 600 local main-loop steps: in MCX_OPT_SPLIT_RNG mode a segment is longer
+    than one chunk of pre-generated normals (256 steps here), so the launch loop rebases step index, sample rows
+    and the in-kernel exchange snapshot per chunk; in MCX_OPT_PERSIST mode the whole run is one launch whose
+    recorder wavefronts take the snapshot.  Thinned and unthinned sample store."""
+    from mcpar_amd import engine as E
+    d, n, nshards, nburn, nsamp, pl = 16, 8192, 2, 60, 600, 1.0
+    vo, keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl, threads=16) for s in range(nshards)]
+    O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+    opts = {E.OPT_SPLIT_RNG: 1, E.OPT_PERSIST: 1 if mode == "persistent" else 0, E.OPT_SAMPLE_STRIDE: stride,
+            E.OPT_MAX_SEGMENT: 1 << 20}
+    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, mask=0, opts=opts)
+    for s in range(nshards):
+        eo, eg = eos[s], egs[s]
+        assert eg.counters["naccept_main"] == eo.naccept_main and eg.counters["naccept_burn"] == eo.naccept_burn
+        for name in ("state", "mean", "var", "musigall"):
+            assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), (s, name)
+        want = eo.samples.reshape(nsamp, n, d + 1)[::stride].reshape(-1, d + 1)
+        assert np.array_equal(eg.samples.view(np.uint32), want.view(np.uint32)), s
 
 
 def test_c5_shape_mixture_four_shards():
