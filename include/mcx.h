@@ -137,6 +137,18 @@ int mcx_debug_exchange(mcx_engine *e);
 typedef int (*mcx_output_fn)(void *ctx, int steps_done);
 int mcx_set_output_hook(mcx_engine *e, mcx_output_fn fn, void *ctx);
 
+/* Streaming sample sink: the role of MCout as the reference fills it (src/mcpar.cc:176-182) and dumps it every
+ * outstep steps (:110-119), for runs whose samples should not all stay in HBM.  With a sink installed the
+ * engine keeps only a ring of 4 blocks of `block_steps` main-loop steps on the device; when a block is complete
+ * its rows -- MCout layout, np+1 columns, step-major then chain -- are interleaved on the device and copied to
+ * pinned host memory on a second stream while the step stream goes on with the next blocks, and fn is called on
+ * the thread that called mcx_run with rows valid for the duration of the call (first_step / nsteps count KEPT
+ * steps, see MCX_OPT_SAMPLE_STRIDE).  nsamp is then bounded by nothing but the int32 range; mcx_samples_copy
+ * serves only what the ring still holds, mcx_samples_maxlike keeps its running maximum on the device.
+ * fn == NULL removes the sink.  block_steps is rounded up to a multiple of the sample stride. */
+typedef int (*mcx_sink_fn)(void *ctx, int first_step, int nsteps, const float *rows);
+int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_steps);
+
 /* ---- options ------------------------------------------------------------------------------ */
 enum {
   MCX_OPT_SAMPLES = 1,     /* 0 none, 1 keep every (step, chain) row in HBM (reference semantics,
@@ -205,8 +217,10 @@ enum {
   MCX_PLAN_GATHER_BEGIN = 6, /* exchange hook, MCX_XCHG_BEGIN */
   MCX_PLAN_GATHER_WAIT = 7,  /* exchange hook, MCX_XCHG_WAIT */
   MCX_PLAN_REMOTE_STEP = 8,  /* first = isamp of a Murray (genRemote) step */
-  MCX_PLAN_MAIN_SEGMENT = 9  /* first, nsteps: consecutive local main-loop steps in one launch;
+  MCX_PLAN_MAIN_SEGMENT = 9, /* first, nsteps: consecutive local main-loop steps in one launch;
                                 aux = local step after which the kernel snapshots the slot, or -1 */
+  MCX_PLAN_SINK = 10         /* first = main-loop steps completed, nsteps = steps of the block that just ended:
+                                hand the block to the sample sink (mcx_set_sink) */
 };
 typedef struct mcx_plan_item {
   int kind, first, nsteps, aux;
@@ -214,8 +228,8 @@ typedef struct mcx_plan_item {
 /* tbase = steps consumed by earlier runs of the engine (0 for a fresh one).  items may be NULL to
  * query the count. */
 int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed, uint32_t tbase, int nshards,
-             int eager, int fused, int max_segment, int has_output_hook, mcx_plan_item *items,
-             int max_items, int *nitems);
+             int eager, int fused, int max_segment, int has_output_hook, int sink_block_steps,
+             mcx_plan_item *items, int max_items, int *nitems);
 
 /* ---- profiling (MCX_OPT_PROFILE) ---------------------------------------------------------- */
 enum { MCX_K_FUSED_BURN = 0, MCX_K_FUSED_MAIN, MCX_K_PROPOSE, MCX_K_EVAL, MCX_K_ACCEPT,

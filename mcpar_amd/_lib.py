@@ -14,6 +14,7 @@ class McxError(RuntimeError):
 HOSTFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
 XCHGFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 OUTFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+SINKFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
 
 
 class VLFunc(C.Structure):
@@ -69,6 +70,7 @@ def load():
         "mcx_covar_setup": [vp, fp, fp],
         "mcx_set_exchange": [vp, XCHGFN, vp],
         "mcx_set_output_hook": [vp, OUTFN, vp],
+        "mcx_set_sink": [vp, SINKFN, vp, C.c_int],
         "mcx_set_option": [vp, C.c_int, C.c_int64],
         "mcx_get_counters": [vp, C.POINTER(Counters)],
         "mcx_get_state": [vp, fp], "mcx_get_loglike": [vp, fp], "mcx_get_mean": [vp, fp],
@@ -83,7 +85,7 @@ def load():
         "mcx_copy_to_host": [vp, vp, C.c_size_t, vp],
         "mcx_copy_to_device": [vp, vp, C.c_size_t, vp],
         "mcx_plan": [C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
-                     C.c_int, C.c_int, C.POINTER(PlanItem), C.c_int, C.POINTER(C.c_int)],
+                     C.c_int, C.c_int, C.c_int, C.POINTER(PlanItem), C.c_int, C.POINTER(C.c_int)],
         "mcx_abi_version": [],
         "mcx_device_info": [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
         "mcx_set_device": [C.c_int],

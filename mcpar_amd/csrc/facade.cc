@@ -32,7 +32,7 @@ static void die(const char *where)
 // ---------------------------------------------------------------------------------------------
 MCout::MCout(int np, std::ostream *aoutstream, MPI_Comm acomm)
     : nparam_(np), width_(np + 1), fill_(0), flushed_(0), stored_rows_(0), capacity_rows_(0),
-      best_l_(-std::numeric_limits<float>::infinity()), best_p_(static_cast<size_t>(np), 0.0f), sink_(0)
+      best_l_(-std::numeric_limits<float>::infinity()), best_p_(static_cast<size_t>(np), 0.0f), sink_(0), binary_(false)
 {
 #ifdef MCX_WITH_MPI
   if (MPI_Comm_dup(acomm, &comm_) != MPI_SUCCESS) {
@@ -82,6 +82,11 @@ void MCout::output()
   float *all = collect(&count);
   if (rank_ != 0 || count == 0) return;
   std::ostream &os = *sink_;
+  if (binary_) {
+    os.write(reinterpret_cast<const char *>(all), (std::streamsize)(count * sizeof(float)));
+    delete[] all;
+    return;
+  }
   for (size_t i = 0; i < count; ++i) {
     os << all[i] << "  ";
     if ((i + 1) % width_ == 0) os << "\n";
@@ -336,18 +341,16 @@ void write_step_diagnostics(RunCtx *c, int upto)
   c->logged_upto = upto;
 }
 
-// where the reference dumps output (src/mcpar.cc:115-119): move the new rows from the HBM sample
-// store into MCout, then let MCout print them
-int output_hook(void *vctx, int steps_done)
+// The engine streams the samples out in blocks of `outstep` main-loop steps -- the interval at which the
+// reference dumps output (src/mcpar.cc:110-119) -- through a small ring in HBM and pinned staging memory, while
+// the chains keep stepping (mcx_set_sink).  Each block goes into MCout exactly as the reference's per-step
+// MCout::add calls would have filled it (src/mcpar.cc:176-182), and MCout prints it where the reference does.
+int sample_sink(void *vctx, int first_step, int nsteps, const float *rows)
 {
   RunCtx *c = static_cast<RunCtx *>(vctx);
-  const int ns = steps_done - c->copied_steps;
-  if (ns > 0) {
-    c->stage.resize((size_t)ns * c->nchain * c->ncol);
-    if (mcx_samples_copy(c->eng, c->copied_steps, ns, c->stage.data()) != MCX_OK) return 1;
-    c->out->add_rows(c->stage.data(), (size_t)ns * c->nchain);
-    c->copied_steps = steps_done;
-  }
+  const int steps_done = first_step + nsteps;
+  c->out->add_rows(rows, (size_t)nsteps * c->nchain);
+  c->copied_steps = steps_done;
   write_step_diagnostics(c, steps_done);  // iterations before this dump point
   if (steps_done < c->nsamp) {
     (*c->log) << "Beginning output at step " << steps_done << std::endl;
@@ -405,7 +408,8 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
 
   RunCtx ctx = {eng,   &outsamples, &logfile, nchain,   nparam + 1, 0, nsamp, std::vector<float>(),
                 logging, mpi,        logstep,  SYNCSTEP, 0,          outsamples.size()};
-  mcx_set_output_hook(eng, output_hook, &ctx);
+  const int outstep = nsamp > 50 ? nsamp / 10 : 5;  // src/mcpar.cc:110
+  mcx_set_sink(eng, sample_sink, &ctx, outstep);
 #ifdef MCX_WITH_MPI
   std::vector<float> nohost;
   XchgCtx xc = {comm ? comm->comm : MPI_COMM_WORLD, comm ? comm->host : nohost};
@@ -413,12 +417,12 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   if (staged) mcx_set_exchange(eng, mpi_exchange, &xc);
 #endif
   logfile << "Starting burn-in.  Samples = " << nburn << std::endl;  // src/mcpar.cc:56
-  const int outstep = nsamp > 50 ? nsamp / 10 : 5;
   logfile << "Starting main sample loop:  nsamp = " << nsamp << std::endl;  // :111-112
   logfile << "Output after each " << outstep << " steps." << std::endl;
 
   const int st = mcx_run(eng, nsamp, nburn, pinit, &f, incov);
-  mcx_set_output_hook(eng, 0, 0);
+  mcx_set_sink(eng, 0, 0, 0);
+  if (st == MCX_OK) write_step_diagnostics(&ctx, nsamp);
 #ifdef MCX_WITH_MPI
   if (staged) mcx_set_exchange(eng, 0, 0);  // its context lives on this stack frame
 #endif

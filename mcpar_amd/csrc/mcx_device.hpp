@@ -1262,6 +1262,56 @@ static __global__ void k_rows_interleave(const float *__restrict__ sx, const flo
   rows[i] = c < d ? sx[r * d + c] : sl[r];
 }
 
+// Running maximum-likelihood sample (MCout::add's maxlval, src/mcout.cc:140-144: the FIRST strict maximum in
+// (step, chain) order).  key = order-preserving bits of the value << 32 | ~row: the largest key is the largest
+// value at the lowest row; 0 = nothing above -inf seen (NaN never compares greater and stays out).
+static __global__ __launch_bounds__(BLOCK) void k_argmax_first(const float *__restrict__ ly, size_t nrows,
+                                                               unsigned long long *__restrict__ key_out)
+{
+  unsigned long long best = 0;
+  for (size_t r = (size_t)blockIdx.x * BLOCK + threadIdx.x; r < nrows; r += (size_t)gridDim.x * BLOCK) {
+    const float v = ly[r];
+    if (v > -__builtin_inff()) {
+      uint32_t b = as_u32(v);
+      b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
+      const unsigned long long k = ((unsigned long long)b << 32) | (unsigned long long)(0xffffffffu - (uint32_t)r);
+      best = k > best ? k : best;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o);
+    best = other > best ? other : best;
+  }
+  if ((threadIdx.x & 63u) == 0 && best) atomicMax(key_out, best);
+}
+
+// best = {log-likelihood, parameters}: replaced when the block's first maximum is strictly greater (an equal
+// value in a later block is not the FIRST maximum); clears the key for the next block
+static __global__ void k_best_update(unsigned long long *__restrict__ key, const float *__restrict__ ly,
+                                     const float *__restrict__ x, int d, float *__restrict__ best)
+{
+  const unsigned long long k = *key;
+  if (k) {
+    const size_t r = (size_t)(0xffffffffu - (uint32_t)k);
+    const float v = ly[r];
+    if (v > best[0])
+      for (int i = threadIdx.x; i < d; i += blockDim.x) best[1 + i] = x[r * (size_t)d + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (v > best[0]) best[0] = v;
+      *key = 0;
+    }
+  }
+}
+
+static __global__ void k_best_reset(float *best, int d, unsigned long long *key)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { best[0] = -__builtin_inff(); *key = 0; }
+  if (i >= 1 && i <= d) best[i] = 0.0f;
+}
+
 // test hooks -----------------------------------------------------------------------------------
 static __global__ void k_debug_numerics(int what, int n, const uint32_t *in, uint32_t *out)
 {

@@ -333,6 +333,8 @@ static int eval_device(const LikDev &L, const float *x, float *y, int n, int d, 
 // counters of one run: [0..7] tuner / accept totals, [8..] the tuner events' meeting words of k_run_small
 constexpr int CTR_WORDS = 8 + PEVENTS, CTR_RING = 16;
 
+constexpr int SINK_RING = 4;  // blocks of the device ring in sink mode
+
 struct EvPair {
   hipEvent_t a, b;
   int kind;
@@ -383,6 +385,19 @@ struct mcx_engine {
   hipEvent_t xready = nullptr, xdone = nullptr;
   mcx_output_fn ofn = nullptr;
   void *octx = nullptr;
+  // streaming sample sink (mcx_set_sink): ring of SINK_RING blocks in samp_x / samp_ly, staged out on cstream
+  mcx_sink_fn sfn = nullptr;
+  void *sctx = nullptr;
+  int sink_block = 0;  // main-loop steps per block (0 = no sink: the whole run stays in HBM)
+  bool run_sink = false;           // the current / last run streamed its samples
+  int last_sink_total = 0;         // kept steps handed to the copy stream so far
+  int run_sblock = 0, run_kb = 0;  // its block length in steps / in kept steps
+  hipStream_t cstream = nullptr;
+  hipEvent_t ev_steps[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
+  DevBuf<float> sink_stage[2];
+  PinBuf<float> sink_pin[2];
+  DevBuf<float> best_row;            // running maximum-likelihood sample: [0] = log-likelihood, [1..np] = parameters
+  DevBuf<unsigned long long> best_key;  // scratch of the arg-max reduction
   mcx_counters cnt{};
   std::vector<EvPair> evs;
   mcx_profile prof{};
@@ -555,6 +570,14 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
   e->h_ptrial.release(); e->h_lytrial.release(); e->zpre.release(); e->upre.release(); e->trash.release();
+  for (int b = 0; b < 2; ++b) {
+    e->sink_stage[b].release();
+    e->sink_pin[b].release();
+    if (e->ev_steps[b]) (void)hipEventDestroy(e->ev_steps[b]);
+    if (e->ev_copy[b]) (void)hipEventDestroy(e->ev_copy[b]);
+  }
+  e->best_row.release(); e->best_key.release(); e->cov0.release();
+  if (e->cstream) (void)hipStreamDestroy(e->cstream);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MCX_OK;
@@ -681,6 +704,17 @@ static int eval_trials(mcx_engine *e, const float *x_dev, float *y_dev, uint64_t
   return eval_device(e->lik, x_dev, y_dev, n, d, e->stream);
 }
 
+// Base pointers such that kept step r = isamp / stride of the run lives at base + r * rowsize: the whole-run
+// store itself, or -- in sink mode -- the ring slot of isamp's block shifted back by the block's first row
+// (kernels index rows of the run; a launch never straddles a block).
+static void samp_vbase(const mcx_engine *e, int isamp, float **px, float **pl)
+{
+  if (!e->run_sink) { *px = e->samp_x.p; *pl = e->samp_ly.p; return; }
+  const long long b = isamp / e->run_sblock, slot = b % SINK_RING, shift = (slot - b) * (long long)e->run_kb;
+  *px = e->samp_x.p + shift * (long long)e->ntot;
+  *pl = e->samp_ly.p + shift * (long long)e->nchain;
+}
+
 static void fill_step(mcx_engine *e, StepArgs &a, uint32_t t, int isamp, bool main, size_t maskrow,
                       int samprow, int remote)
 {
@@ -691,8 +725,10 @@ static void fill_step(mcx_engine *e, StepArgs &a, uint32_t t, int isamp, bool ma
   a.acc_slots = e->acc_slots.p;
   a.T = e->cov.p;
   const bool keep = main && e->opt_samples && samprow % e->opt_stride == 0;
-  a.samp_x = keep ? e->samp_x.p + (size_t)(samprow / e->opt_stride) * e->ntot : nullptr;
-  a.samp_ly = keep ? e->samp_ly.p + (size_t)(samprow / e->opt_stride) * e->nchain : nullptr;
+  float *vx = nullptr, *vl = nullptr;
+  if (keep) samp_vbase(e, samprow, &vx, &vl);
+  a.samp_x = keep ? vx + (size_t)(samprow / e->opt_stride) * e->ntot : nullptr;
+  a.samp_ly = keep ? vl + (size_t)(samprow / e->opt_stride) * e->nchain : nullptr;
   a.mask = e->opt_mask ? e->mask.p + maskrow * (size_t)e->nchain : nullptr;
   a.lik = e->lik.params.p; a.ncomp = e->lik.ncomp;
   a.n = e->nchain; a.d = e->nparam;
@@ -1024,6 +1060,7 @@ struct PlanCfg {
   uint32_t seed, tbase;
   bool sharded, eager, fused, output_hook;
   int maxseg;
+  int sink_block;  // > 0: cut the main loop into blocks of this many steps for the sample sink
 };
 
 // one Philox draw per step for the whole job (the reference draws per rank: src/mcpar.cc:142-146)
@@ -1060,6 +1097,7 @@ static std::vector<mcx_plan_item> build_plan(const PlanCfg &c)
   // eager = the reference's schedule (each gather overlapped with the next segment).
   bool need_gather = false;
   for (int isamp = 0; isamp < c.nsamp;) {
+    if (c.sink_block > 0 && isamp % c.sink_block == 0 && isamp > 0) add(MCX_PLAN_SINK, isamp, c.sink_block, 0);
     if (isamp % outstep == 0 && isamp > 0 && c.output_hook) add(MCX_PLAN_OUTPUT, isamp, 0, 0);  // :115-119
     if (c.sharded && isamp % c.sync == 0) {  // :127-140
       add(MCX_PLAN_PUBLISH, isamp, 0, 0);
@@ -1083,6 +1121,7 @@ static std::vector<mcx_plan_item> build_plan(const PlanCfg &c)
     while (isamp + steps < c.nsamp && steps < c.maxseg) {
       const int nx = isamp + steps;
       if (nx % outstep == 0 && c.output_hook) break;
+      if (c.sink_block > 0 && nx % c.sink_block == 0) break;
       if (c.sharded && !span_sync && nx % c.sync == 0) break;
       if (coin_is_remote(c, nx)) break;
       ++steps;
@@ -1098,6 +1137,7 @@ static std::vector<mcx_plan_item> build_plan(const PlanCfg &c)
     add(MCX_PLAN_MAIN_SEGMENT, isamp, steps, snap_after);
     isamp += steps;
   }
+  if (c.sink_block > 0 && c.nsamp > 0) add(MCX_PLAN_SINK, c.nsamp, c.nsamp - ((c.nsamp - 1) / c.sink_block) * c.sink_block, 0);
   if (need_gather) add(MCX_PLAN_GATHER_BEGIN, c.nsamp, 0, 0);  // remote slots end as of the last sync point
   if (c.sharded) add(MCX_PLAN_GATHER_WAIT, c.nsamp, 0, 0);
   add(MCX_PLAN_PUBLISH, c.nsamp, 0, 0);
@@ -1105,16 +1145,77 @@ static std::vector<mcx_plan_item> build_plan(const PlanCfg &c)
 }
 
 extern "C" int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed, uint32_t tbase, int nshards,
-                        int eager, int fused, int max_segment, int has_output_hook, mcx_plan_item *items,
-                        int max_items, int *nitems)
+                        int eager, int fused, int max_segment, int has_output_hook, int sink_block_steps,
+                        mcx_plan_item *items, int max_items, int *nitems)
 {
-  if (nsamp < 0 || nburn < 0 || sync < 1 || nshards < 1 || max_segment < 1 || !nitems)
+  if (nsamp < 0 || nburn < 0 || sync < 1 || nshards < 1 || max_segment < 1 || sink_block_steps < 0 || !nitems)
     return fail(MCX_ERR_INVALID, "bad arguments");
-  const PlanCfg c = {nsamp, nburn, sync, pl, seed, tbase, nshards > 1, eager != 0, fused != 0, has_output_hook != 0, max_segment};
+  const PlanCfg c = {nsamp, nburn, sync, pl, seed, tbase, nshards > 1, eager != 0, fused != 0, has_output_hook != 0, max_segment,
+                     sink_block_steps};
   const std::vector<mcx_plan_item> p = build_plan(c);
   *nitems = (int)p.size();
   if (items)
     for (int i = 0; i < (int)p.size() && i < max_items; ++i) items[i] = p[(size_t)i];
+  return MCX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming sample sink (mcx_set_sink).  Block number seq (main-loop steps [done - nsteps, done)) has just been
+// queued on the step stream: note its maximum-likelihood sample, then stage it out on the copy stream -- rows
+// interleaved into MCout's layout on the device, one D2H into pinned memory -- while the step stream runs on.
+// Two staging buffers: before block seq may take buffer seq % 2, the consumer is given block seq - 2 (the host
+// waits for THAT copy only; the device ring holds SINK_RING = 4 blocks, so steps are never held up by a slot
+// that is still being read as long as the consumer keeps up).
+// ---------------------------------------------------------------------------------------------
+static int sink_deliver(mcx_engine *e, int seq)
+{
+  const int b = seq & 1;
+  HIPCHK(hipEventSynchronize(e->ev_copy[b]));
+  const int first = seq * e->run_kb;  // kept steps before this block
+  const int kept = std::min(e->run_kb, (e->last_sink_total - first));
+  if (e->sfn(e->sctx, first, kept, e->sink_pin[b].p) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
+  return MCX_OK;
+}
+
+static int sink_block_done(mcx_engine *e, int done, int nsteps, int seq)
+{
+  const int n = e->nchain, d = e->nparam, b = seq & 1;
+  const int first_step = done - nsteps;  // the block's first main-loop step: a multiple of the block length
+  float *vx, *vl;
+  samp_vbase(e, first_step, &vx, &vl);
+  const size_t row0 = (size_t)(first_step / e->opt_stride);
+  const size_t kept = (size_t)((done + e->opt_stride - 1) / e->opt_stride) - row0;
+  const float *sx = vx + row0 * e->ntot, *sl = vl + row0 * n;
+  e->last_sink_total = (int)(row0 + kept);
+  // running maximum (src/mcout.cc:140-144), on the step stream: cheap, and ordered before the slot's reuse
+  hipLaunchKernelGGL(k_argmax_first, dim3(std::min<unsigned>(nblocks(kept * n), 1024u)), dim3(BLOCK), 0, e->stream, sl, kept * n, e->best_key.p);
+  hipLaunchKernelGGL(k_best_update, dim3(1), dim3(BLOCK), 0, e->stream, e->best_key.p, sl, sx, d, e->best_row.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev_steps[b], e->stream));
+  if (seq >= 2) MCXCHK(sink_deliver(e, seq - 2));  // frees staging buffer b
+  HIPCHK(hipStreamWaitEvent(e->cstream, e->ev_steps[b], 0));
+  hipLaunchKernelGGL(k_rows_interleave, dim3(nblocks(kept * n * (d + 1))), dim3(BLOCK), 0, e->cstream, sx, sl,
+                     e->sink_stage[b].p, kept * n, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(e->sink_pin[b].p, e->sink_stage[b].p, kept * n * (d + 1) * sizeof(float), hipMemcpyDeviceToHost, e->cstream));
+  HIPCHK(hipEventRecord(e->ev_copy[b], e->cstream));
+  // the ring: block seq + SINK_RING - 1 will overwrite the slot of block seq - 1, whose copy is already waited for
+  // two blocks from now at the latest; with SINK_RING = 4 the host-side wait above is the only synchronisation
+  return MCX_OK;
+}
+
+static int sink_drain(mcx_engine *e, int nblocks_done)
+{
+  for (int seq = std::max(0, nblocks_done - 2); seq < nblocks_done; ++seq) MCXCHK(sink_deliver(e, seq));
+  return MCX_OK;
+}
+
+extern "C" int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_steps)
+{
+  if (!e || (fn && block_steps < 1)) return fail(MCX_ERR_INVALID, "bad arguments");
+  e->sfn = fn;
+  e->sctx = ctx;
+  e->sink_block = fn ? block_steps : 0;
   return MCX_OK;
 }
 
@@ -1133,11 +1234,32 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   // sample store: every chain, every main-loop step (src/mcpar.cc:31-40, 177-182), kept in HBM
   e->samp_steps = 0;
   const int nkeep = (nsamp + e->opt_stride - 1) / e->opt_stride;  // kept steps: isamp % stride == 0
+  // sink mode: a ring of SINK_RING blocks instead of the whole run (block length a multiple of the stride)
+  const bool sink = e->sfn != nullptr && e->opt_samples && nsamp > 0;
+  const int sblock = sink ? ((std::max(e->sink_block, 1) + e->opt_stride - 1) / e->opt_stride) * e->opt_stride : 0;
+  const int kb = sink ? sblock / e->opt_stride : 0;
+  e->run_sink = sink; e->run_sblock = sblock; e->run_kb = kb;
   if (e->opt_samples && nsamp > 0) {
-    int s1 = e->samp_x.alloc((size_t)nkeep * e->ntot), s2 = e->samp_ly.alloc((size_t)nkeep * n);
+    const size_t rows = sink ? (size_t)std::min<long long>((long long)SINK_RING * kb, nkeep + kb) : (size_t)nkeep;
+    int s1 = e->samp_x.alloc(rows * e->ntot), s2 = e->samp_ly.alloc(rows * n);
     if (s1 != MCX_OK || s2 != MCX_OK)
       return fail(MCX_ERR_ALLOC, "Unable to allocate space for output samples (%zu bytes)",
-                  (size_t)nkeep * n * (d + 1) * sizeof(float));
+                  rows * n * (d + 1) * sizeof(float));
+  }
+  if (sink) {
+    for (int b = 0; b < 2; ++b) {
+      MCXCHK(e->sink_stage[b].alloc((size_t)kb * n * (d + 1)));
+      MCXCHK(e->sink_pin[b].alloc((size_t)kb * n * (d + 1)));
+      if (!e->ev_steps[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_steps[b], hipEventDisableTiming));
+      if (!e->ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_copy[b], hipEventDisableTiming));
+    }
+    if (!e->cstream) HIPCHK(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+  }
+  MCXCHK(e->best_row.alloc((size_t)d + 1));
+  MCXCHK(e->best_key.alloc(1));
+  if (sink) {
+    hipLaunchKernelGGL(k_best_reset, dim3(nblocks((size_t)d + 1)), dim3(BLOCK), 0, st, e->best_row.p, d, e->best_key.p);
+    HIPCHK(hipGetLastError());
   }
   if (e->opt_mask) {
     MCXCHK(e->mask.alloc((size_t)(nburn + nsamp) * n));
@@ -1193,9 +1315,10 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   sa.trash = nullptr;
 
   const PlanCfg cfg = {nsamp, nburn, e->SYNCSTEP, e->PLOCAL, e->seed, e->tbase, e->size > 1, e->opt_eager != 0,
-                       fused, e->ofn != nullptr, e->opt_maxseg};
+                       fused, e->ofn != nullptr, e->opt_maxseg, sink ? sblock : 0};
   const std::vector<mcx_plan_item> plan = build_plan(cfg);
   bool sig_done = false, slots_used = false;
+  int sink_seq = 0;
   for (size_t pi = 0; pi < plan.size(); ++pi) {
     const mcx_plan_item &it = plan[pi];
     if (persist && (it.kind == MCX_PLAN_BURN_SEGMENT || it.kind == MCX_PLAN_INIT_MOMENTS || it.kind == MCX_PLAN_MAIN_SEGMENT)) {
@@ -1221,7 +1344,8 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
         RunArgs ra;
         ra.x = e->pvals.p; ra.ly = e->lylast.p; ra.mu = e->mu.p; ra.psum2 = e->psum2.p; ra.sig = e->sig.p;
         ra.acc_cnt = e->acc_cnt.p; ra.T = e->cov.p;
-        ra.samp_x = e->opt_samples ? e->samp_x.p : nullptr; ra.samp_ly = e->opt_samples ? e->samp_ly.p : nullptr;
+        ra.samp_x = ra.samp_ly = nullptr;
+        if (e->opt_samples && pm > 0) samp_vbase(e, is0, &ra.samp_x, &ra.samp_ly);
         ra.samp_stride = e->opt_stride;
         MCXCHK(e->trash.alloc(4 * (size_t)PBLOCK * (size_t)std::max(e->ncu, 1)));
         ra.trash = e->trash.p;
@@ -1299,6 +1423,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       e->samp_steps = e->opt_samples ? (isamp + e->opt_stride - 1) / e->opt_stride : 0;
       if (e->ofn(e->octx, isamp) != 0) return fail(MCX_ERR_INVALID, "output hook failed");
       break;
+    case MCX_PLAN_SINK: MCXCHK(sink_block_done(e, isamp, steps, sink_seq++)); break;
     case MCX_PLAN_PUBLISH: MCXCHK(publish(e, isamp)); break;
     case MCX_PLAN_GATHER_BEGIN: MCXCHK(exchange_begin(e)); break;  // src/mcpar.cc:127-140
     case MCX_PLAN_GATHER_WAIT: MCXCHK(exchange_wait(e)); break;
@@ -1319,8 +1444,10 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
       if (fused) {
         const size_t row0 = e->opt_stride == 1 ? (size_t)isamp : 0;  // thinned: the kernel indexes from step 0
-        sa.samp_x = e->opt_samples ? e->samp_x.p + row0 * e->ntot : nullptr;
-        sa.samp_ly = e->opt_samples ? e->samp_ly.p + row0 * n : nullptr;
+        float *vx = nullptr, *vl = nullptr;
+        if (e->opt_samples) samp_vbase(e, isamp, &vx, &vl);
+        sa.samp_x = e->opt_samples ? vx + row0 * e->ntot : nullptr;
+        sa.samp_ly = e->opt_samples ? vl + row0 * n : nullptr;
         sa.mask = e->opt_mask ? e->mask.p + (size_t)(nburn + isamp) * n : nullptr;
         sa.nsteps = steps; sa.t0 = t; sa.isamp0 = isamp;
         sa.snap_after = it.aux;
@@ -1361,7 +1488,8 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   HIPCHK(hipStreamSynchronize(st));
   e->cnt.naccept_burn = hctr[3];
   e->cnt.naccept_main = hctr[4];
-  e->samp_steps = e->opt_samples ? nkeep : 0;
+  if (sink) MCXCHK(sink_drain(e, sink_seq));
+  e->samp_steps = (e->opt_samples && !sink) ? nkeep : 0;
   e->last_nsamp = nsamp;
   e->last_nburn = nburn;
   e->have_run = true;
@@ -1601,18 +1729,24 @@ extern "C" int mcx_samples_maxlike(mcx_engine *e, float *lmax, float *params)
 {
   MCXCHK(enter(e));
   if (!e || !lmax || !params) return fail(MCX_ERR_INVALID, "bad arguments");
-  const size_t n = (size_t)e->nchain, d = (size_t)e->nparam, nr = (size_t)e->samp_steps * n;
-  if (nr == 0) return fail(MCX_ERR_INVALID, "sample store is empty");
-  std::vector<float> hl(nr);
-  MCXCHK(d2h(e, hl.data(), e->samp_ly.p, nr));
-  size_t best = 0;
-  float bv = -INFINITY;
-  bool any = false;
-  for (size_t r = 0; r < nr; ++r)  // first strict maximum, like MCout::add (src/mcout.cc:140)
-    if (hl[r] > bv) { bv = hl[r]; best = r; any = true; }
-  *lmax = bv;
-  if (any) MCXCHK(d2h(e, params, e->samp_x.p + best * d, d));
-  else std::fill(params, params + d, 0.0f);
+  const size_t n = (size_t)e->nchain, d = (size_t)e->nparam;
+  if (!e->run_sink) {  // arg-max over the whole HBM-resident store, on the device (first strict maximum, src/mcout.cc:140)
+    const size_t nr = (size_t)e->samp_steps * n;
+    if (nr == 0) return fail(MCX_ERR_INVALID, "sample store is empty");
+    if (nr > 0xfffffff0ull) return fail(MCX_ERR_UNSUPPORTED, "sample store too large for the arg-max key");
+    MCXCHK(e->best_row.alloc(d + 1));
+    MCXCHK(e->best_key.alloc(1));
+    hipLaunchKernelGGL(k_best_reset, dim3(nblocks(d + 1)), dim3(BLOCK), 0, e->stream, e->best_row.p, (int)d, e->best_key.p);
+    hipLaunchKernelGGL(k_argmax_first, dim3(std::min<unsigned>(nblocks(nr), 2048u)), dim3(BLOCK), 0, e->stream, e->samp_ly.p, nr, e->best_key.p);
+    hipLaunchKernelGGL(k_best_update, dim3(1), dim3(BLOCK), 0, e->stream, e->best_key.p, e->samp_ly.p, e->samp_x.p, (int)d, e->best_row.p);
+    HIPCHK(hipGetLastError());
+  } else if (!e->have_run) {
+    return fail(MCX_ERR_INVALID, "sample store is empty");
+  }
+  std::vector<float> h(d + 1);
+  MCXCHK(d2h(e, h.data(), e->best_row.p, d + 1));
+  *lmax = h[0];
+  std::copy(h.begin() + 1, h.end(), params);
   return MCX_OK;
 }
 

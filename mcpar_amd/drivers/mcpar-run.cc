@@ -22,7 +22,7 @@ int main(int argc, char *argv[])
   std::string func = "rosen1";
   int np = 16, nc = 4096, nsamp = 100, nburn = 500, sync = 10, ncomp = 8;
   float pl = 1.0f;
-  bool quiet = false, iter = false;
+  bool quiet = false, iter = false, binary = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : "0"; };
@@ -36,6 +36,7 @@ int main(int argc, char *argv[])
     else if (a == "--ncomp") ncomp = atoi(val());
     else if (a == "--quiet") quiet = true;
     else if (a == "--iter") iter = true;
+    else if (a == "--binary") binary = true;  // rows as raw float32 (np+1 per row) instead of text
     else { std::cerr << "unknown option " << a << "\n"; return 2; }
   }
   MPI_Init(&argc, &argv);
@@ -65,6 +66,7 @@ int main(int argc, char *argv[])
 
   std::ostringstream sink;
   MCout rslts(np, (quiet || iter) ? static_cast<std::ostream *>(&sink) : &std::cout, MPI_COMM_WORLD);
+  rslts.binary(binary);
   std::vector<float> pinit((size_t)nc * np);
   for (int j = 0; j < nc; ++j)
     for (int i = 0; i < np; ++i)

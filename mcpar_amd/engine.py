@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (HOSTFN, K_NAMES, OUTFN, XCHGFN, Counters, PlanItem, Profile, VLFunc, check, load)
+from ._lib import (HOSTFN, K_NAMES, OUTFN, SINKFN, XCHGFN, Counters, PlanItem, Profile, VLFunc, check, load)
 
 VL_ROSENBROCK1, VL_ROSENBROCK2, VL_GAUSSIAN, VL_DUALGAUSS, VL_GAUSSMIX, VL_HOST = 1, 2, 3, 4, 5, 100
 VL_DEVICE = 101
@@ -46,18 +46,18 @@ def vlfunc_eval(kind, d, x, params=None, ncomp=0):
 
 
 PLAN_NAMES = {1: "burn_segment", 2: "tuner", 3: "init_moments", 4: "output", 5: "publish", 6: "gather_begin",
-              7: "gather_wait", 8: "remote_step", 9: "main_segment"}
+              7: "gather_wait", 8: "remote_step", 9: "main_segment", 10: "sink"}
 
 
 def plan(nsamp, nburn, sync=10, pl=0.9, seed=8675309, tbase=0, nshards=1, eager=0, fused=1, max_segment=256,
-         has_output_hook=0):
+         has_output_hook=0, sink_block=0):
     """the launch schedule mcx_run executes for these settings (host logic only, needs no GPU)"""
     n = C.c_int(0)
     check(load().mcx_plan(nsamp, nburn, sync, pl, seed, tbase, nshards, eager, fused, max_segment, has_output_hook,
-                          None, 0, C.byref(n)))
+                          sink_block, None, 0, C.byref(n)))
     items = (PlanItem * max(1, n.value))()
     check(load().mcx_plan(nsamp, nburn, sync, pl, seed, tbase, nshards, eager, fused, max_segment, has_output_hook,
-                          items, n.value, C.byref(n)))
+                          sink_block, items, n.value, C.byref(n)))
     return [(PLAN_NAMES[it.kind], it.first, it.nsteps, it.aux) for it in items[:n.value]]
 
 
@@ -166,6 +166,26 @@ class Engine:
         cb = OUTFN(tramp)
         self._keep.append(cb)
         check(load().mcx_set_output_hook(self.h, cb, None))
+
+    def set_sink(self, pyfn, block_steps):
+        """pyfn(first_step, nsteps, rows[nsteps*nc, np+1]) -> 0; rows is a view of pinned memory valid during the call.
+        pyfn = None removes the sink."""
+        if pyfn is None:
+            check(load().mcx_set_sink(self.h, SINKFN(), None, 0))
+            return
+        nc, ncol = self.nc, self.np + 1
+
+        def tramp(ctx, first, nsteps, rows):
+            try:
+                view = np.ctypeslib.as_array(rows, shape=(nsteps * nc, ncol))
+                return int(pyfn(first, nsteps, view) or 0)
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = SINKFN(tramp)
+        self._keep.append(cb)
+        check(load().mcx_set_sink(self.h, cb, None, int(block_steps)))
 
     def stage_pinit(self, pinit):
         """put the initial chain state in HBM ahead of time; run(..., pinit=None, ...) starts from it"""

@@ -69,7 +69,7 @@ def test_header_is_plain_c99(tmp_path):
     src = tmp_path / "cabi.c"
     src.write_text('#include "mcx.h"\nint main(void){ mcx_vlfunc f = {MCX_VL_ROSENBROCK1, 2, 0, 0, 0, 0}; (void)f;\n'
                    ' mcx_plan_item it; int n = 0; (void)it;\n'
-                   ' if (mcx_plan(10, 60, 10, 0.9f, 1u, 0u, 1, 0, 1, 256, 0, 0, 0, &n) != MCX_OK || n < 3) return 2;\n'
+                   ' if (mcx_plan(10, 60, 10, 0.9f, 1u, 0u, 1, 0, 1, 256, 0, 0, 0, 0, &n) != MCX_OK || n < 3) return 2;\n'
                    ' return mcx_abi_version() == MCX_ABI_VERSION ? 0 : 1; }\n')
     exe = tmp_path / "cabi"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),

@@ -111,3 +111,23 @@ def test_second_run_uses_the_advanced_step_counter():
     rb = [it[1] for it in b if it[0] == "remote_step"]
     assert ra != rb
     assert rb == [s for s in range(200) if coin_remote(s, 50, 10, 0.8, tbase=250)]
+
+
+def test_sink_blocks_cut_the_main_loop():
+    """mcx_set_sink: the main loop is cut at multiples of the block length, every block is handed over once, in
+    order, the last (partial) one at the end; no launch straddles a block"""
+    for nsamp, block, pl in ((100, 10, 1.0), (95, 25, 0.8), (7, 10, 1.0), (40, 1, 0.9), (256, 64, 1.0)):
+        p = get_plan(nsamp=nsamp, nburn=60, pl=pl, sink_block=block, max_segment=4096)
+        sinks = [(f, n) for k, f, n, a in p if k == "sink"]
+        want = [(min(b + block, nsamp), min(block, nsamp - b)) for b in range(0, nsamp, block)]
+        assert sinks == want, (nsamp, block, sinks)
+        done = 0
+        for k, f, n, a in p:
+            if k in ("main_segment", "remote_step"):
+                assert f == done and f // block == (f + n - 1) // block  # inside one block
+                done += n
+            if k == "sink":
+                assert f == done
+        assert done == nsamp
+        q = get_plan(nsamp=nsamp, nburn=60, pl=pl, sink_block=0, max_segment=4096)
+        assert not any(k == "sink" for k, *_ in q)
