@@ -58,11 +58,12 @@ for cfg in ("c3", "c2", "c5", "c3-murray"):
     if not table:
         continue
     json.dump({"source": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --pmc-child --config %s (one pass per counter "
-                         "group: FETCH_SIZE | WRITE_SIZE | SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES | GRBM_GUI_ACTIVE), spawned "
+                         "group, see PMC_PASSES in bench.py), spawned "
                          "by bench.py itself; FETCH_SIZE/WRITE_SIZE in KB" % cfg, "kernels": table},
               open(os.path.join(pr, "%s_%s_pmc_counters.json" % (rnd, cfg)), "w"), indent=1)
     d = line["config"]["nparam"] if line else 16
-    main = [k for k in table if "k_fused_fast<%d, true" % lpc_for(d) in k]
+    match = (line or {}).get("roofline", {}).get("kernel_match") or "k_fused_fast<%d, true" % lpc_for(d)
+    main = [k for k in table if match in k]
     if not main:
         continue
     m = table[main[0]]
@@ -70,9 +71,9 @@ for cfg in ("c3", "c2", "c5", "c3-murray"):
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         res["traffic_bytes_per_launch"] = (2 * m["FETCH_SIZE"]["mean"] + m["WRITE_SIZE"]["mean"]) * 1024
         res["traffic_formula"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM)"
-    if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m:
-        res["valu_busy_fraction"] = 4 * m["SQ_ACTIVE_INST_VALU"]["mean"] / (1024 * m["GRBM_GUI_ACTIVE"]["mean"] / 8)
-        res["valu_formula"] = "4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8)"
+    if line and line.get("roofline") and line["roofline"].get("frac") is not None:
+        res["valu_busy_fraction"] = line["roofline"]["frac"]  # as bench.py computed it live from these counters
+        res["valu_formula"] = line["roofline"].get("formula")
         res["SQ_INSTS_VALU"] = m.get("SQ_INSTS_VALU", {}).get("mean")
     json.dump(res, open(os.path.join(pr, "%s_%s_fused_kernel_counters.json" % (rnd, cfg)), "w"), indent=1)
     print(cfg, {k: v for k, v in res.items() if k in ("traffic_bytes_per_launch", "valu_busy_fraction")})
