@@ -265,7 +265,16 @@ def main():
         # RCCL unique id) on a gloo group; the data path is libmcx's own ncclAllGather
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
-        dist.init_process_group("gloo")
+        # gloo announces its connections on the C-level stdout: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         if args.one_device:
             local_rank = 0
             args.exchange = "staged"
