@@ -688,8 +688,9 @@ static int eval_trials(mcx_engine *e, const float *x_dev, float *y_dev, uint64_t
     HIPCHK(hipMemcpyAsync(e->h_ptrial.p, x_dev, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     (void)e->lik.fn(e->lik.ctx, n, e->h_ptrial.p, e->h_lytrial.p);  // return code ignored like the reference
+    // no second synchronisation: h_lytrial is pinned and is next written by the callback of the NEXT step, which
+    // runs only after that step's D2H -- queued behind this copy on the same stream -- has been waited for
     HIPCHK(hipMemcpyAsync(y_dev, e->h_lytrial.p, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));  // the callback may reuse nothing, but the next step rewrites h_lytrial
     return MCX_OK;
   }
   ProfScope ps(e, MCX_K_EVAL, cs);

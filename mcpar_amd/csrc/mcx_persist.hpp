@@ -338,16 +338,17 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
         float *lq = lbuf + ((size_t)(buf * K) * OWN + wv) * CPW + lane / LPC;
         float4 zn = *zp;
         float lun = *up;
-        for (int s = 0; s < ns; ++s) {
+        // proposal, likelihood, acceptance (src/mcpar.cc:302-312, 62-75); returns the chains of the wave that accepted.
+        // The next step's numbers are fetched first: they are on their way while this step computes.
+        auto metropolis = [&](int s) -> uint32_t {
           const float4 z = zn;
           const float lu = lun;
-          if (s + 1 < ns) {  // the next step's numbers are on their way while this one computes
+          if (s + 1 < ns) {
             zp += (size_t)OWN * 64;
             up += (size_t)OWN * CPW;
             zn = *zp;
             lun = *up;
           }
-          // proposal, likelihood, acceptance (src/mcpar.cc:302-312, 62-75)
           const f32x2 pe = fma2(te, f32x2{z.x, z.y}, xe), po = fma2(to, f32x2{z.z, z.w}, xo);
           const float lyt = loglike(pe, po);
           const bool take = accept_local(lyt, ly, lu);
@@ -355,15 +356,49 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
           xo = take ? po : xo;
           ly = take ? lyt : ly;
           cnt += take ? 1u : 0u;
-          const uint32_t wa = (uint32_t)__popcll(__ballot(take && q == 0));
-          if (s >= nb) {
-            macc += wa;
-            if (REC) {  // main-loop step: hand the state to the recorder (every lane of a chain writes the same ly)
-              *xq = make_float4(xe.x, xe.y, xo.x, xo.y);
-              *lq = ly;
-              xq += (size_t)OWN * 64;
-              lq += (size_t)OWN * CPW;
-            } else {  // no recorders (the run is bound by the generators' throughput, not by this wave's latency)
+          return (uint32_t)__popcll(__ballot(take && q == 0));
+        };
+        // Two loops, not one with a branch: the main-loop steps write to LDS, and a wait shared by both kinds of
+        // step would have to cover those writes (LDS operations retire in order) on every step.
+        int s = 0;
+        for (; s < nb; ++s) {  // ---- burn-in steps (src/mcpar.cc:58-75)
+          wacc += metropolis(s);
+          if (tau0 + s == next_event) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
+            const int last = next_event;
+            const int steps = last - seg_start + 1, check = last > irate ? 1 : 0;
+            const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent]);
+            ++nevent;
+            wacc = 0;
+            tun_na += seg;
+            tun_nt += (unsigned long long)steps * (unsigned long long)a.n;
+            burn_acc += seg;
+            if (check) {
+              const float arate = (float)tun_na / (float)tun_nt;
+              float f = 1.0f;
+              if (arate < a.armin) { tun_na = tun_nt = 0; f = a.dfac; }
+              else if (arate > a.armax) { tun_na = tun_nt = 0; f = a.ifac; }
+              if (f != 1.0f) { te = te * splat2(f); to = to * splat2(f); }
+              if (blockIdx.x == 0 && wv == 0 && lane == 0) {  // lane 0 of the grid holds T[0][0]
+              const int kk = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
+              if (kk < 256) a.trace[kk] = te.x;
+              }
+              ++ntrace_local;
+              irate += 50;
+            }
+            seg_start = last + 1;
+            next_event = irate + 1 < a.nburn ? irate + 1 : a.nburn - 1;
+            }
+        }
+        xq += (size_t)nb * OWN * 64;
+        lq += (size_t)nb * OWN * CPW;
+        for (; s < ns; ++s) {  // ---- main-loop steps (src/mcpar.cc:152-209)
+          macc += metropolis(s);
+          if (REC) {  // hand the state to the recorder (every lane of a chain writes the same ly)
+            *xq = make_float4(xe.x, xe.y, xo.x, xo.y);
+            *lq = ly;
+            xq += (size_t)OWN * 64;
+            lq += (size_t)OWN * CPW;
+          } else {  // no recorders (the run is bound by the generators' throughput, not by this wave's latency)
               if (s == nb && tau0 + s == a.nburn && a.init_moments) {  // src/mcpar.cc:99-104
                 me = mo = splat2(0.0f);
                 se = so = splat2(FPEPS);
@@ -389,36 +424,6 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
                 }
                 kmod = kmod + 1 == sstride ? 0 : kmod + 1;
               }
-            }
-          } else {
-            wacc += wa;
-            xq += (size_t)OWN * 64;
-            lq += (size_t)OWN * CPW;
-            if (tau0 + s == next_event) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
-              const int last = next_event;
-              const int steps = last - seg_start + 1, check = last > irate ? 1 : 0;
-              const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent]);
-              ++nevent;
-              wacc = 0;
-              tun_na += seg;
-              tun_nt += (unsigned long long)steps * (unsigned long long)a.n;
-              burn_acc += seg;
-              if (check) {
-                const float arate = (float)tun_na / (float)tun_nt;
-                float f = 1.0f;
-                if (arate < a.armin) { tun_na = tun_nt = 0; f = a.dfac; }
-                else if (arate > a.armax) { tun_na = tun_nt = 0; f = a.ifac; }
-                if (f != 1.0f) { te = te * splat2(f); to = to * splat2(f); }
-                if (blockIdx.x == 0 && wv == 0 && lane == 0) {  // lane 0 of the grid holds T[0][0]
-                  const int kk = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
-                  if (kk < 256) a.trace[kk] = te.x;
-                }
-                ++ntrace_local;
-                irate += 50;
-              }
-              seg_start = last + 1;
-              next_event = irate + 1 < a.nburn ? irate + 1 : a.nburn - 1;
-            }
           }
         }
       }
