@@ -379,15 +379,15 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
               else if (arate > a.armax) { tun_na = tun_nt = 0; f = a.ifac; }
               if (f != 1.0f) { te = te * splat2(f); to = to * splat2(f); }
               if (blockIdx.x == 0 && wv == 0 && lane == 0) {  // lane 0 of the grid holds T[0][0]
-              const int kk = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
-              if (kk < 256) a.trace[kk] = te.x;
+                const int kk = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
+                if (kk < 256) a.trace[kk] = te.x;
               }
               ++ntrace_local;
               irate += 50;
             }
             seg_start = last + 1;
             next_event = irate + 1 < a.nburn ? irate + 1 : a.nburn - 1;
-            }
+          }
         }
         xq += (size_t)nb * OWN * 64;
         lq += (size_t)nb * OWN * CPW;
@@ -399,31 +399,31 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
             xq += (size_t)OWN * 64;
             lq += (size_t)OWN * CPW;
           } else {  // no recorders (the run is bound by the generators' throughput, not by this wave's latency)
-              if (s == nb && tau0 + s == a.nburn && a.init_moments) {  // src/mcpar.cc:99-104
-                me = mo = splat2(0.0f);
-                se = so = splat2(FPEPS);
+            if (s == nb && tau0 + s == a.nburn && a.init_moments) {  // src/mcpar.cc:99-104
+              me = mo = splat2(0.0f);
+              se = so = splat2(FPEPS);
+            }
+            const f32x2 w2 = splat2(wbuf[(p & 3) * PWAVES + s]);  // 1/pwgt, src/mcpar.cc:186-187
+            const f32x2 de = xe - me, dO = xo - mo;               // src/mcpar.cc:199-202
+            me = fma2(de, w2, me);
+            mo = fma2(dO, w2, mo);
+            se = fma2(de, xe - me, se);
+            so = fma2(dO, xo - mo, so);
+            if (tau0 + s - a.nburn == a.snap_after && live) {  // snapshot for the next exchange (src/mcpar.cc:202-208)
+              const f32x2 ve = se * w2, vo = so * w2;
+              float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
+              slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
+              slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
+            }
+            if (emit) {  // src/mcpar.cc:177-182
+              if (kmod == 0) {
+                *reinterpret_cast<float4 *>(sxv) = make_float4(xe.x, xo.x, xe.y, xo.y);
+                *slv = ly;  // every lane of the chain stores the same value
+                sxv += sxs;
+                slv += sls;
               }
-              const f32x2 w2 = splat2(wbuf[(p & 3) * PWAVES + s]);  // 1/pwgt, src/mcpar.cc:186-187
-              const f32x2 de = xe - me, dO = xo - mo;               // src/mcpar.cc:199-202
-              me = fma2(de, w2, me);
-              mo = fma2(dO, w2, mo);
-              se = fma2(de, xe - me, se);
-              so = fma2(dO, xo - mo, so);
-              if (tau0 + s - a.nburn == a.snap_after && live) {  // snapshot for the next exchange (src/mcpar.cc:202-208)
-                const f32x2 ve = se * w2, vo = so * w2;
-                float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
-                slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
-                slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
-              }
-              if (emit) {  // src/mcpar.cc:177-182
-                if (kmod == 0) {
-                  *reinterpret_cast<float4 *>(sxv) = make_float4(xe.x, xo.x, xe.y, xo.y);
-                  *slv = ly;  // every lane of the chain stores the same value
-                  sxv += sxs;
-                  slv += sls;
-                }
-                kmod = kmod + 1 == sstride ? 0 : kmod + 1;
-              }
+              kmod = kmod + 1 == sstride ? 0 : kmod + 1;
+            }
           }
         }
       }

@@ -43,8 +43,11 @@ def one_case(rng, idx):
     mask = int(rng.random() < 0.5)
     maxseg = int(rng.choice([1, 3, 16, 256]))
     stride = int(rng.choice([1, 1, 2, 5]))
+    persist = int(rng.choice([-1, -1, 0, 1]))   # small-n mode: one launch per run / per-segment kernels
+    split = int(rng.choice([-1, -1, 0, 1]))     # (persist off:) pre-generated normals or generated in the step kernel
+    sink = int(rng.choice([0, 0, 1, 3, 10, 64]))  # > 0: samples streamed through the sink in blocks of that many steps
     desc = dict(idx=idx, kind=kind, d=d, n=n, nburn=nburn, nsamp=nsamp, pl=pl, sync=sync, K=K, fullcov=incov is not None,
-                fuse=fuse, mask=mask, maxseg=maxseg, stride=stride)
+                fuse=fuse, mask=mask, maxseg=maxseg, stride=stride, persist=persist, split=split, sink=sink)
     p = (rng.normal(0, 0.7, (n, d))).astype(np.float32)
     vo, k1 = O.make_vlfunc(kind, d, params, K)
     eo = O.Engine(d, n, pl=pl, sync=sync)
@@ -55,6 +58,11 @@ def one_case(rng, idx):
     eg.set_option(E.OPT_FUSE, fuse)
     eg.set_option(E.OPT_MAX_SEGMENT, maxseg)
     eg.set_option(E.OPT_SAMPLE_STRIDE, stride)
+    eg.set_option(E.OPT_PERSIST, persist)
+    eg.set_option(E.OPT_SPLIT_RNG, split)
+    streamed = []
+    if sink:
+        eg.set_sink(lambda first, nsteps, rows: streamed.append((first, rows.copy())) and 0, sink)
     eg.run(nsamp, nburn, p, vg, incov)
     c = eg.counters
     assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main, desc
@@ -68,7 +76,18 @@ def one_case(rng, idx):
         a, b = getattr(eg, name), getattr(eo, name)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, desc)
     want = eo.samples.reshape(nsamp, n, d + 1)[::stride].reshape(-1, d + 1) if nsamp else np.zeros((0, d + 1), np.float32)
-    got = eg.samples
+    if sink:
+        assert [f for f, r in streamed] == sorted(f for f, r in streamed), desc
+        got = np.concatenate([r for f, r in streamed]) if streamed else np.zeros((0, d + 1), np.float32)
+        if nsamp:
+            ll = want[:, d]
+            ok = ll > -np.inf
+            lm, pm = eg.maxlike()
+            if ok.any():
+                i = int(np.argmax(np.where(ok, ll, -np.inf)))
+                assert lm == ll[i] and np.array_equal(pm.view(np.uint32), want[i, :d].view(np.uint32)), ("maxlike", desc)
+    else:
+        got = eg.samples
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), ("samples", desc)
 
 
