@@ -9,6 +9,10 @@
 #include "mcx_persist.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types only: librccl.so.1 is loaded at run time (mcx_rccl_*), never linked
 
 #include <algorithm>
@@ -364,6 +368,8 @@ struct mcx_engine {
   std::vector<float> h_cov, h_cov_dev, h_winv;  // h_cov_dev = what cov0 holds
   bool cov_pending = false;  // cov has not been reset to cov0 for the current run yet
   int ctr_set = 0;           // counter block of the current run (ring of CTR_RING blocks, zeroed when it wraps)
+  int meet_fd = -1;          // lock file of this GPU: at most one kernel with grid-wide meetings in flight (see meet_lock_open)
+  bool meet_held = false;    // this engine holds the lock: a launch with meetings may still be running
   // run bookkeeping
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -577,6 +583,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
     if (e->ev_copy[b]) (void)hipEventDestroy(e->ev_copy[b]);
   }
   e->best_row.release(); e->best_key.release(); e->cov0.release();
+  if (e->meet_fd >= 0) (void)close(e->meet_fd);
   if (e->cstream) (void)hipStreamDestroy(e->cstream);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -834,9 +841,12 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
   return MCX_OK;
 }
 
+static int meet_release(mcx_engine *e, bool stream_is_idle);
+
 static int exchange_wait(mcx_engine *e)
 {
   if (!e->xchg_pending) return MCX_OK;
+  MCXCHK(meet_release(e, false));
   e->xchg_pending = false;
   if (e->xfn(e->xctx, MCX_XCHG_WAIT, e->musigall.p, 2 * (size_t)e->ntot, e->rank, e->size, e->stream) != 0)
     return fail(MCX_ERR_EXCHANGE, "exchange hook failed in WAIT");
@@ -859,6 +869,7 @@ static int publish(mcx_engine *e, int steps_done)
 
 static int exchange_begin(mcx_engine *e)
 {
+  MCXCHK(meet_release(e, false));  // a hook may wait for other engines: never while holding the GPU's meeting lock
   MCXCHK(exchange_wait(e));
   if (e->xfn(e->xctx, MCX_XCHG_BEGIN, e->musigall.p, 2 * (size_t)e->ntot, e->rank, e->size, e->stream) != 0)
     return fail(MCX_ERR_EXCHANGE, "exchange hook failed in BEGIN");
@@ -1161,6 +1172,48 @@ extern "C" int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_run_small's tuner events are meetings of ALL its workgroups at a device counter: every workgroup of the
+// grid must be resident.  The grid is sized to fit the GPU on its own (one workgroup per CU), but two such
+// kernels dispatched at the same time -- two engines of one process, or two processes sharing a GPU -- could
+// each get part of the CUs and wait for the rest forever.  So a launch that contains meetings (burn-in steps)
+// holds an exclusive advisory lock on a per-GPU lock file until it has completed; launches without meetings
+// (main-loop steps only: workgroups are independent) need none.  flock() excludes both other processes and
+// other engines of this process (each engine has its own open file description).
+// ---------------------------------------------------------------------------------------------
+// the launch that took the lock has completed (or is waited for here): let the next one in
+static int meet_release(mcx_engine *e, bool stream_is_idle)
+{
+  if (!e->meet_held) return MCX_OK;
+  hipError_t se = hipSuccess;
+  if (!stream_is_idle) se = hipStreamSynchronize(e->stream);
+  (void)flock(e->meet_fd, LOCK_UN);
+  e->meet_held = false;
+  HIPCHK(se);
+  return MCX_OK;
+}
+
+static bool meet_lock_open(mcx_engine *e)
+{
+  if (e->meet_fd >= 0) return true;
+  char bus[64] = "gpu";
+  (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, e->device);
+  for (char *c = bus; *c; ++c)
+    if (*c == ':' || *c == '/') *c = '_';
+  const char *dirs[] = {getenv("TMPDIR"), "/tmp", "/dev/shm"};
+  for (const char *d : dirs) {
+    if (!d || !*d) continue;
+    const std::string path = std::string(d) + "/mcx_meet_" + bus + ".lock";
+    const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+    if (fd >= 0) {
+      (void)fchmod(fd, 0666);  // shared by every user of the GPU
+      e->meet_fd = fd;
+      return true;
+    }
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Streaming sample sink (mcx_set_sink).  Block number seq (main-loop steps [done - nsteps, done)) has just been
 // queued on the step stream: note its maximum-likelihood sample, then stage it out on the copy stream -- rows
 // interleaved into MCout's layout on the device, one D2H into pinned memory -- while the step stream runs on.
@@ -1170,6 +1223,7 @@ extern "C" int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed,
 // ---------------------------------------------------------------------------------------------
 static int sink_deliver(mcx_engine *e, int seq)
 {
+  MCXCHK(meet_release(e, false));  // (the consumer may take its time)
   const int b = seq & 1;
   HIPCHK(hipEventSynchronize(e->ev_copy[b]));
   const int first = seq * e->run_kb;  // kept steps before this block
@@ -1228,6 +1282,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   if (nsamp < 0 || nburn < 0) return fail(MCX_ERR_INVALID, "bad run arguments");
   if (!pinit && !e->pinit_staged) return fail(MCX_ERR_INVALID, "pinit is NULL and no state was staged (mcx_stage_pinit)");
   if (e->size > 1 && !e->xfn) return fail(MCX_ERR_EXCHANGE, "nshards > 1 needs mcx_set_exchange()");
+  MCXCHK(meet_release(e, false));  // (left over from a run that failed half-way)
   const int n = e->nchain, d = e->nparam;
   hipStream_t st = e->stream;
   MCXCHK(lik_setup(e->lik, L, d, st));
@@ -1285,7 +1340,8 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   const bool persist = fused && e->lpc <= 8 && fast_lik && e->diag && e->vec4 && !e->opt_mask && e->ncu > 0 &&
                        nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
                        mcxk_persist_lds_bytes(e->lpc, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
-                       (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0));
+                       (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0)) &&
+                       (nburn == 0 || meet_lock_open(e));
   // When the run opens with such a launch, the launch itself takes the initial state (and its likelihood,
   // src/mcpar.cc:47-53) and the factor as installed, and starts its counters afresh: no reset kernels at all.
   bool lead = persist && nburn + nsamp > 0;
@@ -1375,9 +1431,18 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
           e->published_steps = nsamp;
           sig_done = true;
         }
+        // tuner events inside: exclusive on this GPU until the kernel has completed.  The lock is given back at
+        // the run's next synchronisation with the stream -- before any user hook may block this thread, at the latest
+        // at the end of the run
+        if (pb > 0) {
+          if (flock(e->meet_fd, LOCK_EX) != 0) return fail(MCX_ERR_HIP, "cannot lock the GPU's meeting lock file");
+          e->meet_held = true;
+        }
         {
           ProfScope ps(e, MCX_K_RUN_SMALL, (uint64_t)(pb + pm) * n);
-          HIPCHK(mcxk_launch_persist(e->lpc, e->lik.kind, ra, st));
+          const hipError_t le = mcxk_launch_persist(e->lpc, e->lik.kind, ra, st);
+          if (le != hipSuccess) (void)meet_release(e, true);
+          HIPCHK(le);
         }
         pi = pj - 1;
         continue;
@@ -1421,6 +1486,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       break;
     case MCX_PLAN_OUTPUT:  // src/mcpar.cc:115-119
       HIPCHK(hipStreamSynchronize(st));
+      MCXCHK(meet_release(e, true));
       e->samp_steps = e->opt_samples ? (isamp + e->opt_stride - 1) / e->opt_stride : 0;
       if (e->ofn(e->octx, isamp) != 0) return fail(MCX_ERR_INVALID, "output hook failed");
       break;
@@ -1429,6 +1495,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     case MCX_PLAN_GATHER_BEGIN: MCXCHK(exchange_begin(e)); break;  // src/mcpar.cc:127-140
     case MCX_PLAN_GATHER_WAIT: MCXCHK(exchange_wait(e)); break;
     case MCX_PLAN_REMOTE_STEP: {  // src/mcpar.cc:152-175 with genRemote
+      MCXCHK(meet_release(e, false));  // (genRemote synchronises with the stream after every pass anyway)
       const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
       int npass = 0;
       MCXCHK(remote_device(e, t, e->pvals.p, e->musigall.p, e->ptrial.p, e->cfac.p, e->mutrial.p,
@@ -1486,7 +1553,11 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   unsigned long long hctr[8];
   MCXCHK(cov_reset(e));  // (a run without any step)
   HIPCHK(hipMemcpyAsync(hctr, ctrp, sizeof hctr, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    const hipError_t se = hipStreamSynchronize(st);
+    (void)meet_release(e, true);
+    HIPCHK(se);
+  }
   e->cnt.naccept_burn = hctr[3];
   e->cnt.naccept_main = hctr[4];
   if (sink) MCXCHK(sink_drain(e, sink_seq));

@@ -25,7 +25,10 @@
 //     takes the same decision from the same integers and rescales its own copy of the Cholesky diagonal.
 //
 // Same functions, same bits as the per-segment kernels (tests/test_gpu_run_parity.py, test_gpu_fuzz.py).
-// Every workgroup of the grid must be resident at once (grid <= number of CUs, checked by the launcher).
+// Every workgroup of a launch that contains tuner events must be resident at once: the grid is at most one
+// workgroup per CU, and the host holds a per-GPU lock while such a launch is in flight (mcx_engine.hip,
+// meet_lock_open), so no second kernel of this kind -- from this or any other process -- can take part of the
+// CUs and leave two kernels waiting for each other.  Launches of main-loop steps only have no meetings.
 #pragma once
 #include "mcx_device.hpp"
 
