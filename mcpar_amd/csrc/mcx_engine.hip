@@ -1422,6 +1422,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
         ra.nown = nown;
         const int nwg = std::min(nown, e->ncu);
         ra.own = (nown + nwg - 1) / nwg;
+        ra.ksteps = mcxk_persist_ksteps(e->lpc, ra.own);
         if (snap >= 0) {  // the kernel rewrites this shard's slot: no gather may still be reading it
           MCXCHK(exchange_wait(e));
           e->published_steps = is0 + snap + 1;

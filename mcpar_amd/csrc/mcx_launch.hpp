@@ -16,4 +16,5 @@ hipError_t mcxk_launch_generic_main(int lpc, int lik, const mcx::SegArgs &a, hip
 namespace mcx { struct RunArgs; }
 hipError_t mcxk_launch_persist(int lpc, int lik, const mcx::RunArgs &a, hipStream_t st);                // mcx_k_persist.hip
 size_t mcxk_persist_lds_bytes(int lpc, int own);
+int mcxk_persist_ksteps(int lpc, int own);
 constexpr size_t MCXK_PERSIST_LDS_LIMIT = (size_t)152 << 10;  // dynamic LDS a launch may ask for (160 KB per CU less the static part)

@@ -37,6 +37,7 @@ namespace mcx {
 constexpr int PBLOCK = 1024;          // 16 wavefronts: 4 per SIMD of one CU
 constexpr int PWAVES = PBLOCK / 64;
 constexpr int POWN_MAX = 4;
+constexpr int PKMAX = 32;             // most steps per phase (LDS double buffers hold 2 phases)
 constexpr int PEVENTS = 64;           // tuner events (steps 51, 101, ... and the end of the burn-in) one launch can hold
 
 struct RunArgs {
@@ -68,6 +69,7 @@ struct RunArgs {
   int *ntrace;
   int nown;                 // owner wavefronts in the whole grid = ceil(n * LPC / 64)
   int own;                  // owner wavefronts per workgroup (1..POWN_MAX)
+  int ksteps;               // steps per phase (mcxk_persist_ksteps: what the LDS double buffers hold, <= PKMAX)
 };
 
 // all owners of the grid meet; returns the sum of `mine` over the workgroups.  One atomic per workgroup:
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   __shared__ float lds_logw[8];
   __shared__ unsigned lds_sum, lds_cnt;
   __shared__ unsigned long long lds_out[PEVENTS];  // one result word per tuner event (never reused within a launch)
-  __shared__ float wbuf[4 * PWAVES];  // 1/pwgt of a phase's main-loop steps, by phase % 4 (written 1 ahead, read 1 behind)
+  __shared__ float wbuf[4 * PKMAX];  // 1/pwgt of a phase's main-loop steps, by phase % 4 (written 1 ahead, read 1 behind)
   if (LIK == LIK_MIX) {
     const int kd = a.ncomp * a.d;
     for (int i = threadIdx.x; i < kd; i += PBLOCK) lds_means[i] = a.lik[i];
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   }
   if (threadIdx.x == 0) { lds_sum = 0; lds_cnt = 0; }
   if (threadIdx.x < PEVENTS) lds_out[threadIdx.x] = ~0ull;
-  const int OWN = a.own, NREC = REC ? OWN : 0, K = PWAVES - OWN - NREC;
+  const int OWN = a.own, NREC = REC ? OWN : 0, K = a.ksteps;  // steps per phase: a multiple of the generator count
   const int T = a.nburn + a.nmain;
   const int nphase = (T + K - 1) / K;
   const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
           }
       } else if (lane < ns) {  // 1/pwgt (src/mcpar.cc:186-187), from the host-built table
         const int im = tau0 + lane - a.nburn;
-        wbuf[(phase & 3) * PWAVES + lane] = (im >= 0 && im < a.nmain) ? a.winv[a.isamp0 + im] : 1.0f;
+        wbuf[(phase & 3) * PKMAX + lane] = (im >= 0 && im < a.nmain) ? a.winv[a.isamp0 + im] : 1.0f;
       }
     }
   };
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
     sls = (mine && rec) ? rowl : 0;
   }
 
-  const int NG = PWAVES - OWN - NREC;  // pure generator waves (= K)
+  const int NG = PWAVES - OWN - NREC;  // pure generator waves
   __syncthreads();
   if (!owner) fill(0, wv - OWN, PWAVES - OWN);  // (nobody has anything to record yet)
   __syncthreads();
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
               me = mo = splat2(0.0f);
               se = so = splat2(FPEPS);
             }
-            const f32x2 w2 = splat2(wbuf[(p & 3) * PWAVES + s]);  // 1/pwgt, src/mcpar.cc:186-187
+            const f32x2 w2 = splat2(wbuf[(p & 3) * PKMAX + s]);  // 1/pwgt, src/mcpar.cc:186-187
             const f32x2 de = xe - me, dO = xo - mo;               // src/mcpar.cc:199-202
             me = fma2(de, w2, me);
             mo = fma2(dO, w2, mo);
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
           }
           const float4 *xq = xbuf + ((size_t)(pb * K + nb) * OWN + slot_o) * 64 + lane;
           const float *lq = lbuf + ((size_t)(pb * K + nb) * OWN + slot_o) * CPW + lane / LPC;
-          const float *wq = wbuf + ((p - 1) & 3) * PWAVES;
+          const float *wq = wbuf + ((p - 1) & 3) * PKMAX;
           for (int s = nb; s < ns; ++s) {
             const float4 xv = *xq;
             const float lyv = *lq;
