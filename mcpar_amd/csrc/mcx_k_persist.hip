@@ -16,8 +16,9 @@ static size_t lds_for(int lpc, int own, int rec, int K)
   return (size_t)2 * (1 + rec) * K * own * 64 * sizeof(float4) + (size_t)2 * (1 + rec) * K * own * (64 / lpc) * sizeof(float);
 }
 
-// steps per phase: the generators' count (16 - owners - recorders).  Twice that (the LDS double buffers would
-// hold it with one owner) was measured slower: 8-D x 4096 chains 0.355 ms against 0.319 ms per job.
+// steps per phase: the generators' count (16 - owners - recorders).  Measured on 8-D x 4096 chains (one owner,
+// 14 generators): 14 steps per phase 0.315 ms per job, 28 (the LDS double buffers would hold it) 0.355, 10 -> 0.364,
+// 7 -> 0.443: a phase must be long enough for one wavefront to finish a two-step generator item behind it.
 int mcxk_persist_ksteps(int lpc, int own)
 {
   (void)lpc;
