@@ -592,6 +592,11 @@ def main():
                              SQ_INSTS_VALU_MUL_F32=mul, SQ_INSTS_VALU_INT64=i64, SQ_INSTS_VALU_TRANS_F32=trans,
                              SQ_INSTS_VALU_IOPS=c_.get("SQ_INSTS_VALU_IOPS"), packed_f32_instructions_est=packed,
                              plain_instructions_est=plain, issue_cycles=issue,
+                             frac_at_measured_issue_intervals=(2.7 * plain + 4.7 * (packed + i64) + 8.2 * trans) / (N_SIMD * cyc),
+                             frac_at_measured_issue_intervals_note="same counters priced with the issue intervals tools/ubench.hip "
+                                                                   "measured on this chip at 4 waves/SIMD (full-rate 2.7 cycles, "
+                                                                   "v_pk_*_f32 / v_mad_u64_u32 4.7, v_sqrt_f32 8.2) instead of the "
+                                                                   "architectural 2 / 4 / 8",
                              fp32_TFLOPs=(flops * 64.0 / t_launch / 1e12),
                              fp32_frac_of_vector_peak=(flops * 64.0 / t_launch) / FP32_VALU_PEAK)
                     roofline.update(
