@@ -284,7 +284,8 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   case 8: { constexpr int DMAX_ = 8; CALL; } break;               \
   case 16: { constexpr int DMAX_ = 16; CALL; } break;             \
   case 32: { constexpr int DMAX_ = 32; CALL; } break;             \
-  default: return fail(MCX_ERR_UNSUPPORTED, "internal: register Murray kernels cover np <= 32"); \
+  case 64: { constexpr int DMAX_ = 64; CALL; } break;             \
+  default: return fail(MCX_ERR_UNSUPPORTED, "internal: register Murray kernels cover np <= 64"); \
   }
 
 // The fused-kernel families are compiled in their own translation units (mcx_k_fast.hip,
@@ -767,8 +768,8 @@ static int launch_accept(mcx_engine *e, const StepArgs &a, bool main)
 static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
                          float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
 {
-  const int n = e->nchain, d = e->nparam, N = e->tchains, dm = d <= 32 ? dmax_for(d) : 32;
-  const bool big = d > 32;
+  const int n = e->nchain, d = e->nparam, N = e->tchains, dm = d <= 64 ? dmax_for(d) : 64;
+  const bool big = d > 64;  // chain vector in registers up to np = 64, re-read from memory above
   const int S = (N + QBLOCK - 1) / QBLOCK;
   hipStream_t st = e->stream;
   ProfScope ps(e, MCX_K_REMOTE, (uint64_t)n);

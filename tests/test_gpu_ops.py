@@ -38,7 +38,7 @@ def test_gen_local_full_covariance_statistics():
         eg.covar_setup(-np.eye(d, dtype=np.float32))
 
 
-@pytest.mark.parametrize("d,n,nshards", [(2, 64, 1), (16, 300, 1), (8, 96, 3), (5, 40, 1), (32, 33, 2), (33, 40, 1), (80, 24, 2)])
+@pytest.mark.parametrize("d,n,nshards", [(2, 64, 1), (16, 300, 1), (8, 96, 3), (5, 40, 1), (32, 33, 2), (33, 40, 1), (48, 70, 1), (64, 65, 2), (65, 30, 1), (80, 24, 2)])
 def test_gen_remote(d, n, nshards):
     import mcpar_amd as M
     rng = np.random.default_rng(10 * d + nshards)
