@@ -143,7 +143,7 @@ def pmc_child(cfg, n):
     eng.close()
 
 
-def collect_pmc(config_name, n, keep_dir=None, budget_s=240.0):
+def collect_pmc(config_name, n, keep_dir=None, budget_s=150.0):
     """-> ({kernel: {counter: mean per dispatch}}, {kernel: mean duration ns under the profiler}, note).
     Each counter group is its own `rocprofv3 --pmc ... --kernel-trace` run of `bench.py --pmc-child`."""
     exe = shutil.which("rocprofv3")
@@ -162,7 +162,7 @@ def collect_pmc(config_name, n, keep_dir=None, budget_s=240.0):
         cmd = [exe, "--pmc", *group, "--kernel-trace", "-f", "csv", "-d", ddir, "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", config_name, "--chains", str(n)]
         try:
-            r = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150,
+            r = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=90,
                                env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
         except Exception as ex:  # noqa: BLE001
             return out or None, dur, "rocprofv3 %s: %r" % (",".join(group), ex)
