@@ -482,6 +482,25 @@ def main():
         j5.close()
         job = None
 
+    # ---- N > 1: the same total job split over the ranks (strong scaling; `value` above is weak scaling) ----------
+    strong_multi = None
+    if world > 1 and not args.strong and not args.no_extras and total % world == 0:
+        cs = dict(cfg)
+        ns_ = total // world
+        cs["n"] = ns_
+        js = make_job(cs, ns_, emit)
+        for _ in range(3):
+            js.run()
+        ks = max(10, args.steps)
+        ds_ = timed(js, ks)
+        strong_multi = dict(workload=workload_text(cs, ns_), chains_total=total, chains_per_gpu=ns_,
+                            value=float(total) * (nburn + nsamp) * ks / ds_, unit="chain-steps/s", steps=ks,
+                            ms_per_step=ds_ / ks * 1e3, exchanges_per_run=js.eng.counters["exchanges"],
+                            kernel_launches_per_run=js.eng.counters["kernel_launches"],
+                            what="the N = 1 job (%d chains in all) split evenly over the ranks: ms_per_step against the N = 1 "
+                                 "run's ms_per_step is the strong-scaling speed-up" % total)
+        js.close()
+
     # ---- N = 1 extras: end to end, other configurations, counters, CPU baseline ---------------------------
     if world == 1 and rank == 0:
         if emit and not args.no_extras:
@@ -636,6 +655,7 @@ def main():
                        "exchange_backend": state["backend"],
                        "reference_schedule": ref_sched,
                        "murray": murray_multi,
+                       "strong_scaling": strong_multi,
                        "accept_rate_main": cnt["naccept_main"] / float(n * nsamp) if nsamp else None,
                        "remote_steps": cnt["remote_steps"], "remote_passes": cnt["remote_passes"],
                        "value_with_host_pinit": value_host_pinit,
