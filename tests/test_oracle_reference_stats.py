@@ -51,3 +51,23 @@ def test_target_moments_rosenbrock_2d():
     s = e.samples.reshape(3000, 512, 3)[1000:, :, 0]
     assert abs(s.mean() - 1.0) < 0.1
     assert abs(s.var() - 0.5) < 0.1
+
+
+def test_murray_pass_count_growth_matches_the_reference():
+    """SURVEY fact 5 / §6, measured from the unmodified reference: 2-D unimodal Gaussian, 256 chains, nburn 500,
+    pl 0.9 -> 1 953 genRemote rejection passes at nsamp = 100, 25 936 at 400, 180 341 at 1600 (about 1 100 per remote
+    step at the end: the accept probability qimax/qisum tends to 1/N as the per-chain Gaussians converge), main-loop
+    accept rate 0.445 at nsamp = 1600.  The pass count is set by the whole moment machinery -- Welford updates, the
+    adoption of (mutrial, sigtrial) with psum2 = sig (pwgt - 1) on accepted remote proposals (src/mcpar.cc:189-197),
+    the (mu, sig^2) slots the sweep reads -- so it pins more than the accept rate does.  Different RNG: statistical."""
+    ref = {100: 1953, 400: 25936, 1600: 180341}
+    vl, keep = O.make_vlfunc(O.VL_GAUSSIAN, 2)
+    for nsamp, want in ref.items():
+        e = O.Engine(2, 256, pl=0.9, threads=8)
+        e.set_record(samples=False, mask=True)
+        e.run(nsamp, 500, O.default_pinit(2, 256), vl)
+        assert 0.55 * want < e.remote_passes < 1.6 * want, (nsamp, e.remote_passes, want)
+        assert abs(e.remote_steps - 0.1 * nsamp) < 4 * (0.09 * nsamp) ** 0.5 + 1  # the coin: pl = 0.9
+        if nsamp == 1600:
+            assert 800 < e.remote_passes / e.remote_steps < 1450  # reference: ~1 100 passes per remote step
+            assert abs(main_accept_rate(e, 500) - 0.445) < 0.02
