@@ -233,3 +233,26 @@ def test_c5_per_gpu_shape_two_shards_bit_exact():
         assert c["naccept_main"] == eo.naccept_main
         for name in ("state", "mean", "var", "musigall"):
             assert same_bits(getattr(eg, name), getattr(eo, name)), (s, name)
+
+
+def test_murray_many_passes_bit_exact():
+    """The regime SURVEY fact 5 measured on the reference: 2-D unimodal Gaussian, 256 chains, pl = 0.9 -- once the
+    per-chain Gaussians have converged a Murray step needs hundreds of rejection passes (21 674 in this run).
+    Every pass, every adoption of (mutrial, sigtrial) on an accepted remote proposal and every moment must equal
+    the oracle's."""
+    import mcpar_amd as M
+    d, n, nburn, nsamp = 2, 256, 500, 400
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(O.VL_GAUSSIAN, d)
+    eo = O.Engine(d, n, pl=0.9, threads=THREADS)
+    eo.set_record(samples=True, mask=False)
+    eo.run(nsamp, nburn, p, vo)
+    assert eo.remote_passes > 10000
+    vg, k2 = M.make_vlfunc(M.VL_GAUSSIAN, d)
+    eg = M.Engine(d, n, pl=0.9)
+    eg.run(nsamp, nburn, p, vg)
+    c = eg.counters
+    assert c["remote_steps"] == eo.remote_steps and c["remote_passes"] == eo.remote_passes
+    assert c["naccept_main"] == eo.naccept_main
+    for name in ("state", "loglike", "mean", "var", "musigall", "samples"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
