@@ -489,11 +489,78 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t owner, int 
 // (same functions, same bits) and are streamed in with a 4-step register prefetch ring.  With few
 // chains the fused kernel is bound by the latency of one wave's instruction stream, two thirds of which
 // is the random-number work -- which does not depend on the chain state and can run on the idle SIMDs.
-template <int LPC, bool MAIN, int LIK = LIK_ROSEN1, bool PREGEN = false>
+//
+// FULL: proposals x' = x + T z with the full lower-triangular Cholesky factor (src/mcpar.cc:302-312 with
+// covar_setup's factor, :454-484).  A lane needs its four rows of T and the whole z of its chain:
+//   * T is staged in LDS as [row in block k][column block qq][lane of the chain q][4 columns]: for a given
+//     (k, qq) the lanes of a wavefront read LPC consecutive 16-byte slots -- every ds_read_b128 lane group
+//     sees each slot's address on all its readers (broadcast) and no bank twice;
+//   * z travels as the DPP operand of the multiply-adds for chains of <= 4 lanes (no memory, no moves); chains of 8 lanes write
+//     their z block to LDS (9 slots per chain, so the four chains of a ds_read_b128 lane group sit on
+//     different banks) and read the 8 blocks back;
+//   * every lane runs all columns, in ascending order like the oracle's loop over k <= i: the entries above
+//     the diagonal are exact zeros and fma(0, z, acc) == acc (z is finite; acc = -0 would need x = -0).
+// One column block of the triangular product for chains of 2 or 4 lanes: p[k] = fma(T[k][c], z_qq[c], p[k]) for
+// c = 0..3 (ascending columns), the z operand taken straight from lane qq of the chain by the DPP operand of
+// v_fmac_f32 (fused, one rounding, like __builtin_fmaf) -- no separate broadcast moves.  The s_nop covers the
+// two wait states a DPP read needs after a VALU write of the same register, which the compiler cannot see
+// inside the asm.  PERM: the quad_perm selector.
+#define MCX_FMAC_DPP_BLOCK(PERM)                                                                              \
+  asm("s_nop 1\n\t"                                                                                           \
+      "v_fmac_f32_dpp %0, %4, %8 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                      \
+      "v_fmac_f32_dpp %1, %4, %12 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %2, %4, %16 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %3, %4, %20 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %0, %5, %9 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                      \
+      "v_fmac_f32_dpp %1, %5, %13 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %2, %5, %17 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %3, %5, %21 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %0, %6, %10 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %1, %6, %14 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %2, %6, %18 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %3, %6, %22 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %0, %7, %11 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %1, %7, %15 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %2, %7, %19 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
+      "v_fmac_f32_dpp %3, %7, %23 " PERM " row_mask:0xf bank_mask:0xf"                                          \
+      : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3])                                                        \
+      : "v"(zv[0]), "v"(zv[1]), "v"(zv[2]), "v"(zv[3]), "v"(t0.x), "v"(t0.y), "v"(t0.z), "v"(t0.w), "v"(t1.x), \
+        "v"(t1.y), "v"(t1.z), "v"(t1.w), "v"(t2.x), "v"(t2.y), "v"(t2.z), "v"(t2.w), "v"(t3.x), "v"(t3.y),     \
+        "v"(t3.z), "v"(t3.w))
+
+template <int LPC>
+__device__ __forceinline__ void fmac_dpp_block(float p[4], const float zv[4], int qq, float4 t0, float4 t1, float4 t2, float4 t3)
+{
+  if (LPC == 2) {
+    if (qq == 0) MCX_FMAC_DPP_BLOCK("quad_perm:[0,0,2,2]");
+    else MCX_FMAC_DPP_BLOCK("quad_perm:[1,1,3,3]");
+  } else {
+    switch (qq) {
+    case 0: MCX_FMAC_DPP_BLOCK("quad_perm:[0,0,0,0]"); break;
+    case 1: MCX_FMAC_DPP_BLOCK("quad_perm:[1,1,1,1]"); break;
+    case 2: MCX_FMAC_DPP_BLOCK("quad_perm:[2,2,2,2]"); break;
+    default: MCX_FMAC_DPP_BLOCK("quad_perm:[3,3,3,3]"); break;
+    }
+  }
+}
+
+template <int LPC, bool MAIN, int LIK = LIK_ROSEN1, bool PREGEN = false, bool FULL = false>
 __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
 {
   static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX,
                 "fast path: Rosenbrock1, diagonal Gaussian, or a mixture of <= 8 unit Gaussians");
+  static_assert(!(FULL && PREGEN), "the pre-generated normals are laid out for diagonal proposals");
+  __shared__ __attribute__((aligned(16))) float4 lds_T[FULL ? 4 * LPC * LPC : 1];
+  __shared__ __attribute__((aligned(16))) float4 lds_z[FULL && LPC == 8 ? (BLOCK / 8) * 9 : 1];
+  if (FULL) {
+    const int dd = a.d;
+    for (int i = threadIdx.x; i < 16 * LPC * LPC; i += BLOCK) {
+      const int c = i & 3, qv = (i >> 2) % LPC, qq = ((i >> 2) / LPC) % LPC, k = (i >> 2) / (LPC * LPC);
+      const int row = 4 * qv + k, col = 4 * qq + c;
+      reinterpret_cast<float *>(lds_T)[i] = (row < dd && col < dd) ? a.T[row * dd + col] : 0.0f;
+    }
+    if (LIK != LIK_MIX) __syncthreads();
+  }
   // mixture: component means and log-weights staged in LDS (every lane group reads the same rows)
   __shared__ __attribute__((aligned(16))) float lds_means[LIK == LIK_MIX ? 8 * MAXD_LDS : 4];
   __shared__ float lds_logw[8];
@@ -544,7 +611,41 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
 
   // one Metropolis step given this lane's four normals (ze = z0,z2; zo = z1,z3) and the log of the acceptance draw
   auto step = [&](int s, f32x2 ze, f32x2 zo, float u, float winv_s) {
-    const f32x2 pe = fma2(te, ze, xe), po = fma2(to, zo, xo);  // src/mcpar.cc:302-312
+    f32x2 pe, po;
+    if (!FULL) {
+      pe = fma2(te, ze, xe);  // src/mcpar.cc:302-312
+      po = fma2(to, zo, xo);
+    } else {
+      float p[4] = {xe.x, xo.x, xe.y, xo.y};
+      const float zv[4] = {ze.x, zo.x, ze.y, zo.y};
+      const int zslot = ((int)threadIdx.x >> 3) * 9;
+      if (LPC == 8) {
+        lds_z[zslot + q] = make_float4(zv[0], zv[1], zv[2], zv[3]);
+        __builtin_amdgcn_wave_barrier();  // a chain never spans wavefronts; LDS is in order per wavefront
+      }
+#pragma unroll
+      for (int qq = 0; qq < LPC; ++qq) {
+        if (LPC == 2 || LPC == 4) {
+          fmac_dpp_block<LPC>(p, zv, qq, lds_T[(0 * LPC + qq) * LPC + q], lds_T[(1 * LPC + qq) * LPC + q],
+                              lds_T[(2 * LPC + qq) * LPC + q], lds_T[(3 * LPC + qq) * LPC + q]);
+          continue;
+        }
+        float4 zz;
+        if (LPC == 8) zz = lds_z[zslot + qq];
+        else zz = make_float4(zv[0], zv[1], zv[2], zv[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 tr = lds_T[(k * LPC + qq) * LPC + q];
+          p[k] = __builtin_fmaf(tr.x, zz.x, p[k]);
+          p[k] = __builtin_fmaf(tr.y, zz.y, p[k]);
+          p[k] = __builtin_fmaf(tr.z, zz.z, p[k]);
+          p[k] = __builtin_fmaf(tr.w, zz.w, p[k]);
+        }
+      }
+      if (LPC == 8) __builtin_amdgcn_wave_barrier();  // this step's reads precede the next step's write
+      pe = f32x2{p[0], p[2]};
+      po = f32x2{p[1], p[3]};
+    }
     float acc = 0.0f;
     if (LIK == LIK_ROSEN1) {
       // src/rosenbrock.cc:4-21 on the pairs (x0,x1), (x2,x3)

@@ -293,7 +293,9 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
 static int launch_fused_plain(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st, bool fast)
 {
   hipError_t err;
+  const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
   if (fast) err = mcxk_launch_fast(lpc, lik, main, a, st);  // hot path
+  else if (lpc <= 8 && fast_lik && !a.diag && a.vec4 && !a.mask) err = mcxk_launch_fast_full(lpc, lik, main, a, st);
   else err = main ? mcxk_launch_generic_main(lpc, lik, a, st) : mcxk_launch_generic_burn(lpc, lik, a, st);
   if (err == hipErrorInvalidValue) return fail(MCX_ERR_UNSUPPORTED, "no fused kernel for lanes/chain = %d, likelihood %d", lpc, lik);
   HIPCHK(err);

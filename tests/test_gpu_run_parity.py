@@ -153,6 +153,25 @@ def test_full_covariance():
     assert_same(eo, eg, "fullcov16")
 
 
+@pytest.mark.parametrize("d", [4, 8, 12, 16, 20, 24, 28, 32])
+def test_full_covariance_fast_kernel(d):
+    """k_fused_fast<..., FULL>: the Cholesky factor staged in LDS, z by DPP (<= 4 lanes per chain) or through LDS
+    (8 lanes), every likelihood of the fast path, burn-in (tuner rescales the factor) + main loop."""
+    rng = np.random.default_rng(100 + d)
+    a = rng.normal(size=(d, d)).astype(np.float32)
+    cov = (0.3 * (a @ a.T / d + 0.5 * np.eye(d))).astype(np.float32)
+    n = 3 * 64 + 5  # several wavefronts, the last one ragged
+    eo, eg = run_pair(O.VL_ROSENBROCK1, d, n, 160, 45, 1.0, incov=cov)
+    assert_same(eo, eg, "fullcov fast rosen1 d%d" % d)
+    g = np.concatenate([rng.normal(size=d), rng.uniform(0.5, 2.0, size=d)]).astype(np.float32)
+    eo, eg = run_pair(O.VL_GAUSSIAN, d, n, 110, 30, 0.9, params=g, incov=cov)
+    assert_same(eo, eg, "fullcov fast gauss d%d" % d)
+    K = 3
+    m = np.concatenate([rng.normal(size=K * d), [2.0, 1.0, 1.0]]).astype(np.float32)
+    eo, eg = run_pair(O.VL_GAUSSMIX, d, n, 60, 30, 1.0, params=m, ncomp=K, incov=cov)
+    assert_same(eo, eg, "fullcov fast mix d%d" % d)
+
+
 def test_second_run_continues_rng():
     import mcpar_amd as M
     from mcpar_amd import engine as E
