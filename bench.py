@@ -197,7 +197,7 @@ def find_kernel(table, *needles):
 # one configuration on this rank's engine
 # ---------------------------------------------------------------------------------------------
 class Job:
-    def __init__(self, M, E, cfg, n, rank, world, emit=True, max_segment=0, rccl_id=None):
+    def __init__(self, M, E, cfg, n, rank, world, emit=True, max_segment=0):
         self.M, self.E, self.cfg, self.n = M, E, cfg, n
         self.eng = M.Engine(cfg["d"], n, nshards=world, shard=rank, pl=cfg["pl"])
         self.eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
@@ -206,8 +206,6 @@ class Job:
         self.vl, self._keep = make_lik(M, cfg)
         self.p = pinit_for(cfg["d"], n, rank * n)
         self.eng.stage_pinit(self.p)  # inputs resident in HBM before any timed region
-        if rccl_id is not None:
-            self.eng.rccl_init(rccl_id)
 
     def run(self, host_pinit=False):
         self.eng.run(self.cfg["nsamp"], self.cfg["nburn"], self.p if host_pinit else None, self.vl)
@@ -237,6 +235,8 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=("rccl", "staged"),
                     help="N > 1: rccl = the library's in-place ncclAllGather (default); staged = host-staged all-gather "
                          "over a gloo group (rehearsals on one GPU only)")
+    ap.add_argument("--try-rccl", action="store_true", help="with --one-device: attempt the RCCL communicator anyway (RCCL refuses two "
+                    "ranks on one GPU: rehearses the collective fallback to the staged exchange)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses device 0 (implies --exchange staged)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -277,7 +277,8 @@ def main():
             os.close(saved_fd)
         if args.one_device:
             local_rank = 0
-            args.exchange = "staged"
+            if not args.try_rccl:
+                args.exchange = "staged"
     import numpy as np
     import mcpar_amd as M
     from mcpar_amd import engine as E
@@ -335,12 +336,31 @@ def main():
         if world == 1:
             return Job(M, E, c, nn, 0, 1, emit_, args.max_segment)
         uid = new_rccl_id() if args.exchange == "rccl" else None
-        j = Job(M, E, c, nn, rank, world, emit_, args.max_segment, rccl_id=uid)
+        j = Job(M, E, c, nn, rank, world, emit_, args.max_segment)
+        why = "requested" if args.exchange == "staged" else "fallback: RCCL not loadable on every rank"
+        if uid is not None:
+            # communicator + one gather now: a broken fabric shows here, not inside the timed region.  Every rank
+            # learns whether ALL ranks succeeded, so the fallback is taken by all of them or by none.
+            err = ""
+            try:
+                j.eng.rccl_init(uid)
+                j.eng.debug_exchange()
+            except Exception as ex:  # MCX_ERR_EXCHANGE with the RCCL error string
+                err = str(ex)
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                try:
+                    j.eng.rccl_destroy()
+                except Exception:
+                    pass
+                uid = None
+                why = "fallback: " + (err or "RCCL failed on another rank")
+                print("bench: rank %d: RCCL exchange unavailable (%s); using the host-staged all-gather" % (rank, why), file=sys.stderr)
         if uid is None:
             staged_exchange(j.eng)
-            state["backend"] = "gloo, host-staged (%s)" % ("requested" if args.exchange == "staged" else "fallback: " + lib.mcx_last_error().decode())
+            state["backend"] = "gloo, host-staged (%s)" % why
         else:
-            j.eng.debug_exchange()  # one gather now: a broken fabric fails here, not inside the timed region
             state["backend"] = "rccl (libmcx in-place ncclAllGather on a side stream)"
         return j
 
