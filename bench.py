@@ -656,6 +656,27 @@ def main():
                 roofline["valu"] = v
             if "frac" not in roofline or "traffic" not in roofline:
                 fallback_from_profiles(roofline, note, args.config)
+            if murray is not None and pmc:
+                # the sweep kernels of the same child passes: how busy their VALU issue slots and their LDS are
+                vi = {}
+                need = ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_FLOPS_FP32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT64",
+                        "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32")
+                for kk2, c_ in pmc.items():
+                    if "k_remote_sweep" not in kk2 or not all(c in c_ for c in need):
+                        continue
+                    cyc2 = c_["GRBM_GUI_ACTIVE"] / 8.0
+                    fma, add, mul = c_["SQ_INSTS_VALU_FMA_F32"], c_["SQ_INSTS_VALU_ADD_F32"], c_["SQ_INSTS_VALU_MUL_F32"]
+                    base = 2.0 * fma + add + mul
+                    packed = min(max((c_["SQ_INSTS_VALU_FLOPS_FP32"] - base) / max(base, 1.0), 0.0), 1.0) * (fma + add + mul)
+                    plain = max(c_["SQ_INSTS_VALU"] - packed - c_["SQ_INSTS_VALU_INT64"] - c_["SQ_INSTS_VALU_TRANS_F32"], 0.0)
+                    vi[kk2.split("(")[0].replace("void mcx::", "")] = dict(
+                        SQ_INSTS_VALU=c_["SQ_INSTS_VALU"], packed_f32_instructions_est=packed, GRBM_GUI_ACTIVE=c_["GRBM_GUI_ACTIVE"],
+                        frac=(2.0 * plain + 4.0 * packed) / (N_SIMD * cyc2),
+                        frac_at_measured_issue_intervals=(2.7 * plain + 4.7 * packed) / (N_SIMD * cyc2))
+                if vi:
+                    murray["valu_issue"] = dict(kernels=vi, formula="per kernel, mean per launch of the measured child job: (2*plain + "
+                                                "4*packed_f32) issue cycles / (1024 SIMDs * GRBM_GUI_ACTIVE/8), as roofline.frac; the second "
+                                                "figure prices the same counts with the issue intervals tools/ubench.hip measured (2.7 / 4.7)")
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg)
 

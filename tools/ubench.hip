@@ -6,6 +6,7 @@
 #include <vector>
 
 #define ITER 4096
+typedef float f2 __attribute__((ext_vector_type(2)));
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 #define KERNEL(name, decl, body, fin_stmt)                                                   \
@@ -41,12 +42,74 @@
 #define OP_ADD(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a##k) : "v"(seed));
 #define OP_DPP(k) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a##k));
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 #define DV(k) f2 a##k = {seed * 1e-9f + k + threadIdx.x, 0.5f + k};
 #define FINV unsigned fin = __float_as_uint(a0.x + a1.x + a2.x + a3.x + a4.y + a5.y + a6.y + a7.y)
 #define OP_PKFMA(k) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(a##k));
 #define OP_PKMUL(k) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(a##k));
 
+// the Murray sweep's per-dimension patterns (counted per instruction of the group, like the others):
+//   mov3: v_mov s->v ; v_fma -x, s, v ; v_fmac     (two scalar operands: one has to go through a VGPR)
+//   fma2: v_fma (one scalar operand) ; v_fmac      (the other operand already in a VGPR)
+//   mov64: v_mov_b64 s[..]->v[..] counted alone
+//   lds_b128: ds_read_b128 of one address by all lanes, 1 per 8 v_fma (what feeding 4 dimensions' operands costs)
+#define OP_MOV3(k) asm volatile("v_mov_b32 %1, %2\n\tv_fma_f32 %1, -%0, %3, %1\n\tv_fmac_f32 %0, %1, %1" : "+v"(a##k), "=&v"(b##k) : "s"(sf), "s"(sg));
+#define OP_FMA2(k) asm volatile("v_fma_f32 %1, -%0, %2, %1\n\tv_fmac_f32 %0, %1, %1" : "+v"(a##k), "+v"(b##k) : "s"(sf));
+#define OP_MOV64(k) asm volatile("v_mov_b64 %0, %1" : "=v"(a##k) : "s"(sl));
+#define OP_FMADPP(k) asm volatile("v_fmac_f32_dpp %0, %1, %1 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(a##k) : "v"(b##k));
+#define DSF float sf = __uint_as_float(__builtin_amdgcn_readfirstlane(seed)) * 1e-9f, sg = sf + 1.0f;
+#define DSL unsigned long long sl = __builtin_amdgcn_readfirstlane(seed) | ((unsigned long long)__builtin_amdgcn_readfirstlane(seed + 1) << 32);
+__global__ void k_mov3(unsigned *out, unsigned seed)
+{
+  DSF R8(DP)
+  for (int i = 0; i < ITER / 3; ++i) { R8(OP_MOV3) }
+  FINP; out[blockIdx.x * blockDim.x + threadIdx.x] = fin;
+}
+__global__ void k_fma2(unsigned *out, unsigned seed)
+{
+  DSF R8(DP)
+  for (int i = 0; i < ITER / 2; ++i) { R8(OP_FMA2) }
+  FINP; out[blockIdx.x * blockDim.x + threadIdx.x] = fin;
+}
+__global__ void k_mov64(unsigned *out, unsigned seed)
+{
+  DSL R8(DL)
+  for (int i = 0; i < ITER; ++i) { R8(OP_MOV64) }
+  FINL; out[blockIdx.x * blockDim.x + threadIdx.x] = fin;
+}
+__global__ void k_fmac_dpp(unsigned *out, unsigned seed)
+{
+  R8(DP)
+  for (int i = 0; i < ITER; ++i) { R8(OP_FMADPP) }
+  FINP; out[blockIdx.x * blockDim.x + threadIdx.x] = fin;
+}
+// 8 v_fma + 1 broadcast ds_read_b128 per group, counted as 8 instructions: the LDS read rides along if this equals fma
+__global__ void k_fma_lds(unsigned *out, unsigned seed)
+{
+  __shared__ float4 tab[256];
+  tab[threadIdx.x] = make_float4(seed * 1e-9f, 1.f, 2.f, 3.f);
+  __syncthreads();
+  R8(DF)
+  float4 v = tab[seed & 255];
+  for (int i = 0; i < ITER; ++i) {
+    const float4 w = tab[(seed + i) & 255];  // wave-uniform address: every lane reads the same 16 bytes
+    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a0) : "v"(v.x)); asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a1) : "v"(v.y));
+    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a2) : "v"(v.z)); asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a3) : "v"(v.w));
+    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a4) : "v"(v.x)); asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a5) : "v"(v.y));
+    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a6) : "v"(v.z)); asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a7) : "v"(v.w));
+    v = w;
+  }
+  FINF; out[blockIdx.x * blockDim.x + threadIdx.x] = fin;
+}
+//   pk2: two chains per lane: v_pk_fma t2 = -x2 * (s,s) + (m',m') with both scalars taken from ONE SGPR pair by op_sel ; v_pk_fma arg2
+#define OP_PK2(k) asm volatile("v_pk_fma_f32 %1, %0, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\tv_pk_fma_f32 %0, %1, %1, %0" : "+v"(a##k), "+v"(b##k) : "s"(sl));
+#define DV2(k) f2 a##k = {seed * 1e-9f + k + threadIdx.x, 0.5f + k}, b##k = a##k;
+__global__ void k_pk2(unsigned *out, unsigned seed)
+{
+  DSL R8(DV2)
+  for (int i = 0; i < ITER / 2; ++i) { R8(OP_PK2) }
+  unsigned fin = __float_as_uint(a0.x + a1.x + a2.x + a3.x + a4.y + a5.y + a6.y + a7.y + b0.x + b7.y);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = fin;
+}
 KERNEL(k_fma, R8(DF), R8(OP_FMA), FINF)
 KERNEL(k_xor, R8(DU), R8(OP_XOR), FINU)
 KERNEL(k_mul_lo_u32, R8(DU), R8(OP_MULLO), FINU)
@@ -66,7 +129,7 @@ typedef void (*kfn)(unsigned *, unsigned);
 struct K { const char *name; kfn f; };
 int main()
 {
-  K ks[] = {{"fma", k_fma},{"xor", k_xor},{"mul_lo_u32", k_mul_lo_u32},{"mul_hi_u32", k_mul_hi_u32},{"mad_u64_u32", k_mad_u64_u32},{"mul_u32_u24", k_mul_u32_u24},{"sqrt", k_sqrt},{"rcp", k_rcp},{"cvt_f32_u32", k_cvt_f32_u32},{"cndmask", k_cndmask},{"add_u32", k_add_u32},{"add_f32_dpp", k_add_f32_dpp},{"pk_fma", k_pk_fma},{"pk_mul", k_pk_mul}};
+  K ks[] = {{"fma", k_fma},{"xor", k_xor},{"mul_lo_u32", k_mul_lo_u32},{"mul_hi_u32", k_mul_hi_u32},{"mad_u64_u32", k_mad_u64_u32},{"mul_u32_u24", k_mul_u32_u24},{"sqrt", k_sqrt},{"rcp", k_rcp},{"cvt_f32_u32", k_cvt_f32_u32},{"cndmask", k_cndmask},{"add_u32", k_add_u32},{"add_f32_dpp", k_add_f32_dpp},{"pk_fma", k_pk_fma},{"pk_mul", k_pk_mul},{"sweep mov3", k_mov3},{"sweep fma2", k_fma2},{"mov_b64 s->v", k_mov64},{"fmac_f32_dpp", k_fmac_dpp},{"8fma+lds_b128", k_fma_lds},{"sweep pk2", k_pk2}};
   hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
   const int cus = p.multiProcessorCount;
   unsigned *out; CHK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * 4));
