@@ -371,6 +371,7 @@ struct mcx_engine {
   DevBuf<uint8_t> mask;
   // host staging
   PinBuf<float> h_ptrial, h_lytrial;
+  PinBuf<unsigned long long> h_ctr;  // the run's counters, read back once at its end
   std::vector<float> h_cov, h_cov_dev, h_winv;  // h_cov_dev = what cov0 holds
   bool cov_pending = false;  // cov has not been reset to cov0 for the current run yet
   int ctr_set = 0;           // counter block of the current run (ring of CTR_RING blocks, zeroed when it wraps)
@@ -581,7 +582,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
-  e->h_ptrial.release(); e->h_lytrial.release(); e->zpre.release(); e->upre.release(); e->trash.release();
+  e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->zpre.release(); e->upre.release(); e->trash.release();
   for (int b = 0; b < 2; ++b) {
     e->sink_stage[b].release();
     e->sink_pin[b].release();
@@ -1557,9 +1558,10 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, ctrp + 4);
     HIPCHK(hipGetLastError());
   }
-  unsigned long long hctr[8];
+  MCXCHK(e->h_ctr.alloc(8));  // pinned: the copy queues behind the last kernel instead of staging through the runtime
+  unsigned long long *hctr = e->h_ctr.p;
   MCXCHK(cov_reset(e));  // (a run without any step)
-  HIPCHK(hipMemcpyAsync(hctr, ctrp, sizeof hctr, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   {
     const hipError_t se = hipStreamSynchronize(st);
     (void)meet_release(e, true);
