@@ -260,6 +260,10 @@ int mcx_device_count(int *n);
 /* PCI bus id of the calling thread's current device ("0000:05:00.0"): lets a multi-process launcher see
  * whether two ranks share a GPU (RCCL refuses such a communicator) */
 int mcx_device_pci_bus_id(char *buf, size_t len);
+/* measured device-copy bandwidth of the current device: `reps` device-to-device copies of `bytes` bytes, timed with
+ * HIP events; *gbps = (bytes read + bytes written) / time in GB/s.  What bench.py reports the HBM figures against
+ * next to the nominal 8 TB/s. */
+int mcx_debug_copy_bandwidth(size_t bytes, int reps, double *gbps);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:
  * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
  * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf,

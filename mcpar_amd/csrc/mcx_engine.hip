@@ -1883,6 +1883,34 @@ extern "C" int mcx_debug_numerics(int what, int n, const uint32_t *in, uint32_t 
   return rc;
 }
 
+extern "C" int mcx_debug_copy_bandwidth(size_t bytes, int reps, double *gbps)
+{
+  if (!gbps || bytes == 0 || reps <= 0) return fail(MCX_ERR_INVALID, "copy bandwidth: bytes > 0, reps > 0, gbps != NULL");
+  DevBuf<unsigned char> a, b;
+  MCXCHK(a.alloc(bytes));
+  MCXCHK(b.alloc(bytes));
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  int rc = MCX_OK;
+  float ms = 0.0f;
+  do {
+    if (hipMemset(a.p, 1, bytes) != hipSuccess || hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess ||
+        hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, nullptr) != hipSuccess ||  // warm
+        hipEventRecord(t0, nullptr) != hipSuccess) { rc = MCX_ERR_HIP; break; }
+    for (int r = 0; r < reps && rc == MCX_OK; ++r)
+      if (hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = MCX_ERR_HIP;
+    if (rc != MCX_OK) break;
+    if (hipEventRecord(t1, nullptr) != hipSuccess || hipEventSynchronize(t1) != hipSuccess ||
+        hipEventElapsedTime(&ms, t0, t1) != hipSuccess || !(ms > 0.0f)) rc = MCX_ERR_HIP;
+  } while (0);
+  if (t0) (void)hipEventDestroy(t0);
+  if (t1) (void)hipEventDestroy(t1);
+  a.release();
+  b.release();
+  if (rc != MCX_OK) return fail(rc, "copy bandwidth: %s", hipGetErrorString(hipGetLastError()));
+  *gbps = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;
+  return MCX_OK;
+}
+
 extern "C" int mcx_debug_sqrt_sweep(uint32_t lo_bits, uint32_t hi_bits, uint64_t *nbad, uint32_t *first_bad)
 {
   if (!nbad || !first_bad || hi_bits < lo_bits) return fail(MCX_ERR_INVALID, "bad arguments");
