@@ -1210,7 +1210,7 @@ struct RemoteArgs {
   const float *musigall, *winv, *cmax;  // winv = qpar: (m', s) pairs
   float *ptrial, *mutrial, *sigtrial, *cfac;
   float *racpt;        // [n] rejection threshold of this pass, by chain
-  float *psum, *pmax;  // [nact][S] per-block partial sums / maxima, by position in the active list
+  float *psum, *pmax;  // [S][nact] per-block partial sums / maxima, by position in the active list
   int n, d, N, pass, S;
   uint32_t g0, t, seed;
 };
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
 #pragma unroll
   for (int c = 0; c < CPL; ++c)
     if (valid[c]) {
-      const size_t o = (size_t)pos[c] * S + sb;
+      const size_t o = (size_t)sb * nact + pos[c];  // [block][position]: coalesced here and in the combining kernels
       if (SUMS) {
         psum[o] = c == 0 ? part.x : part.y;
         pmax[o] = c == 0 ? m.x : m.y;
@@ -1414,7 +1414,7 @@ static __global__ void k_remote_cmax_combine(const float *__restrict__ pmin, flo
   if (j >= n) return;
   float amin = __builtin_inff();
   for (int sb = 0; sb < S; ++sb) {
-    const float v = pmin[(size_t)j * S + sb];
+    const float v = pmin[(size_t)sb * n + j];
     amin = v < amin ? v : amin;
   }
   cmax[j] = expf_v2(-0.5f * amin);
@@ -1428,8 +1428,8 @@ static __global__ void k_remote_decide(const RemoteArgs a)
   const int j = a.active_in ? a.active_in[i] : i;
   float qs = FPEPS, qm = FPEPS;  // src/mcpar.cc:355-365
   for (int sb = 0; sb < a.S; ++sb) {
-    qs = qs + a.psum[(size_t)i * a.S + sb];
-    const float v = a.pmax[(size_t)i * a.S + sb];
+    qs = qs + a.psum[(size_t)sb * a.nact + i];
+    const float v = a.pmax[(size_t)sb * a.nact + i];
     qm = v > qm ? v : qm;
   }
   const float pacpt = qm / qs;
