@@ -7,6 +7,8 @@ expects (all optional, per configuration C in c2 c3 c5 c3-murray):
   gpurun_out/<rnd>_bench_C.json   the JSON line of `bench.py --config C [--keep-pmc gpurun_out/<rnd>_pmc_C]`
   gpurun_out/<rnd>_pmc_C/<COUNTERS>/**/*counter_collection.csv   the live PMC passes bench.py kept
   gpurun_out/<rnd>_kt_C/**/*kernel_stats.csv    `rocprofv3 --kernel-trace --stats -- python3 bench.py --config C ...`
+(gpurun merges into gpurun_out/ without deleting: remove gpurun_out/<rnd>_pmc_* and <rnd>_kt_* before a new
+`gpurun -- bash tools/refresh_profiles.sh <rnd>`, or counters of kernels that no longer exist stay in the tables)
 and writes
   profiles/<rnd>_bench_C.json, profiles/<rnd>_C_kernel_stats.csv,
   profiles/<rnd>_C_pmc_counters.json  (per kernel: mean per dispatch of every collected counter, second job only),
@@ -42,7 +44,7 @@ for cfg in ("c3", "c2", "c5", "c3-murray"):
         json.dump(line, open(os.path.join(pr, "%s_bench_%s.json" % (rnd, cfg)), "w"), indent=1)
     ks = glob.glob(os.path.join(go, "%s_kt_%s" % (rnd, KT_DIR[cfg]), "**", "*kernel_stats.csv"), recursive=True)
     if ks:
-        shutil.copy(ks[0], os.path.join(pr, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
+        shutil.copy(max(ks, key=os.path.getmtime), os.path.join(pr, "%s_%s_kernel_stats.csv" % (rnd, cfg)))  # the latest run's
     table = collections.defaultdict(dict)
     for f in glob.glob(os.path.join(go, "%s_pmc_%s" % (rnd, cfg), "*", "**", "*counter_collection.csv"), recursive=True):
         acc = collections.defaultdict(list)

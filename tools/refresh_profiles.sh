@@ -1,0 +1,16 @@
+# On the GPU box: the bench lines, live PMC passes and rocprofv3 kernel stats that tools/collect_profiles.py turns into
+# profiles/<round>_*.  usage: bash tools/refresh_profiles.sh r02
+set -o pipefail
+RND=${1:-r02}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+G=$R/gpurun_out
+mkdir -p $G
+for C in c3 c2 c5 c3-murray; do
+  case $C in c3-murray) K=c3m;; *) K=$C;; esac
+  rm -rf $G/${RND}_pmc_$C $G/${RND}_kt_$K
+  ( cd $R && timeout -k 10 400 python3 bench.py --config $C --keep-pmc $G/${RND}_pmc_$C > $G/${RND}_bench_$C.json 2> $G/${RND}_bench_$C.err ) || { echo "bench $C failed"; tail -3 $G/${RND}_bench_$C.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv -d $G/${RND}_kt_$K -- python3 $R/bench.py --config $C --no-pmc --no-extras --no-cpu-baseline > $G/${RND}_kt_$K.log 2>&1 || { echo "kernel trace $C failed"; tail -3 $G/${RND}_kt_$K.log; exit 1; }
+  echo "$C done"
+done
+( cd $R && timeout -k 10 300 python3 bench.py --config c3 --chains 8192 --steps 100 --warmup 10 --no-extras --no-cpu-baseline > $G/${RND}_bench_c3_8192chains.json 2> $G/${RND}_bench_c3_8192chains.err ) && echo "8192 done"
