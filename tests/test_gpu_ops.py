@@ -38,7 +38,10 @@ def test_gen_local_full_covariance_statistics():
         eg.covar_setup(-np.eye(d, dtype=np.float32))
 
 
-@pytest.mark.parametrize("d,n,nshards", [(2, 64, 1), (16, 300, 1), (8, 96, 3), (5, 40, 1), (32, 33, 2), (33, 40, 1), (48, 70, 1), (64, 65, 2), (65, 30, 1), (80, 24, 2)])
+# (32, 513, 1) / (32, 1030, 2): two chains per lane -- an odd count, and counts that cross one and two workgroups' worth
+# (2 x 256 positions each); (16, 700, 1) / (4, 520, 1): N not a multiple of the 256-row block nor of the LDS stage
+@pytest.mark.parametrize("d,n,nshards", [(2, 64, 1), (16, 300, 1), (8, 96, 3), (5, 40, 1), (32, 33, 2), (33, 40, 1), (48, 70, 1), (64, 65, 2),
+                                         (65, 30, 1), (80, 24, 2), (32, 513, 1), (32, 1030, 2), (16, 700, 1), (4, 520, 1)])
 def test_gen_remote(d, n, nshards):
     import mcpar_amd as M
     rng = np.random.default_rng(10 * d + nshards)
