@@ -167,7 +167,7 @@ enum {
   MCX_OPT_PERSIST = 10,    /* small-n mode, one launch per stretch of local steps: the burn-in with its tuner, the start of
                               the main loop and the local main-loop steps run in ONE kernel whose owner wavefronts keep
                               the chains while the other wavefronts of each CU generate their random numbers into LDS
-                              (same bits).  -1 auto [default: when the chains fill at most 4 wavefronts per CU and
+                              (same bits).  -1 auto [default: when the chains fill at most 8 wavefronts per CU and
                               SPLIT_RNG is not 0], 0 off, 1 on */
   MCX_OPT_EAGER_EXCHANGE = 7 /* 0 [default]: gather the latest sync-point snapshot only when a Murray step (or
                               the end of the run) will read it -- bit-identical to 1: gather at every sync

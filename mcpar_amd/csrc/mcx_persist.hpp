@@ -36,7 +36,7 @@ namespace mcx {
 
 constexpr int PBLOCK = 1024;          // 16 wavefronts: 4 per SIMD of one CU
 constexpr int PWAVES = PBLOCK / 64;
-constexpr int POWN_MAX = 4;
+constexpr int POWN_MAX = 8;           // owner wavefronts per workgroup: measured 1.2-3x faster than the fused kernels up to 6, equal at 7-8 (tools/persist_sweep.py)
 constexpr int PKMAX = 32;             // most steps per phase (LDS double buffers hold 2 phases)
 constexpr int PEVENTS = 64;           // tuner events (steps 51, 101, ... and the end of the burn-in) one launch can hold
 

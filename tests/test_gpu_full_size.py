@@ -111,3 +111,30 @@ def test_reference_accept_rates_at_full_size():
         s = eg.samples.reshape(nsamp, n, d + 1)
         changed = np.any(s[1:, :, :d] != s[:-1, :, :d], axis=2)
         assert abs(changed.mean() - ref) < tol, (d, n, changed.mean())
+
+
+@pytest.mark.parametrize("d,n", [(16, 20480), (16, 24576), (16, 32768), (8, 49152), (32, 16384)])
+def test_small_n_mode_with_five_to_eight_owners_per_workgroup(d, n):
+    """k_run_small with 5-8 owner wavefronts per workgroup (no recorders, 8-11 generators): between 16 k and 32 k
+    chains x 16-D the one-launch run beats the fused kernels' 1.5-2 waves per SIMD.  State, log-likelihood, moments,
+    per-chain accept counts, tuner trace and sample rows against the oracle, every step of a short job."""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    p = O.default_pinit(d, n)
+    vo, _ko = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    vg, _kg = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=1.0, threads=8)
+    eo.set_record(samples=True, mask=False)
+    eg = M.Engine(d, n, pl=1.0)
+    eg.set_option(E.OPT_PERSIST, 1)
+    eo.run(60, 110, p, vo)
+    eg.run(60, 110, p, vg)
+    c = eg.counters
+    assert c["kernel_launches"] == 1, c  # the whole run was one k_run_small launch
+    assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+    np.testing.assert_array_equal(eg.accept_counts, eo.accept_counts)
+    np.testing.assert_array_equal(eg.tuner_trace.view(np.uint32), eo.tuner_trace.view(np.uint32))
+    for name in ("state", "loglike", "mean", "var", "musigall", "samples"):
+        a, b = getattr(eg, name), getattr(eo, name)
+        assert a.shape == b.shape, name
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
