@@ -1057,12 +1057,12 @@ static __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsi
 }
 
 // ---------------------------------------------------------------------------------------------
-// genRemote (src/mcpar.cc:315-451).  One lane per chain, chain vector in registers, the N
-// per-chain Gaussians Q_i streamed through wave-uniform (scalar) loads.
+// genRemote (src/mcpar.cc:315-451).  One lane per chain (two at 32-D), chain vector in registers, the N
+// per-chain Gaussians Q_i staged through LDS a block at a time and read back as broadcasts.
 // ---------------------------------------------------------------------------------------------
 // qpar[i] = (m'_i, s_i) with s = sqrt(1/sig2), m' = mu s: sum_k (mu_k - x_k)^2 / sig2_k (src/mcpar.cc:369-383)
 // is then sum_k t_k^2 with t_k = fma(-x_k, s_k, m'_k) -- two operations per pair-dimension.  One Q_i is 2d
-// contiguous floats, fetched with wide scalar loads.
+// contiguous floats.
 static __global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ qpar, size_t nd)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1073,25 +1073,11 @@ static __global__ void k_remote_prep(const float *__restrict__ musigall, float *
   }
 }
 
-// EXACT: d == DMAX, no per-element guard (lets the compiler fetch a whole Q_i with wide scalar loads)
-template <int DMAX, bool EXACT = false>
-__device__ __forceinline__ float q_arg(const float *__restrict__ qp, const float x[DMAX], int d)
-{
-  float arg = 0.0f;
-#pragma unroll
-  for (int k = 0; k < DMAX; ++k)
-    if (EXACT || k < d) {
-      const float t = __builtin_fmaf(-x[k], qp[2 * k + 1], qp[2 * k]);
-      arg = __builtin_fmaf(t, t, arg);
-    }
-  return arg;
-}
-
 // The sweep loop over the rows of Gaussians staged in LDS (row stride 2*DMAX floats, zero-padded past 2*DD), with
 // wave-uniform early outs.  The partial sums of arg only grow (every term is a square), so once every chain of
 // the wavefront has `arg > bound(lane)` after a group of dimensions the remaining dimensions cannot bring any of
 // them back under its bound, and this Q_i is dropped for the whole wavefront; completed sums are the same bits
-// as q_arg's.  One Q_i against 64 chains is mostly far away from all of them, so most of the
+// as the oracle's qarg().  One Q_i against 64 chains is mostly far away from all of them, so most of the
 // sweep ends after the first group.  use(arg) consumes a completed sum; bound() is re-read per Q_i.
 // Every lane reads the same address (a broadcast ds_read_b128 = two dimensions), so both operands of
 // t = fma(-x, s, m') arrive in VGPRs.  Round 1 streamed the rows through wave-uniform scalar loads instead:
