@@ -113,16 +113,22 @@ def test_reference_accept_rates_at_full_size():
         assert abs(changed.mean() - ref) < tol, (d, n, changed.mean())
 
 
-@pytest.mark.parametrize("d,n", [(16, 20480), (16, 24576), (16, 32768), (8, 49152), (32, 16384)])
-def test_small_n_mode_with_five_to_eight_owners_per_workgroup(d, n):
+@pytest.mark.parametrize("d,n,mix", [(16, 20480, 0), (16, 24576, 0), (16, 32768, 0), (8, 49152, 0), (32, 16384, 0), (32, 14336, 8), (16, 28672, 3)])
+def test_small_n_mode_with_five_to_eight_owners_per_workgroup(d, n, mix):
     """k_run_small with 5-8 owner wavefronts per workgroup (no recorders, 8-11 generators): between 16 k and 32 k
     chains x 16-D the one-launch run beats the fused kernels' 1.5-2 waves per SIMD.  State, log-likelihood, moments,
     per-chain accept counts, tuner trace and sample rows against the oracle, every step of a short job."""
     import mcpar_amd as M
     from mcpar_amd import engine as E
     p = O.default_pinit(d, n)
-    vo, _ko = O.make_vlfunc(O.VL_ROSENBROCK1, d)
-    vg, _kg = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    if mix:  # a sum of `mix` unit Gaussians (the C5 likelihood): means 5k/(K-1) in every dimension, weights (5, 1, ..., 1)
+        means = np.stack([np.full(d, 5.0 * k / (mix - 1)) for k in range(mix)]).astype(np.float32)
+        params = np.concatenate([means.ravel(), [5.0] + [1.0] * (mix - 1)]).astype(np.float32)
+        vo, _ko = O.make_vlfunc(O.VL_GAUSSMIX, d, params, mix)
+        vg, _kg = M.make_vlfunc(M.VL_GAUSSMIX, d, params, mix)
+    else:
+        vo, _ko = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+        vg, _kg = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eo = O.Engine(d, n, pl=1.0, threads=8)
     eo.set_record(samples=True, mask=False)
     eg = M.Engine(d, n, pl=1.0)
