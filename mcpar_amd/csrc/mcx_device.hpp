@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
                                                         const int *__restrict__ active, int nact,
                                                         const float *__restrict__ qpar,
                                                         float *__restrict__ psum,
-                                                        float *__restrict__ pmax, int d, int N, int S, int own0)
+                                                        float *__restrict__ pmax, int d, int N, int own0)
 {
   static_assert(CPL == 1 || (CPL == 2 && EXACT), "two chains per lane: d == DMAX only");
   // the block's Gaussians pass through LDS 16 KB (8 KB with two chains per lane) at a time

@@ -794,11 +794,11 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     if (d == dm) {
       DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, true, SWEEP_CPL(DMAX_)>), dim3(nblocks(((size_t)n + SWEEP_CPL(DMAX_) - 1) / SWEEP_CPL(DMAX_)), S), dim3(BLOCK),
                                            0, st, pvals, (const int *)nullptr, n, e->winvall.p,
-                                           (float *)nullptr, e->pmax.p, d, N, S, e->rank * e->nchain));
+                                           (float *)nullptr, e->pmax.p, d, N, e->rank * e->nchain));
     } else {
       DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
                                            0, st, pvals, (const int *)nullptr, n, e->winvall.p,
-                                           (float *)nullptr, e->pmax.p, d, N, S, e->rank * e->nchain));
+                                           (float *)nullptr, e->pmax.p, d, N, e->rank * e->nchain));
     }
   }
   if (!big) hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S);
@@ -824,11 +824,11 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
       if (d == dm) {
         DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, true, SWEEP_CPL(DMAX_)>), dim3(nblocks(((size_t)nact + SWEEP_CPL(DMAX_) - 1) / SWEEP_CPL(DMAX_)), S), dim3(BLOCK),
                                              0, st, ptrial, (const int *)ain, nact, e->winvall.p,
-                                             e->psum.p, e->pmax.p, d, N, S, -1));
+                                             e->psum.p, e->pmax.p, d, N, -1));
       } else {
         DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, false>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
                                              0, st, ptrial, (const int *)ain, nact, e->winvall.p,
-                                             e->psum.p, e->pmax.p, d, N, S, -1));
+                                             e->psum.p, e->pmax.p, d, N, -1));
       }
       }
       hipLaunchKernelGGL(k_remote_decide, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);

@@ -19,8 +19,20 @@ def test_gaussian_target_moments():
     s = eg.samples.reshape(nsamp, n, d + 1)[300:, :, :d].astype(np.float64)
     np.testing.assert_allclose(s.mean((0, 1)), mu, atol=0.05)
     np.testing.assert_allclose(s.var((0, 1)), s2, rtol=0.08)
-    # the per-chain running moments the engine publishes are the moments of each chain's samples
     assert eg.counters["remote_steps"] > 30
+    # The per-chain running moments the engine publishes (Welford updates, and on an accepted remote proposal the
+    # donor's moments adopted with psum2 = sig (pwgt - 1): src/mcpar.cc:184-202) estimate the target's moments too:
+    # the means directly; the variances from below, because 800 autocorrelated steps of one chain do not span the
+    # target in its wide dimensions (measured 0.70-0.96 of sigma^2).  A wrong sign or weight in the adoption would
+    # show here -- on the oracle and the kernels alike, which the bit-exact tests cannot see.
+    m, v = eg.mean.astype(np.float64), eg.var.astype(np.float64)
+    assert np.all(v > 0)
+    np.testing.assert_allclose(m.mean(0), mu, atol=0.15)
+    ratio = v.mean(0) / s2
+    assert np.all(ratio > 0.6) and np.all(ratio < 1.1), ratio
+    ms = eg.musigall.astype(np.float64)  # what the other shards would sweep over: the same numbers
+    np.testing.assert_array_equal(ms[:, :, 0], m)
+    np.testing.assert_array_equal(ms[:, :, 1], v)
 
 
 def test_bimodal_target_mode_weights():
