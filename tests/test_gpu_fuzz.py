@@ -92,8 +92,10 @@ def one_case(rng, idx):
 
 
 def test_random_configurations():
-    rng = np.random.default_rng(20261003)
-    for idx in range(400):
+    import os
+    # MCX_FUZZ_SEED / MCX_FUZZ_CASES: a soak run with other seeds (the default is the fixed regression set)
+    rng = np.random.default_rng(int(os.environ.get("MCX_FUZZ_SEED", "20261003")))
+    for idx in range(int(os.environ.get("MCX_FUZZ_CASES", "400"))):
         one_case(rng, idx)
 
 
