@@ -967,6 +967,18 @@ __global__ __launch_bounds__(BLOCK) void k_accept(const StepArgs a)
   if ((threadIdx.x & 63u) == 0 && wacc) a.acc_slots[gid >> 6] += wacc;
 }
 
+// start of a run on the multi-launch paths, one launch instead of three fills and a copy: per-wavefront and
+// per-chain accept counters and the tuner-trace length to zero, the staged initial state into place (src/mcpar.cc:47-50)
+static __global__ void k_run_reset(uint32_t *slots, size_t nslots, uint32_t *acc_cnt, size_t n, int *ntrace,
+                                   float *__restrict__ x, const float *__restrict__ x0, size_t ntot)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nslots) slots[i] = 0u;
+  if (i < n) acc_cnt[i] = 0u;
+  if (i == 0) *ntrace = 0;
+  if (x0 && i < ntot) x[i] = x0[i];
+}
+
 // start of the main loop: mu = 0, psum2 = FPEPS (src/mcpar.cc:99-104)
 static __global__ void k_init_moments(float *mu, float *psum2, size_t ntot)
 {

@@ -1359,10 +1359,10 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   // pinit is pageable caller memory: the runtime stages it before hipMemcpyAsync returns
   if (pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
   if (!lead) {
-    HIPCHK(hipMemsetAsync(e->acc_slots.p, 0, (size_t)e->nslots * sizeof(uint32_t), st));
-    HIPCHK(hipMemsetAsync(e->ntrace.p, 0, sizeof(int), st));
-    HIPCHK(hipMemsetAsync(e->acc_cnt.p, 0, (size_t)n * sizeof(uint32_t), st));
-    if (!pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, e->pinit_dev.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_run_reset, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->acc_slots.p, (size_t)e->nslots,
+                       e->acc_cnt.p, (size_t)n, e->ntrace.p, e->pvals.p, pinit ? (const float *)nullptr : e->pinit_dev.p,
+                       (size_t)e->ntot);
+    HIPCHK(hipGetLastError());
     MCXCHK(eval_trials(e, e->pvals.p, e->lylast.p, 0));  // :53
     MCXCHK(cov_reset(e));
   }
