@@ -101,8 +101,9 @@ def test_random_configurations():
 
 def test_random_multishard_configurations():
     from test_gpu_multishard import run_sharded_gpu
-    rng = np.random.default_rng(77)
-    for idx in range(24):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("MCX_FUZZ_SEED", "77")))
+    for idx in range(int(os.environ.get("MCX_FUZZ_SHARD_CASES", "24"))):
         d = int(rng.choice([2, 4, 8, 16, 20, 32]))
         n = int(rng.integers(3, 120))
         nshards = int(rng.choice([2, 3, 5]))
