@@ -777,6 +777,8 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
   const int n = e->nchain, d = e->nparam, N = e->tchains, dm = d <= 64 ? dmax_for(d) : 64;
   const bool big = d > 64;  // chain vector in registers up to np = 64, re-read from memory above
   const int S = (N + QBLOCK - 1) / QBLOCK;
+  if (!big && S > 65535)  // blocks of Gaussians go in gridDim.y
+    return fail(MCX_ERR_UNSUPPORTED, "Murray proposals over %d chains in all: at most %d", N, 65535 * QBLOCK);
   hipStream_t st = e->stream;
   ProfScope ps(e, MCX_K_REMOTE, (uint64_t)n);
   if (!big) {
