@@ -1069,7 +1069,7 @@ static __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsi
 }
 
 // ---------------------------------------------------------------------------------------------
-// genRemote (src/mcpar.cc:315-451).  One lane per chain (two at 32-D), chain vector in registers, the N
+// genRemote (src/mcpar.cc:315-451).  One lane per chain (two chains per lane at 16-D and 32-D), chain vector in registers, the N
 // per-chain Gaussians Q_i staged through LDS a block at a time and read back as broadcasts.
 // ---------------------------------------------------------------------------------------------
 // qpar[i] = (m'_i, s_i) with s = sqrt(1/sig2), m' = mu s: sum_k (mu_k - x_k)^2 / sig2_k (src/mcpar.cc:369-383)

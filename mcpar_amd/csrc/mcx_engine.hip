@@ -277,9 +277,10 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   default: return fail(MCX_ERR_UNSUPPORTED, "np > 256 is not supported"); \
   }
 
-// chains per lane of the Murray sweep when np == DMAX (mcx_device.hpp, sweep_rows2): two at 32-D, where the LDS
-// broadcast reads bind with one (measured: sweeps 5 % faster at 32-D, 2 % slower at 16-D -- coarser early-outs)
-#define SWEEP_CPL(DMAX) ((DMAX) == 32 ? 2 : 1)
+// chains per lane of the Murray sweep when np == DMAX (mcx_device.hpp, sweep_rows2): two at 16-D and 32-D, where the
+// LDS broadcast reads bind with one (measured on one box: R-murray jobs 3.5 % faster at 16-D, 5 % faster sweeps at 32-D;
+// the coarser early-outs of 128 chains per wavefront cost less than the reads save)
+#define SWEEP_CPL(DMAX) ((DMAX) == 16 || (DMAX) == 32 ? 2 : 1)
 #define DISPATCH_DMAX(dm, CALL)                                   \
   switch (dm) {                                                   \
   case 2: { constexpr int DMAX_ = 2; CALL; } break;               \
