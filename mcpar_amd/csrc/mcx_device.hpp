@@ -495,53 +495,30 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t owner, int 
 //   * T is staged in LDS as [row in block k][column block qq][lane of the chain q][4 columns]: for a given
 //     (k, qq) the lanes of a wavefront read LPC consecutive 16-byte slots -- every ds_read_b128 lane group
 //     sees each slot's address on all its readers (broadcast) and no bank twice;
-//   * z travels as the DPP operand of the multiply-adds for chains of <= 4 lanes (no memory, no moves); chains of 8 lanes write
+//   * z travels by DPP quad permutes for chains of <= 4 lanes (no memory: 4 moves per column block, the multiply-adds
+//     packed by the compiler; feeding z as the DPP operand of v_fmac_f32 through inline asm measured the same); chains of 8 lanes write
 //     their z block to LDS (9 slots per chain, so the four chains of a ds_read_b128 lane group sit on
 //     different banks) and read the 8 blocks back;
 //   * every lane runs all columns, in ascending order like the oracle's loop over k <= i: the entries above
 //     the diagonal are exact zeros and fma(0, z, acc) == acc (z is finite; acc = -0 would need x = -0).
-// One column block of the triangular product for chains of 2 or 4 lanes: p[k] = fma(T[k][c], z_qq[c], p[k]) for
-// c = 0..3 (ascending columns), the z operand taken straight from lane qq of the chain by the DPP operand of
-// v_fmac_f32 (fused, one rounding, like __builtin_fmaf) -- no separate broadcast moves.  The s_nop covers the
-// two wait states a DPP read needs after a VALU write of the same register, which the compiler cannot see
-// inside the asm.  PERM: the quad_perm selector.
-#define MCX_FMAC_DPP_BLOCK(PERM)                                                                              \
-  asm("s_nop 1\n\t"                                                                                           \
-      "v_fmac_f32_dpp %0, %4, %8 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                      \
-      "v_fmac_f32_dpp %1, %4, %12 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %2, %4, %16 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %3, %4, %20 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %0, %5, %9 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                      \
-      "v_fmac_f32_dpp %1, %5, %13 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %2, %5, %17 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %3, %5, %21 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %0, %6, %10 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %1, %6, %14 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %2, %6, %18 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %3, %6, %22 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %0, %7, %11 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %1, %7, %15 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %2, %7, %19 " PERM " row_mask:0xf bank_mask:0xf\n\t"                                     \
-      "v_fmac_f32_dpp %3, %7, %23 " PERM " row_mask:0xf bank_mask:0xf"                                          \
-      : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3])                                                        \
-      : "v"(zv[0]), "v"(zv[1]), "v"(zv[2]), "v"(zv[3]), "v"(t0.x), "v"(t0.y), "v"(t0.z), "v"(t0.w), "v"(t1.x), \
-        "v"(t1.y), "v"(t1.z), "v"(t1.w), "v"(t2.x), "v"(t2.y), "v"(t2.z), "v"(t2.w), "v"(t3.x), "v"(t3.y),     \
-        "v"(t3.z), "v"(t3.w))
-
+// value of lane qq of this lane's chain (2 or 4 lanes per chain; qq is a compile-time constant after unrolling): one DPP move
 template <int LPC>
-__device__ __forceinline__ void fmac_dpp_block(float p[4], const float zv[4], int qq, float4 t0, float4 t1, float4 t2, float4 t3)
+__device__ __forceinline__ float quad_bcast(float v, int qq)
 {
+  const int iv = (int)as_u32(v);
+  int r;
   if (LPC == 2) {
-    if (qq == 0) MCX_FMAC_DPP_BLOCK("quad_perm:[0,0,2,2]");
-    else MCX_FMAC_DPP_BLOCK("quad_perm:[1,1,3,3]");
+    r = qq ? __builtin_amdgcn_update_dpp(0, iv, 0xF5, 0xF, 0xF, true)   // quad_perm [1,1,3,3]
+           : __builtin_amdgcn_update_dpp(0, iv, 0xA0, 0xF, 0xF, true);  // quad_perm [0,0,2,2]
   } else {
     switch (qq) {
-    case 0: MCX_FMAC_DPP_BLOCK("quad_perm:[0,0,0,0]"); break;
-    case 1: MCX_FMAC_DPP_BLOCK("quad_perm:[1,1,1,1]"); break;
-    case 2: MCX_FMAC_DPP_BLOCK("quad_perm:[2,2,2,2]"); break;
-    default: MCX_FMAC_DPP_BLOCK("quad_perm:[3,3,3,3]"); break;
+    case 0: r = __builtin_amdgcn_update_dpp(0, iv, 0x00, 0xF, 0xF, true); break;
+    case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x55, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0xAA, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, iv, 0xFF, 0xF, 0xF, true); break;
     }
   }
+  return as_f32((uint32_t)r);
 }
 
 template <int LPC, bool MAIN, int LIK = LIK_ROSEN1, bool PREGEN = false, bool FULL = false>
@@ -625,14 +602,10 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
       }
 #pragma unroll
       for (int qq = 0; qq < LPC; ++qq) {
-        if (LPC == 2 || LPC == 4) {
-          fmac_dpp_block<LPC>(p, zv, qq, lds_T[(0 * LPC + qq) * LPC + q], lds_T[(1 * LPC + qq) * LPC + q],
-                              lds_T[(2 * LPC + qq) * LPC + q], lds_T[(3 * LPC + qq) * LPC + q]);
-          continue;
-        }
         float4 zz;
         if (LPC == 8) zz = lds_z[zslot + qq];
-        else zz = make_float4(zv[0], zv[1], zv[2], zv[3]);
+        else if (LPC == 1) zz = make_float4(zv[0], zv[1], zv[2], zv[3]);
+        else zz = make_float4(quad_bcast<LPC>(zv[0], qq), quad_bcast<LPC>(zv[1], qq), quad_bcast<LPC>(zv[2], qq), quad_bcast<LPC>(zv[3], qq));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float4 tr = lds_T[(k * LPC + qq) * LPC + q];
