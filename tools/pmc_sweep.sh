@@ -1,3 +1,5 @@
+# LDS and VALU counters of the Murray sweep kernels: two rocprofv3 --pmc passes over `bench.py --pmc-child --config c5`
+# (usage on the GPU box: bash tools/pmc_sweep.sh; prints per-kernel sums, raw output under gpurun_out/pmc_sw/)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_sw && mkdir -p $R/gpurun_out/pmc_sw
