@@ -21,13 +21,13 @@ static size_t lds_for(int lpc, int own, int rec, int K)
 // every even length the LDS buffers hold: 8-D x 4096 chains (1 owner) 14 steps 0.291 ms per launch, 16 -> 0.287,
 // 20 -> 0.306, 22 -> 0.280, 24 -> 0.273, 26 -> 0.282, 28 -> 0.329, 32 -> 0.288; 16-D x 8192 (2 owners) 12 -> 0.407,
 // 14 -> 0.395, 16 -> 0.382; 16-D x 12 288 (3 owners) 13 -> 0.548, 16 -> 0.547, 18 -> 0.508, 20 -> 0.501, 22 -> 0.522;
-// 16-D x 16 384 (4 owners) 8 -> 0.750, 10 -> 0.725, 12 -> 0.660, 14 -> 0.663.  The pattern is not monotonic: how the
+// 16-D x 16 384 (4 owners) 8 -> 0.750, 10 -> 0.725, 12 -> 0.661, 14 -> 0.663, 16 -> 0.655.  The pattern is not monotonic: how the
 // phase's items (a two-step item per owner and step pair, one acceptance item per owner) deal out over the filling
 // wavefronts matters as much as the phase count.
 int mcxk_persist_ksteps(int lpc, int own)
 {
   const int rec = mcxk_persist_recorders(own) ? 1 : 0;
-  int k = own == 1 ? 24 : (own == 2 ? 16 : (own == 3 ? 20 : PWAVES - own - rec * own));
+  int k = own == 1 ? 24 : (own == 2 ? 16 : (own == 3 ? 20 : (own == 4 ? 16 : PWAVES - own - rec * own)));
   while (k > 2 && (k > PKMAX || lds_for(lpc, own, rec, k) > MCXK_PERSIST_LDS_LIMIT)) k -= 2;
   return k;
 }
