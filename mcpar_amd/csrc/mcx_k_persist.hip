@@ -18,8 +18,8 @@ static size_t lds_for(int lpc, int own, int rec, int K)
 
 // Steps per phase.  The default is the generators' count (16 - owners - recorders); with 1-3 owners per workgroup
 // longer phases are faster (fewer phase changes for the latency-bound owners), by a table measured on one box with
-// every even length the LDS buffers hold: 8-D x 4096 chains (1 owner) 14 steps 0.291 ms per launch, 16 -> 0.287,
-// 20 -> 0.306, 22 -> 0.280, 24 -> 0.273, 26 -> 0.282, 28 -> 0.329, 32 -> 0.288; 16-D x 8192 (2 owners) 12 -> 0.407,
+// every even length the LDS buffers hold: 8-D x 4096 chains (1 owner; recorders not filling) 14 steps 0.290 ms per
+// launch, 20 -> 0.308, 24 -> 0.274, 28 -> 0.269, 32 -> 0.268; 16-D x 8192 (2 owners) 12 -> 0.407,
 // 14 -> 0.395, 16 -> 0.382; 16-D x 12 288 (3 owners) 13 -> 0.548, 16 -> 0.547, 18 -> 0.508, 20 -> 0.501, 22 -> 0.522;
 // 16-D x 16 384 (4 owners) 8 -> 0.750, 10 -> 0.725, 12 -> 0.661, 14 -> 0.663, 16 -> 0.655.  The pattern is not monotonic: how the
 // phase's items (a two-step item per owner and step pair, one acceptance item per owner) deal out over the filling
@@ -27,7 +27,7 @@ static size_t lds_for(int lpc, int own, int rec, int K)
 int mcxk_persist_ksteps(int lpc, int own)
 {
   const int rec = mcxk_persist_recorders(own) ? 1 : 0;
-  int k = own == 1 ? 24 : (own == 2 ? 16 : (own == 3 ? 20 : (own == 4 ? 16 : PWAVES - own - rec * own)));
+  int k = own == 1 ? 32 : (own == 2 ? 16 : (own == 3 ? 20 : (own == 4 ? 16 : PWAVES - own - rec * own)));
   while (k > 2 && (k > PKMAX || lds_for(lpc, own, rec, k) > MCXK_PERSIST_LDS_LIMIT)) k -= 2;
   return k;
 }
