@@ -1045,16 +1045,17 @@ static __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsi
 // genRemote (src/mcpar.cc:315-451).  One lane per chain (two chains per lane at 16-D and 32-D), chain vector in registers, the N
 // per-chain Gaussians Q_i staged through LDS a block at a time and read back as broadcasts.
 // ---------------------------------------------------------------------------------------------
-// qpar[i] = (m'_i, s_i) with s = sqrt(1/sig2), m' = mu s: sum_k (mu_k - x_k)^2 / sig2_k (src/mcpar.cc:369-383)
-// is then sum_k t_k^2 with t_k = fma(-x_k, s_k, m'_k) -- two operations per pair-dimension.  One Q_i is 2d
+// qpar[i] = (mu_i, w_i), w = 1/sig2: sum_k (mu_k - x_k)^2 / sig2_k (src/mcpar.cc:369-383) is formed the way the
+// reference forms it -- xm = mu - x first, so a chain on a Gaussian's mean gives exactly 0 however narrow the
+// Gaussian, then xm * xm -- with the division replaced by a multiplication with w (arithmetic v3: sub, mul,
+// fma per pair-dimension; v2's fma(-x, s, mu s) lost the cancellation when |mu| s was large).  One Q_i is 2d
 // contiguous floats.
 static __global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ qpar, size_t nd)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nd) {
     const float2 ms = reinterpret_cast<const float2 *>(musigall)[i];
-    const float sq = __builtin_sqrtf(1.0f / ms.y);
-    reinterpret_cast<float2 *>(qpar)[i] = make_float2(ms.x * sq, sq);
+    reinterpret_cast<float2 *>(qpar)[i] = make_float2(ms.x, 1.0f / ms.y);
   }
 }
 
@@ -1065,7 +1066,7 @@ static __global__ void k_remote_prep(const float *__restrict__ musigall, float *
 // as the oracle's qarg().  One Q_i against 64 chains is mostly far away from all of them, so most of the
 // sweep ends after the first group.  use(arg) consumes a completed sum; bound() is re-read per Q_i.
 // Every lane reads the same address (a broadcast ds_read_b128 = two dimensions), so both operands of
-// t = fma(-x, s, m') arrive in VGPRs.  Round 1 streamed the rows through wave-uniform scalar loads instead:
+// xm = mu - x, fma(xm xm, w, arg) arrive in VGPRs.  Round 1 streamed the rows through wave-uniform scalar loads instead:
 // VALU instructions take one scalar operand, so m' went through a v_mov (3 instead of 2 instructions per
 // pair-dimension), and scalar loads return out of order -- every wait is a wait for all of them -- which
 // exposed their full latency once per group (VALU 60 % busy).  Same operations in the same order: same bits.
@@ -1082,12 +1083,12 @@ __device__ __forceinline__ void sweep_rows(const float *rows, int nrow, const fl
   for (int k = 0; k < G4; ++k) cur[k] = rp[k];
   auto two_dims = [&](float4 v, int k, float arg) {  // dimensions k, k + 1 (k even)
     if (EXACT || k < DD) {
-      const float t = __builtin_fmaf(-x[k], v.y, v.x);
-      arg = __builtin_fmaf(t, t, arg);
+      const float xm = v.x - x[k];
+      arg = __builtin_fmaf(xm * xm, v.y, arg);
     }
     if (EXACT || k + 1 < DD) {
-      const float t = __builtin_fmaf(-x[k + 1], v.w, v.z);
-      arg = __builtin_fmaf(t, t, arg);
+      const float xm = v.z - x[k + 1];
+      arg = __builtin_fmaf(xm * xm, v.w, arg);
     }
     return arg;
   };
@@ -1135,10 +1136,10 @@ __device__ __forceinline__ void sweep_rows2(const float *rows, int nrow, const f
 #pragma unroll
   for (int k = 0; k < G4; ++k) cur[k] = rp[k];
   auto two_dims = [&](float4 v, int k, f32x2 arg) {
-    const f32x2 t0 = fma2(-x[k], splat2(v.y), splat2(v.x));
-    arg = fma2(t0, t0, arg);
-    const f32x2 t1 = fma2(-x[k + 1], splat2(v.w), splat2(v.z));
-    arg = fma2(t1, t1, arg);
+    const f32x2 xm0 = splat2(v.x) - x[k];
+    arg = fma2(xm0 * xm0, splat2(v.y), arg);
+    const f32x2 xm1 = splat2(v.z) - x[k + 1];
+    arg = fma2(xm1 * xm1, splat2(v.w), arg);
     return arg;
   };
   const unsigned long long everyone = __ballot(true), no_a = __ballot(!valid_a), no_b = __ballot(!valid_b);
@@ -1178,7 +1179,7 @@ struct RemoteArgs {
   int nact;
   int *active_out;
   int *nact_out;
-  const float *musigall, *winv, *cmax;  // winv = qpar: (m', s) pairs
+  const float *musigall, *winv, *cmax;  // winv = qpar: (mu, 1/sig2) pairs
   float *ptrial, *mutrial, *sigtrial, *cfac;
   float *racpt;        // [n] rejection threshold of this pass, by chain
   float *psum, *pmax;  // [S][nact] per-block partial sums / maxima, by position in the active list
@@ -1298,8 +1299,8 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
         for (int k = 0; k < DMAX; ++k)
           if (EXACT || k < DD) {
             const float xk = CPL == 1 ? x[CPL == 1 ? k : 0] : (c == 0 ? xx[CPL == 2 ? k : 0].x : xx[CPL == 2 ? k : 0].y);
-            const float t = __builtin_fmaf(-xk, qo[2 * k + 1], qo[2 * k]);
-            a0 = __builtin_fmaf(t, t, a0);
+            const float xm = qo[2 * k] - xk;
+            a0 = __builtin_fmaf(xm * xm, qo[2 * k + 1], a0);
           }
         const float old = c == 0 ? amin.x : amin.y;
         const float now = a0 < old ? a0 : old;  // a NaN stays out, like below
@@ -1418,8 +1419,8 @@ __device__ __forceinline__ float q_arg_mem(const float *__restrict__ qp, const f
 {
   float arg = 0.0f;
   for (int k = 0; k < d; ++k) {
-    const float t = __builtin_fmaf(-x[k], qp[2 * k + 1], qp[2 * k]);
-    arg = __builtin_fmaf(t, t, arg);
+    const float xm = qp[2 * k] - x[k];
+    arg = __builtin_fmaf(xm * xm, qp[2 * k + 1], arg);
   }
   return arg;
 }

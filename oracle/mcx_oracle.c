@@ -1,7 +1,7 @@
 /*
  * mcx_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See mcx_oracle.h.
  *
- * Every function cites the reference lines it restates.  "MCX arithmetic v2" 
+ * Every function cites the reference lines it restates.  "MCX arithmetic v3" 
  * is restated here independently of mcpar_amd/csrc/: nothing is shared with the product
  * except the written specification.
  *
@@ -361,7 +361,7 @@ mcxo_engine *mcxo_create(int np, int nc, int nshards, int shard, float pl, float
   e->sig = zalloc(4 * nt); e->mutrial = zalloc(4 * nt); e->sigtrial = zalloc(4 * nt);
   e->psum2 = zalloc(4 * nt);
   e->musigall = zalloc(8 * (size_t)e->tchains * np);
-  e->winvall = zalloc(8 * (size_t)e->tchains * np); /* (m', s) pairs of the Murray sweep */
+  e->winvall = zalloc(8 * (size_t)e->tchains * np); /* (mu, 1/sig2) pairs of the Murray sweep */
   e->lylast = zalloc(4 * n); e->lytrial = zalloc(4 * n); e->cfac = zalloc(4 * n);
   e->pacpt = zalloc(4 * n); e->acpt = zalloc(4 * n); e->qisum = zalloc(4 * n);
   e->qimax = zalloc(4 * n); e->cmax = zalloc(4 * n);
@@ -426,15 +426,16 @@ int mcxo_gen_local(const mcxo_engine *e, uint32_t t, const float *pvals, float *
   return 0;
 }
 
-/* sum_k (mu_qk - x_k)^2 / sig2_qk (src/mcpar.cc:369-383) as sum_k t_k^2, t_k = s_qk (mu_qk - x_k) evaluated
- * as fma(-x_k, s_qk, m'_qk) with s = sqrt(1/sig2) and m' = mu s precomputed per Gaussian: two operations per
- * pair-dimension.  qp = the Gaussian's (m', s) pairs. */
+/* sum_k (mu_qk - x_k)^2 / sig2_qk exactly as src/mcpar.cc:369-383 forms it -- xm = mu - x first (so a chain
+ * sitting on a Gaussian's mean gives exactly 0 however narrow the Gaussian), then xm*xm -- with the division
+ * replaced by a multiplication with w = 1/sig2, precomputed once per Gaussian ("MCX arithmetic v3"; v2's
+ * fma(-x, s, mu s) lost the cancellation when |mu| s was large).  qp = the Gaussian's (mu, 1/sig2) pairs. */
 static inline float qarg(int d, const float *qp, const float *x)
 {
   float arg = 0.0f;
   for (int k = 0; k < d; ++k) {
-    float t = fmaf(-x[k], qp[2 * k + 1], qp[2 * k]);
-    arg = fmaf(t, t, arg);
+    float xm = qp[2 * k] - x[k];
+    arg = fmaf(xm * xm, qp[2 * k + 1], arg);
   }
   return arg;
 }
@@ -474,10 +475,10 @@ static void sweep_scalar(int d, int N, const float *qpar, const float *x, float 
 #include <immintrin.h>
 #define MCXO_HAVE_AVX2 1
 /* The same sweep, eight Q_i at a time: every lane performs exactly the scalar sequence of IEEE
- * operations (two fma per dimension, the mcxo_expf polynomial), the eight results are then added / compared
+ * operations (sub, mul, fma per dimension, the mcxo_expf polynomial), the eight results are then added / compared
  * one by one in index order -- same bits as sweep_scalar (tests/test_oracle_numerics.py checks it),
  * ~8x faster, which is what makes oracle comparisons at 32 768 - 65 536 chains affordable.
- * qt = (m', s) of the Gaussians regrouped in blocks of 8: qt[(b*d + k)*16 + {0..7 | 8..15}]. */
+ * qt = (mu, 1/sig2) of the Gaussians regrouped in blocks of 8: qt[(b*d + k)*16 + {0..7 | 8..15}]. */
 __attribute__((target("avx2,fma"))) static inline __m256 expf8(__m256 x)
 {
   const __m256 fn = _mm256_floor_ps(_mm256_fmadd_ps(x, _mm256_set1_ps(1.44269504f), _mm256_set1_ps(0.5f)));
@@ -514,8 +515,8 @@ __attribute__((target("avx2,fma"))) static void sweep_avx2(int d, int N, const f
       const float *q = qt + (size_t)(qi >> 3) * d * 16;
       __m256 arg = _mm256_setzero_ps();
       for (int k = 0; k < d; ++k) {
-        const __m256 t = _mm256_fnmadd_ps(_mm256_set1_ps(x[k]), _mm256_loadu_ps(q + 16 * k + 8), _mm256_loadu_ps(q + 16 * k));
-        arg = _mm256_fmadd_ps(t, t, arg);
+        const __m256 xm = _mm256_sub_ps(_mm256_loadu_ps(q + 16 * k), _mm256_set1_ps(x[k]));
+        arg = _mm256_fmadd_ps(_mm256_mul_ps(xm, xm), _mm256_loadu_ps(q + 16 * k + 8), arg);
       }
       vmin = _mm256_min_ps(arg, vmin); /* a NaN arg leaves vmin as it is, like `a < amin ? a : amin` */
     }
@@ -538,8 +539,8 @@ __attribute__((target("avx2,fma"))) static void sweep_avx2(int d, int N, const f
       const float *q = qt + (size_t)(qi >> 3) * d * 16;
       __m256 arg = _mm256_setzero_ps();
       for (int k = 0; k < d; ++k) {
-        const __m256 t = _mm256_fnmadd_ps(_mm256_set1_ps(x[k]), _mm256_loadu_ps(q + 16 * k + 8), _mm256_loadu_ps(q + 16 * k));
-        arg = _mm256_fmadd_ps(t, t, arg);
+        const __m256 xm = _mm256_sub_ps(_mm256_loadu_ps(q + 16 * k), _mm256_set1_ps(x[k]));
+        arg = _mm256_fmadd_ps(_mm256_mul_ps(xm, xm), _mm256_loadu_ps(q + 16 * k + 8), arg);
       }
       float gv[8];
       _mm256_storeu_ps(gv, expf8(_mm256_mul_ps(mhalf, arg)));
@@ -581,11 +582,10 @@ int mcxo_gen_remote(mcxo_engine *e, uint32_t t, const float *pvals, const float 
                     float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
 {
   const int d = e->nparam, n = e->nchain, N = e->tchains, nb = (d + 3) / 4;
-  float *qpar = e->winvall; /* (m', s) pairs: s = sqrt(1/sig2), m' = mu s */
+  float *qpar = e->winvall; /* (mu, w) pairs, w = 1/sig2 */
   for (size_t i = 0; i < (size_t)N * d; ++i) {
-    const float sq = sqrtf(1.0f / musigall[2 * i + 1]);
-    qpar[2 * i] = musigall[2 * i] * sq;
-    qpar[2 * i + 1] = sq;
+    qpar[2 * i] = musigall[2 * i];
+    qpar[2 * i + 1] = 1.0f / musigall[2 * i + 1];
   }
   const int vec = use_avx2();
   float *qt = NULL;

@@ -106,3 +106,47 @@ def test_vectorised_murray_sweep_equals_the_scalar_statement():
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     finally:
         O.lib().mcxo_set_scalar_sweep(0)
+
+
+def _murray_f64(pvals, ptrial, ms):
+    """float64 evaluation of the reference's own formula, xm = mu - x; arg += xm*xm/sig2 (src/mcpar.cc:369-386,
+    425-436): max_i Q_i(pvals), max_i Q_i(ptrial)"""
+    mu, s2 = ms[:, :, 0].astype(np.float64), ms[:, :, 1].astype(np.float64)
+
+    def qmax(x):
+        arg = (((mu[None] - x[:, None].astype(np.float64)) ** 2) / s2[None]).sum(2)
+        return np.exp(-0.5 * arg.min(1))
+    return qmax(pvals), qmax(ptrial)
+
+
+def test_murray_sweep_keeps_the_cancellation_of_the_reference_formula():
+    """(mu - x)^2 / sig2 must be formed from the exact difference.  Chains that have not moved since
+    the main loop began sit exactly on their own Gaussian's mean with sig2 = FPEPS / pwgt ~ 1e-15..1e-16: the
+    reference gives arg = 0, Q = 1 there (so cfac's numerator is exactly 1); and targets far from the origin
+    with narrow per-chain Gaussians (|mu| / sigma ~ 1e5) must not lose the digits of mu - x either."""
+    rng = np.random.default_rng(11)
+    d, n = 16, 192
+    # (a) never-accepted chains among ordinary ones
+    ms = np.empty((n, d, 2), np.float32)
+    ms[:, :, 0] = rng.normal(0.3, 0.5, (n, d))
+    ms[:, :, 1] = rng.uniform(0.02, 0.2, (n, d)) ** 2
+    stuck = np.arange(0, n, 3)
+    ms[stuck, :, 1] = np.float32(1e-14) / np.float32(rng.integers(10, 90, (len(stuck), 1)))
+    pv = (ms[:, :, 0] + np.sqrt(ms[:, :, 1]) * rng.standard_normal((n, d))).astype(np.float32)
+    pv[stuck] = ms[stuck, :, 0]
+    e = O.Engine(d, n, threads=4)
+    pt, cf, mt, sg, npass = e.gen_remote(17, pv, ms)
+    e.close()
+    cmax64, qmax64 = _murray_f64(pv, pt, ms)
+    assert np.all(cmax64[stuck] == 1.0)
+    np.testing.assert_allclose(cf, np.maximum(cmax64, 0) / np.maximum(qmax64, 1e-14), rtol=2e-4)
+    assert np.all(np.abs(cf[stuck] * qmax64[stuck] - 1.0) < 2e-4)  # numerator exactly 1 for the stuck chains
+    # (b) a shifted, narrow target: |mu| ~ 1000, sigma ~ 0.01
+    ms[:, :, 0] = 1000.0 + rng.normal(0, 0.05, (n, d))
+    ms[:, :, 1] = rng.uniform(0.008, 0.02, (n, d)) ** 2
+    pv = (ms[:, :, 0] + np.sqrt(ms[:, :, 1]) * rng.standard_normal((n, d))).astype(np.float32)
+    e = O.Engine(d, n, threads=4)
+    pt, cf, mt, sg, npass = e.gen_remote(23, pv, ms)
+    e.close()
+    cmax64, qmax64 = _murray_f64(pv, pt, ms)
+    np.testing.assert_allclose(cf, cmax64 / np.maximum(qmax64, 1e-14), rtol=5e-4)
