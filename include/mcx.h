@@ -8,7 +8,7 @@
  * shims over these functions.  See INTEGRATION.md for the binding a maintainer would add.
  *
  * Plain pointers and sizes only.  Unless a parameter says "device", pointers are host memory.
- * All arithmetic is float32 ("MCX arithmetic v2"); accept decisions are bit-exact
+ * All arithmetic is float32 ("MCX arithmetic v3"); accept decisions are bit-exact
  * against oracle/mcx_oracle.c for a fixed seed.
  *
  * Every function returns MCX_OK (0) or an mcx_status; mcx_last_error() gives the message.
@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 2
+#define MCX_ABI_VERSION 3
 
 typedef enum mcx_status {
   MCX_OK = 0,
@@ -169,9 +169,15 @@ enum {
                               the chains while the other wavefronts of each CU generate their random numbers into LDS
                               (same bits).  -1 auto [default: when the chains fill at most 8 wavefronts per CU and
                               SPLIT_RNG is not 0], 0 off, 1 on */
-  MCX_OPT_EAGER_EXCHANGE = 7 /* 0 [default]: gather the latest sync-point snapshot only when a Murray step (or
+  MCX_OPT_EAGER_EXCHANGE = 7, /* 0 [default]: gather the latest sync-point snapshot only when a Murray step (or
                               the end of the run) will read it -- bit-identical to 1: gather at every sync
                               point like the reference (src/mcpar.cc:127-140), overlapped with compute */
+  MCX_OPT_MEET_TIMEOUT_MS = 11, /* small-n mode: how long a tuner meeting of the one-launch kernel may wait for a
+                              workgroup that is not resident (CU mask, partitioned device, foreign kernel) before
+                              the launch is abandoned and the run repeated on the per-segment kernels (same bits;
+                              mcx_counters.meet_timeouts counts it) [default 2000] */
+  MCX_OPT_DEBUG_MEET = 12    /* test hook: the meetings wait for `value` workgroups more than the grid has, i.e.
+                              they can never complete [default 0] */
 };
 int mcx_set_option(mcx_engine *e, int opt, int64_t value);
 
@@ -182,8 +188,14 @@ typedef struct mcx_counters {
   uint64_t remote_steps, remote_passes; /* genRemote calls / rejection passes */
   uint64_t exchanges;
   uint64_t kernel_launches;
-  uint64_t remote_pairs; /* (chain, Q_i) pairs evaluated by the Murray sweeps: sum over passes of n_active * N,
-                            plus n * N per genRemote call for the cfac numerator (src/mcpar.cc:367-395, 421-437) */
+  uint64_t remote_pairs; /* (chain, Q_i) pairs of the Murray sweeps as the reference loops over them: sum over
+                            passes of n_active * N, plus n * N per genRemote call for the cfac numerator
+                            (src/mcpar.cc:367-395, 421-437) */
+  uint64_t remote_pairs_evaluated; /* of those, the pairs whose arg the sweep kernels actually started to
+                            accumulate: the rest were excluded by an exact bound (their Q_i is exactly 0, or
+                            cannot lower the running minimum) before any per-pair work */
+  uint64_t meet_timeouts; /* runs repeated on the per-segment kernels because a tuner meeting of the one-launch
+                            small-n kernel was abandoned (MCX_OPT_MEET_TIMEOUT_MS) */
 } mcx_counters;
 int mcx_get_counters(mcx_engine *e, mcx_counters *c);
 

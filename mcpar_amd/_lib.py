@@ -25,7 +25,7 @@ class VLFunc(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("naccept_burn", "naccept_main", "nsteps_burn", "nsteps_main",
                                           "remote_steps", "remote_passes", "exchanges", "kernel_launches",
-                                          "remote_pairs")]
+                                          "remote_pairs", "remote_pairs_evaluated", "meet_timeouts")]
 
 
 K_NAMES = ("fused_burn", "fused_main", "propose", "eval", "accept", "remote", "tuner", "misc", "remote_sweep",

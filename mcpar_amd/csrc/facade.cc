@@ -97,9 +97,13 @@ void MCout::output()
 // rows added since the last flush, all ranks', rank-major; buffer exists on rank 0 only
 float *MCout::collect(size_t *ntot)
 {
-  *ntot = 0;
   const size_t fresh = fill_ > flushed_ ? fill_ - flushed_ : 0;
-  if (fresh == 0) return 0;
+  if (fresh == 0) {
+    *ntot = 0;
+    return 0;
+  }
+  // (like the reference, ranks other than 0 leave *ntot alone when they had rows to send: src/mcout.cc:80-92;
+  // pinned by tests/golden/mcout_reference.json)
   float *gathered = 0;
   if (rank_ == 0) {
     *ntot = fresh * static_cast<size_t>(nranks_);

@@ -13,9 +13,19 @@
 #include <sys/file.h>
 #include <sys/stat.h>
 #include <unistd.h>
-#include <rccl/rccl.h>  // types only: librccl.so.1 is loaded at run time (mcx_rccl_*), never linked
+// RCCL types only: librccl.so.1 is loaded at run time (mcx_rccl_*), never linked, and a build machine without the
+// RCCL development headers gets the handful of declarations the dlopen shim needs
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+#endif
 
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -375,9 +385,14 @@ struct mcx_engine {
   PinBuf<unsigned long long> h_ctr;  // the run's counters, read back once at its end
   std::vector<float> h_cov, h_cov_dev, h_winv;  // h_cov_dev = what cov0 holds
   bool cov_pending = false;  // cov has not been reset to cov0 for the current run yet
+  bool cov_offdiag = false;  // cov (device) may hold non-zero entries below the diagonal
   int ctr_set = 0;           // counter block of the current run (ring of CTR_RING blocks, zeroed when it wraps)
   int meet_fd = -1;          // lock file of this GPU: at most one kernel with grid-wide meetings in flight (see meet_lock_open)
   bool meet_held = false;    // this engine holds the lock: a launch with meetings may still be running
+  bool meet_check = false;   // a launch with meetings is in flight: its "abandoned" word has not been looked at yet
+  unsigned long long *meet_word = nullptr;  // that word (ctr[5] of the run's counter block)
+  bool persist_broken = false;  // a meeting was abandoned once on this engine: the one-launch kernel is not used again
+  int opt_meet_timeout_ms = 2000, opt_debug_meet = 0;
   // run bookkeeping
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -633,6 +648,14 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
   case MCX_OPT_EAGER_EXCHANGE: e->opt_eager = value ? 1 : 0; break;
   case MCX_OPT_SPLIT_RNG: e->opt_split = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_PERSIST: e->opt_persist = value < 0 ? -1 : (value ? 1 : 0); break;
+  case MCX_OPT_MEET_TIMEOUT_MS:
+    if (value < 1) return fail(MCX_ERR_INVALID, "MEET_TIMEOUT_MS must be >= 1");
+    e->opt_meet_timeout_ms = (int)std::min<int64_t>(value, 600000);
+    break;
+  case MCX_OPT_DEBUG_MEET:
+    e->opt_debug_meet = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
+    e->persist_broken = false;  // (a test switching the hook off again gets the one-launch kernel back)
+    break;
   case MCX_OPT_STREAM:
     if (e->own_stream && e->stream) {
       (void)hipStreamSynchronize(e->stream);
@@ -671,6 +694,7 @@ static int covar_install(mcx_engine *e, const float *incov, float *cov_out, bool
     HIPCHK(hipMemcpyAsync(e->cov.p, e->cov0.p, c.size() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->cov_pending = false;
+    e->cov_offdiag = !e->diag;
   } else {
     e->cov_pending = true;  // the run resets it: k_run_small reads cov0 itself, every other path copies first
   }
@@ -683,6 +707,7 @@ static int cov_reset(mcx_engine *e)
   if (!e->cov_pending) return MCX_OK;
   HIPCHK(hipMemcpyAsync(e->cov.p, e->cov0.p, (size_t)e->ncov * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
   e->cov_pending = false;
+  e->cov_offdiag = !e->diag;
   return MCX_OK;
 }
 
@@ -1190,18 +1215,35 @@ extern "C" int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed,
 // (main-loop steps only: workgroups are independent) need none.  flock() excludes both other processes and
 // other engines of this process (each engine has its own open file description).
 // ---------------------------------------------------------------------------------------------
-// the launch that took the lock has completed (or is waited for here): let the next one in
+// internal status of run_once(): a tuner meeting of k_run_small was abandoned (or its grid cannot be resident):
+// mcx_run repeats the run on the per-segment kernels.  Never leaves this file.
+constexpr int MCX_INTERNAL_MEET_ABANDONED = 1000;
+
+// the launch that took the lock has completed (or is waited for here): let the next one in, and look at the
+// launch's "abandoned" word -- before any of its results is used or shown to a hook
 static int meet_release(mcx_engine *e, bool stream_is_idle)
 {
-  if (!e->meet_held) return MCX_OK;
+  if (!e->meet_held && !e->meet_check) return MCX_OK;
   hipError_t se = hipSuccess;
   if (!stream_is_idle) se = hipStreamSynchronize(e->stream);
-  (void)flock(e->meet_fd, LOCK_UN);
-  e->meet_held = false;
+  if (e->meet_held) {
+    (void)flock(e->meet_fd, LOCK_UN);
+    e->meet_held = false;
+  }
   HIPCHK(se);
+  if (e->meet_check) {
+    e->meet_check = false;
+    unsigned long long w = 0;
+    HIPCHK(hipMemcpyAsync(&w, e->meet_word, sizeof w, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (w) return MCX_INTERNAL_MEET_ABANDONED;
+  }
   return MCX_OK;
 }
 
+// One fixed path per GPU (PCI bus id), the same for every process and user whatever their TMPDIR: /dev/shm
+// first (always local, never a per-job directory), /tmp second.  O_NOFOLLOW: a symbolic link planted under the
+// name is not followed; the mode is widened only on the file this call created.
 static bool meet_lock_open(mcx_engine *e)
 {
   if (e->meet_fd >= 0) return true;
@@ -1209,18 +1251,29 @@ static bool meet_lock_open(mcx_engine *e)
   (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, e->device);
   for (char *c = bus; *c; ++c)
     if (*c == ':' || *c == '/') *c = '_';
-  const char *dirs[] = {getenv("TMPDIR"), "/tmp", "/dev/shm"};
+  const char *dirs[] = {"/dev/shm", "/tmp"};
   for (const char *d : dirs) {
-    if (!d || !*d) continue;
     const std::string path = std::string(d) + "/mcx_meet_" + bus + ".lock";
-    const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+    int fd = open(path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0666);
+    if (fd >= 0) (void)fchmod(fd, 0666);  // created here: shared by every user of the GPU
+    else fd = open(path.c_str(), O_RDWR | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);  // (another user's file: flock needs no write access)
     if (fd >= 0) {
-      (void)fchmod(fd, 0666);  // shared by every user of the GPU
       e->meet_fd = fd;
       return true;
     }
   }
   return false;
+}
+
+static int meet_lock_take(mcx_engine *e)
+{
+  int rc;
+  do rc = flock(e->meet_fd, LOCK_EX);
+  while (rc != 0 && errno == EINTR);
+  if (rc != 0) return fail(MCX_ERR_HIP, "cannot lock the GPU's meeting lock file: %s", strerror(errno));
+  e->meet_held = true;
+  return MCX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1284,15 +1337,41 @@ extern "C" int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_
   return MCX_OK;
 }
 
+static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L, const float *incov);
+
 extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L,
                        const float *incov)
 {
   MCXCHK(enter(e));
-  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  int rc = run_once(e, nsamp, nburn, pinit, L, incov);
+  uint64_t repeated = 0;
+  if (rc == MCX_INTERNAL_MEET_ABANDONED) {
+    // A tuner meeting of the one-launch small-n kernel was abandoned: some workgroup of its grid was not
+    // resident (CU mask, partitioned device, a foreign kernel on the CUs).  The launch wrote nothing back and
+    // the step counter has not moved: repeat the run on the per-segment kernels (same bits), and keep to them.
+    (void)hipStreamSynchronize(e->stream);
+    e->persist_broken = true;
+    repeated = 1;
+    rc = run_once(e, nsamp, nburn, pinit, L, incov);
+    if (rc == MCX_INTERNAL_MEET_ABANDONED) rc = fail(MCX_ERR_HIP, "internal: meeting abandoned without the one-launch kernel");
+  }
+  e->cnt.meet_timeouts = repeated;
+  if (rc != MCX_OK) {  // never leave the GPU's meeting lock behind a failed run
+    if (e->meet_held) {
+      (void)hipStreamSynchronize(e->stream);
+      (void)flock(e->meet_fd, LOCK_UN);
+      e->meet_held = false;
+    }
+    e->meet_check = false;
+  }
+  return rc;
+}
+
+static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L, const float *incov)
+{
   if (nsamp < 0 || nburn < 0) return fail(MCX_ERR_INVALID, "bad run arguments");
   if (!pinit && !e->pinit_staged) return fail(MCX_ERR_INVALID, "pinit is NULL and no state was staged (mcx_stage_pinit)");
   if (e->size > 1 && !e->xfn) return fail(MCX_ERR_EXCHANGE, "nshards > 1 needs mcx_set_exchange()");
-  MCXCHK(meet_release(e, false));  // (left over from a run that failed half-way)
   const int n = e->nchain, d = e->nparam;
   hipStream_t st = e->stream;
   MCXCHK(lik_setup(e->lik, L, d, st));
@@ -1350,7 +1429,7 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   const bool persist = fused && e->lpc <= 8 && fast_lik && e->diag && e->vec4 && !e->opt_mask && e->ncu > 0 &&
                        nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
                        mcxk_persist_lds_bytes(e->lpc, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
-                       (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0)) &&
+                       (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0)) && !e->persist_broken &&
                        (nburn == 0 || meet_lock_open(e));
   // When the run opens with such a launch, the launch itself takes the initial state (and its likelihood,
   // src/mcpar.cc:47-53) and the factor as installed, and starts its counters afresh: no reset kernels at all.
@@ -1427,12 +1506,20 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
         ra.x0 = lead ? (pinit ? e->pvals.p : e->pinit_dev.p) : nullptr;
         ra.T0 = e->cov_pending ? e->cov0.p : nullptr;
         ra.fresh = lead ? 1 : 0;
+        if (e->cov_pending && e->cov_offdiag) {
+          // the kernel writes back the diagonal only: a full factor left in cov by an earlier run must not
+          // survive next to it (mcx_get_chol would return a mixture)
+          HIPCHK(hipMemcpyAsync(e->cov.p, e->cov0.p, (size_t)e->ncov * sizeof(float), hipMemcpyDeviceToDevice, st));
+          e->cov_offdiag = false;
+        }
         e->cov_pending = false;
         lead = false;
         ra.nown = nown;
         const int nwg = std::min(nown, e->ncu);
         ra.own = (nown + nwg - 1) / nwg;
         ra.ksteps = mcxk_persist_ksteps(e->lpc, ra.own);
+        ra.meet_timeout = (unsigned long long)e->opt_meet_timeout_ms * 100000ull;  // s_memrealtime: 100 MHz
+        ra.meet_expect_extra = e->opt_debug_meet;
         if (snap >= 0) {  // the kernel rewrites this shard's slot: no gather may still be reading it
           MCXCHK(exchange_wait(e));
           e->published_steps = is0 + snap + 1;
@@ -1445,15 +1532,20 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
         // tuner events inside: exclusive on this GPU until the kernel has completed.  The lock is given back at
         // the run's next synchronisation with the stream -- before any user hook may block this thread, at the latest
         // at the end of the run
-        if (pb > 0) {
-          if (flock(e->meet_fd, LOCK_EX) != 0) return fail(MCX_ERR_HIP, "cannot lock the GPU's meeting lock file");
-          e->meet_held = true;
-        }
+        if (pb > 0) MCXCHK(meet_lock_take(e));
         {
           ProfScope ps(e, MCX_K_RUN_SMALL, (uint64_t)(pb + pm) * n);
           const hipError_t le = mcxk_launch_persist(e->lpc, e->lik.kind, ra, st);
           if (le != hipSuccess) (void)meet_release(e, true);
+          if (le == hipErrorCooperativeLaunchTooLarge) {  // the grid cannot be resident at once on this device
+            (void)hipGetLastError();
+            return MCX_INTERNAL_MEET_ABANDONED;
+          }
           HIPCHK(le);
+          if (pb > 0) {  // looked at by meet_release, at the latest at the end of the run
+            e->meet_check = true;
+            e->meet_word = ctrp + 5;
+          }
         }
         pi = pj - 1;
         continue;
@@ -1567,8 +1659,11 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   {
     const hipError_t se = hipStreamSynchronize(st);
+    const bool abandoned = e->meet_check && se == hipSuccess && hctr[5] != 0;  // (the word came with the counters)
+    e->meet_check = false;
     (void)meet_release(e, true);
     HIPCHK(se);
+    if (abandoned) return MCX_INTERNAL_MEET_ABANDONED;
   }
   e->cnt.naccept_burn = hctr[3];
   e->cnt.naccept_main = hctr[4];

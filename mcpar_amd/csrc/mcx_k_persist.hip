@@ -49,7 +49,25 @@ static hipError_t go2(const RunArgs &a, hipStream_t st)
     attr_set = true;
   }
   const unsigned nwg = (unsigned)((a.nown + a.own - 1) / a.own);
-  hipLaunchKernelGGL((k_run_small<LPC, LIK, REC>), dim3(nwg), dim3(PBLOCK), mcxk_persist_lds_bytes(LPC, a.own), st, a);
+  const size_t lds = mcxk_persist_lds_bytes(LPC, a.own);
+  if (a.nburn > 0) {
+    // tuner meetings inside: every workgroup of the grid must be resident at once.  What the occupancy
+    // calculator and the device's CU count promise is checked here; what they cannot see (a CU mask, a foreign
+    // kernel holding LDS) is caught by the meetings' own timeout.
+    static size_t asked_lds = ~(size_t)0;  // (per instantiation: the answer depends on the LDS request only)
+    static int asked_per_cu = 0;
+    int per_cu = asked_per_cu, ncu = 0, dev = 0;
+    hipError_t e = hipSuccess;
+    if (asked_lds != lds) {
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_run_small<LPC, LIK, REC>), PBLOCK, lds);
+      if (e == hipSuccess) { asked_per_cu = per_cu; asked_lds = lds; }
+    }
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    if ((long long)per_cu * ncu < (long long)nwg) return hipErrorCooperativeLaunchTooLarge;
+  }
+  hipLaunchKernelGGL((k_run_small<LPC, LIK, REC>), dim3(nwg), dim3(PBLOCK), lds, st, a);
   return hipGetLastError();
 }
 

@@ -26,9 +26,14 @@
 //
 // Same functions, same bits as the per-segment kernels (tests/test_gpu_run_parity.py, test_gpu_fuzz.py).
 // Every workgroup of a launch that contains tuner events must be resident at once: the grid is at most one
-// workgroup per CU, and the host holds a per-GPU lock while such a launch is in flight (mcx_engine.hip,
-// meet_lock_open), so no second kernel of this kind -- from this or any other process -- can take part of the
-// CUs and leave two kernels waiting for each other.  Launches of main-loop steps only have no meetings.
+// workgroup per CU (checked against the kernel's occupancy at launch), and the host holds a per-GPU lock while
+// such a launch is in flight (mcx_engine.hip, meet_lock_open), so no second kernel of this kind can take part of
+// the CUs and leave two kernels waiting for each other.  That is a courtesy, not the guarantee: a CU mask, a
+// partitioned device or a foreign kernel holding LDS can still keep workgroups out, so a meeting that is not
+// complete after RunArgs::meet_timeout ticks of the 100 MHz wall clock is ABANDONED -- the waiting owner marks
+// the meeting word, every workgroup leaves its phase loop at the next barrier, the launch ends without writing
+// state back, ctr[5] tells the host, and mcx_run repeats the run on the per-segment kernels.  Launches of
+// main-loop steps only have no meetings.
 #pragma once
 #include "mcx_device.hpp"
 
@@ -63,19 +68,26 @@ struct RunArgs {
   int snap_after;           // main step (relative to isamp0) after which the slot is snapshot, or -1
   int final_publish;        // 1: the launch ends the run of a single shard: slot and sig from the final moments
   float armin, armax, dfac, ifac;
-  unsigned long long *ctr;  // [1] tuner naccept [2] tuner ntrial [3] burn-in accepts [4] main-loop accepts
+  unsigned long long *ctr;  // [1] tuner naccept [2] tuner ntrial [3] burn-in accepts [4] main-loop accepts [5] a meeting was abandoned
   unsigned long long *bar;  // one word per tuner event of this launch (<= PEVENTS), zero at launch
   float *trace;
   int *ntrace;
   int nown;                 // owner wavefronts in the whole grid = ceil(n * LPC / 64)
   int own;                  // owner wavefronts per workgroup (1..POWN_MAX)
   int ksteps;               // steps per phase (mcxk_persist_ksteps: what the LDS double buffers hold, <= PKMAX)
+  unsigned long long meet_timeout;  // 100 MHz ticks a tuner meeting may take before the launch is abandoned
+  int meet_expect_extra;    // debug (MCX_OPT_DEBUG_MEET): workgroups the meetings wait for beyond the grid's own
 };
 
-// all owners of the grid meet; returns the sum of `mine` over the workgroups.  One atomic per workgroup:
-// the owner waves of a workgroup first add up in LDS.  word = arrivals << 40 | sum.
+constexpr unsigned long long MEET_ABORT_BIT = 1ull << 63;  // in a meeting word: a waiting owner gave up
+constexpr unsigned long long MEET_ABORTED = ~0ull - 1ull;  // in lds_out / as owners_meet's result: abandon the launch
+
+// all owners of the grid meet; returns the sum of `mine` over the workgroups, or MEET_ABORTED when the meeting
+// was abandoned (some workgroup did not arrive within `timeout` wall-clock ticks).  One atomic per workgroup:
+// the owner waves of a workgroup first add up in LDS.  word = abort << 63 | arrivals << 40 | sum.
 __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *word, unsigned mine, int own, int nwg,
-                                                         unsigned *lds_sum, unsigned *lds_cnt, unsigned long long *lds_out)
+                                                         unsigned *lds_sum, unsigned *lds_cnt, unsigned long long *lds_out,
+                                                         unsigned long long timeout)
 {
   // (lanes of a wave are in step; only lane 0 talks)
   unsigned long long total = 0;
@@ -91,11 +103,18 @@ __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *wo
       // compiler's s_waitcnt bookkeeping and put vmcnt waits -- on the previous step's stores -- into the step loop)
       const unsigned long long add = (1ull << 40) | (unsigned long long)s;
       unsigned long long v = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-      while ((int)(v >> 40) < nwg) {
-        __builtin_amdgcn_s_sleep(4);
-        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)((v & ~MEET_ABORT_BIT) >> 40) < nwg && !(v & MEET_ABORT_BIT)) {
+        // bounded wait: the constant-rate wall clock, read once per poll
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        do {
+          __builtin_amdgcn_s_sleep(4);
+          v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)((v & ~MEET_ABORT_BIT) >> 40) >= nwg || (v & MEET_ABORT_BIT)) break;
+          if (__builtin_amdgcn_s_memrealtime() - t_start > timeout)  // someone never arrived: tell everybody
+            v = __hip_atomic_fetch_or(word, MEET_ABORT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | MEET_ABORT_BIT;
+        } while (!(v & MEET_ABORT_BIT));
       }
-      total = v & ((1ull << 40) - 1ull);
+      total = (v & MEET_ABORT_BIT) ? MEET_ABORTED : (v & ((1ull << 40) - 1ull));
       __hip_atomic_store(lds_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
       for (;;) {
@@ -117,7 +136,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ __attribute__((aligned(16))) float lds_means[LIK == LIK_MIX ? 8 * MAXD_LDS : 4];
   __shared__ float lds_logw[8];
-  __shared__ unsigned lds_sum, lds_cnt;
+  __shared__ unsigned lds_sum, lds_cnt, lds_abort;
   __shared__ unsigned long long lds_out[PEVENTS];  // one result word per tuner event (never reused within a launch)
   __shared__ float wbuf[4 * PKMAX];  // 1/pwgt of a phase's main-loop steps, by phase % 4 (written 1 ahead, read 1 behind)
   if (LIK == LIK_MIX) {
@@ -125,7 +144,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
     for (int i = threadIdx.x; i < kd; i += PBLOCK) lds_means[i] = a.lik[i];
     if (threadIdx.x < (unsigned)a.ncomp) lds_logw[threadIdx.x] = a.lik[kd + threadIdx.x];
   }
-  if (threadIdx.x == 0) { lds_sum = 0; lds_cnt = 0; }
+  if (threadIdx.x == 0) { lds_sum = 0; lds_cnt = 0; lds_abort = 0; }
   if (threadIdx.x < PEVENTS) lds_out[threadIdx.x] = ~0ull;
   const int OWN = a.own, NREC = REC ? OWN : 0, K = a.ksteps;  // steps per phase: a multiple of the generator count
   const int T = a.nburn + a.nmain;
@@ -302,7 +321,8 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   // tuner state (src/mcpar.cc:77-96), identical in every owner wave
   unsigned long long tun_na = a.fresh ? 0ull : a.ctr[1], tun_nt = a.fresh ? 0ull : a.ctr[2], burn_acc = 0;
   int irate = 50, seg_start = 0, nevent = 0, ntrace_local = 0;
-  const int nwg = (int)gridDim.x;
+  const int nwg = (int)gridDim.x + a.meet_expect_extra;
+  bool aborted = false;
   const int own_here = a.nown - (int)blockIdx.x * OWN < OWN ? a.nown - (int)blockIdx.x * OWN : OWN;
   int next_event = a.nburn > 0 ? (51 < a.nburn ? 51 : a.nburn - 1) : -1;  // burn-in step of the next tuner event
 
@@ -332,6 +352,9 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   // iteration p: owners run phase p, recorders digest phase p - 1, everybody else fills phase p + 1
   for (int p = 0; p < nphase + (REC ? 1 : 0); ++p) {
     const int buf = p & 1;
+    // a tuner meeting was abandoned during the last phase: every wavefront of the workgroup reads the same flag
+    // (written before the barrier that ended that phase) and leaves here
+    if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { aborted = true; break; }
     if (owner) {
       if (working && p < nphase) {
         const int tau0 = p * K;
@@ -371,7 +394,16 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
           if (tau0 + s == next_event) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
             const int last = next_event;
             const int steps = last - seg_start + 1, check = last > irate ? 1 : 0;
-            const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent]);
+            const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent],
+                                                       a.meet_timeout);
+            if (seg == MEET_ABORTED) {  // (wave-uniform) the rest of this phase is not run; the flag ends the launch
+              if (lane == 0) {
+                __hip_atomic_store(&lds_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(a.ctr + 5, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              s = ns;
+              break;
+            }
             ++nevent;
             wacc = 0;
             tun_na += seg;
@@ -483,6 +515,9 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
+  // (every iteration ends with a barrier: a flag raised during the last phase is visible here)
+  if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) aborted = true;
+  if (aborted) return;  // abandoned launch: nothing is written back, the host repeats the run (ctr[5] is set)
   if (owner) {
     if (live) {
       *reinterpret_cast<float4 *>(a.x + off) = make_float4(xe.x, xo.x, xe.y, xo.y);

@@ -11,6 +11,8 @@ OPT_SAMPLES, OPT_ACCEPT_MASK, OPT_FUSE, OPT_MAX_SEGMENT, OPT_PROFILE, OPT_STREAM
 OPT_SAMPLE_STRIDE = 8
 OPT_SPLIT_RNG = 9
 OPT_PERSIST = 10
+OPT_MEET_TIMEOUT_MS = 11
+OPT_DEBUG_MEET = 12
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 

@@ -4,6 +4,10 @@
   vlfunc_reference.json  inputs + outputs of the REFERENCE's own likelihood functors
                          (src/rosenbrock.cc compiled in place into oracle/_ref/ by oracle/Makefile,
                          reference Makefile flags -O3 -ffast-math).  Pins oracle + HIP likelihoods.
+  mcout_reference.json   scripts + transcripts of the REFERENCE's own MCout (src/mcout.cc compiled in place
+                         against the image's real MPI headers into oracle/_ref/ref_mcout_script, driven by
+                         tests/cpp/mcout_script.cc) on 1 rank and under `mpiexec -n 2`: text format, incremental
+                         dumps, collect() order, rewind, maxlike.  Pins the facade's MCout.
   oracle_runs.json       small end-to-end runs of the CPU oracle (oracle/mcx_oracle.c), pinning
                          the MCX arithmetic so that neither oracle nor kernels can drift silently.
 
@@ -12,7 +16,10 @@ Only data is written: inputs and expected outputs.
 import ctypes as C
 import json
 import os
+import struct
+import subprocess
 import sys
+import tempfile
 
 import numpy as np
 
@@ -74,6 +81,70 @@ def gen_vlfunc():
                 cases=cases, ctor_guards=guards)
 
 
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def hexf(v):
+    """float32 bit pattern as the script language writes it; strings pass through (already hex)"""
+    if isinstance(v, str):
+        return v
+    return "%08x" % struct.unpack("<I", struct.pack("<f", v))[0]
+
+
+NAN, NINF, PINF, NZERO, DENORM = "7fc00000", "ff800000", "7f800000", "80000000", "00011c37"
+
+
+def mcout_scenarios():
+    """each: name, np, one script (list of lines) per rank.  Collective calls (output, collect, maxlike) appear
+    at the same position in every rank's script, like in MCPar::run."""
+    def add(*v):
+        return "add " + " ".join(hexf(x) for x in v)
+    sc = []
+    # 1 rank: the formats ostream << float produces, incremental dumps, rewind, equal maxima, NaN / -inf
+    sc.append(dict(name="one_rank_formats", np=2, scripts=[[
+        "stat", "output", "collect", "new 3", add(1.5, -2.0, -3.25), add(0.1, 1e-5, 0.5), "stat", "output", "output",
+        add(123456.0, 1e10, 0.25), "output", "stat", "new 7", add(1234567.0, -1e-5, 0.5), add(NAN, NINF, NAN),
+        add(PINF, NZERO, NINF), add(DENORM, 3.4e38, -1e-30), add(0.333333343, 100000.0, 0.4999999),
+        add(1e6, 999999.0, 0.5), add(-0.0009765625, 16777216.0, 0.2), "output", "row 1", "row 4", "row 5", "maxlike",
+        "rewind", "collect", "collect", "rewind", "output", "stat"]]))
+    sc.append(dict(name="one_rank_np1_and_np5", np=1, scripts=[[
+        "new 4", add(2.5, -1.0), add(-7.0, -0.5), "output", add(0.0, -0.5), add(1.0, NINF), "maxlike", "output", "stat"]]))
+    sc.append(dict(name="one_rank_np5", np=5, scripts=[[
+        "new 2", add(1, 2, 3, 4, 5, -6), add(0.5, 0.25, 0.125, 0.0625, 0.03125, -0.015625), "output", "maxlike",
+        "rewind", "collect"]]))
+    # 2 ranks: rank-major row order within a dump, several dumps, MAXLOC ties go to the lower rank
+    r0 = ["new 4", add(1.0, 2.0, -1.0), add(3.0, 4.0, -0.5), "output", add(5.0, 6.0, 0.75), add(7.0, 8.0, -2.0),
+          "stat", "output", "maxlike", "rewind", "collect", "output", "collect"]
+    r1 = ["new 4", add(-1.0, -2.0, -3.0), add(-3.0, -4.0, 0.75), "output", add(-5.0, -6.0, 0.5), add(-7.0, -8.0, NAN),
+          "stat", "output", "maxlike", "rewind", "collect", "output", "collect"]
+    sc.append(dict(name="two_ranks_tie_goes_to_rank0", np=2, scripts=[r0, r1]))
+    r0 = ["new 2", add(0.1, 0.2, 0.3, -10.0), "output", add(1e-5, 123456.0, 1e10, -9.0), "output", "maxlike"]
+    r1 = ["new 2", add(0.4, 0.5, 0.6, -8.5), "output", add(1234567.0, NAN, NINF, -9.5), "output", "maxlike"]
+    sc.append(dict(name="two_ranks_rank1_wins", np=3, scripts=[r0, r1]))
+    return sc
+
+
+def gen_mcout():
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_mcout_script")
+    out = []
+    for sc in mcout_scenarios():
+        nr = len(sc["scripts"])
+        with tempfile.TemporaryDirectory() as td:
+            files = []
+            for r, lines in enumerate(sc["scripts"]):
+                fn = os.path.join(td, "script.%d" % r)
+                with open(fn, "w") as f:
+                    f.write("\n".join(lines) + "\n")
+                files.append(fn)
+            res = subprocess.run([MPIEXEC, "-n", str(nr), exe, str(sc["np"])] + files, capture_output=True,
+                                 text=True, timeout=120)
+            assert res.returncode == 0, res.stderr
+        out.append(dict(name=sc["name"], np=sc["np"], nranks=nr, scripts=sc["scripts"], transcript=res.stdout))
+    return dict(source="oracle/_ref/ref_mcout_script = tests/cpp/mcout_script.cc + /root/reference/src/mcout.cc "
+                       "(g++ -O2, MPICH headers of the image), run under mpiexec -n <nranks>",
+                scenarios=out)
+
+
 def gen_oracle_runs():
     runs = []
 
@@ -115,6 +186,8 @@ if __name__ == "__main__":
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "vlfunc_reference.json"), "w") as f:
         json.dump(gen_vlfunc(), f)
+    with open(os.path.join(out, "mcout_reference.json"), "w") as f:
+        json.dump(gen_mcout(), f, indent=1)
     with open(os.path.join(out, "oracle_runs.json"), "w") as f:
         json.dump(gen_oracle_runs(), f)
     print("wrote", os.listdir(out))

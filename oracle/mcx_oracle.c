@@ -335,6 +335,7 @@ struct mcxo_engine {
   float pwgt;
   /* records */
   int keep_samples, keep_mask, nthreads;
+  int sample_stride; /* keep the rows of main-loop steps with isamp % sample_stride == 0 (1 = every step, like the reference) */
   float *samples; size_t nrows, caprows;
   uint8_t *amask;
   uint32_t *acounts;
@@ -370,7 +371,7 @@ mcxo_engine *mcxo_create(int np, int nc, int nshards, int shard, float pl, float
   e->cov = zalloc(4 * (size_t)e->ncov);
   e->acounts = zalloc(4 * n);
   for (int i = 0; i < np; ++i) e->cov[i * (np + 1)] = 1.0f; /* identity until covar_setup */
-  e->keep_samples = 1; e->keep_mask = 1; e->nthreads = 1;
+  e->keep_samples = 1; e->keep_mask = 1; e->nthreads = 1; e->sample_stride = 1;
   return e;
 }
 
@@ -392,6 +393,7 @@ void mcxo_set_threads(mcxo_engine *e, int nthreads)
   g_threads = e->nthreads;
 }
 void mcxo_set_record(mcxo_engine *e, int ks, int km) { e->keep_samples = ks; e->keep_mask = km; }
+void mcxo_set_sample_stride(mcxo_engine *e, int k) { e->sample_stride = k > 0 ? k : 1; }
 
 /* src/mcpar.cc:454-484 */
 static int covar_setup(mcxo_engine *e, const float *incov)
@@ -701,7 +703,7 @@ static int run_begin(mcxo_engine *e, int nsamp, int nburn, const float *pinit, c
   e->tun_ntrial = e->tun_naccept = 0; e->irate = 50; e->ntrace = 0;
   e->nacc_burn = e->nacc_main = 0; e->nremote_steps = e->nremote_passes = 0;
   memset(e->acounts, 0, 4 * (size_t)e->nchain);
-  if (e->keep_samples) ensure_rows(e, (size_t)nsamp * e->nchain); /* :31 */
+  if (e->keep_samples) ensure_rows(e, (size_t)((nsamp + e->sample_stride - 1) / e->sample_stride) * e->nchain); /* :31 */
   free(e->amask); e->amask = NULL;
   if (e->keep_mask) e->amask = zalloc((size_t)(nburn + nsamp) * e->nchain);
   memcpy(e->pvals, pinit, sizeof(float) * (size_t)e->ntot); /* :47-50 */
@@ -764,7 +766,7 @@ static void main_step(mcxo_engine *e, int isamp)
   mcxo_vlfunc_eval(e->L, n, e->ptrial, e->lytrial); /* :160 */
   e->nacc_main += accept_all(e, t, (size_t)e->nburn + (size_t)isamp, remotep);
   /* :177-182 (the discarded single-set L call at :180 has no effect and is not made) */
-  if (e->keep_samples) {
+  if (e->keep_samples && isamp % e->sample_stride == 0) {
     float *row = e->samples + e->nrows * (size_t)(d + 1);
     for (int j = 0; j < n; ++j, row += d + 1) {
       memcpy(row, e->pvals + (size_t)j * d, sizeof(float) * (size_t)d);

@@ -84,6 +84,9 @@ void mcxo_set_threads(mcxo_engine *e, int nthreads);
 void mcxo_set_scalar_sweep(int on);
 /* keep_samples: 1 = store every (chain, step) row like MCout (src/mcpar.cc:177-182) */
 void mcxo_set_record(mcxo_engine *e, int keep_samples, int keep_accept_mask);
+/* keep only the rows of main-loop steps with isamp % k == 0 (k = 1: every step, the reference's behaviour);
+ * lets a full-size job be compared on a strided sample of its rows without holding all of them */
+void mcxo_set_sample_stride(mcxo_engine *e, int k);
 
 /* mirrors MCPar::run (src/mcpar.hh:36-37).  pinit[nc*np]; incov[np*np] or NULL */
 int mcxo_run(mcxo_engine *e, int nsamp, int nburn, const float *pinit, const mcxo_vlfunc *L,

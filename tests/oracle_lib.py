@@ -63,6 +63,7 @@ def lib():
     L.mcxo_set_threads.argtypes = [C.c_void_p, C.c_int]
     L.mcxo_set_scalar_sweep.argtypes = [C.c_int]
     L.mcxo_set_record.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.mcxo_set_sample_stride.argtypes = [C.c_void_p, C.c_int]
     L.mcxo_run.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, C.POINTER(VLFunc), fp]
     L.mcxo_run_all.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(fp),
                                C.POINTER(VLFunc), fp]
@@ -140,8 +141,9 @@ class Engine:
     def __del__(self):
         self.close()
 
-    def set_record(self, samples=True, mask=True):
+    def set_record(self, samples=True, mask=True, stride=1):
         lib().mcxo_set_record(self.h, int(samples), int(mask))
+        lib().mcxo_set_sample_stride(self.h, int(stride))
 
     def set_exchange(self, pyfn):
         def tramp(ctx, musigall, slot, shard, nshards):

@@ -38,7 +38,7 @@ def test_c3_full_job_bit_exact():
     p = O.default_pinit(d, n)
     vo, k1 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
     eo = O.Engine(d, n, pl=1.0, threads=THREADS)
-    eo.set_record(samples=False, mask=True)
+    eo.set_record(samples=True, mask=True, stride=111)  # rows of steps 0, 111, ..., 999: 10 x 65 536 of them
     t0 = time.time()
     eo.run(nsamp, nburn, p, vo)
     print("oracle C3 job: %.1f s" % (time.time() - t0))
@@ -53,6 +53,11 @@ def test_c3_full_job_bit_exact():
         assert same_bits(getattr(eg, name), getattr(eo, name)), name
     last = eg.samples_range(nsamp - 1, 1)
     assert same_bits(last[:, :d], eo.state) and same_bits(last[:, d], eo.loglike)
+    # a strided sample of the 65.5 M sample rows against the oracle's own rows (first, last and eight between)
+    orows = eo.samples.reshape(-1, n, d + 1)
+    assert orows.shape[0] == 10
+    for k, step in enumerate(range(0, nsamp, 111)):
+        assert same_bits(eg.samples_range(step, 1), orows[k]), "sample rows of step %d" % step
     eg.close()
     em = M.Engine(d, n, pl=1.0)
     em.set_option(E.OPT_ACCEPT_MASK, 1)
