@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 # the host driver on this pool only supports dmabuf IPC (needed by RCCL across processes)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+PORT_OVER_REFERENCE = 2.2  # the oracle port's speed over the compiled reference per set of cores
 HBM_PEAK = 8.0e12       # B/s, MI355X_MICROARCH.md chip table
 FP32_VALU_PEAK = 157.3e12  # flop/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
@@ -118,9 +119,15 @@ def cpu_baseline(cfg):
     dt = time.perf_counter() - t0
     passes = e.remote_passes
     e.close()
-    return dict(value=n * (nburn + nsamp) / dt, unit="chain-steps/s", cores=cores, kind="port",
+    v = n * (nburn + nsamp) / dt
+    return dict(value=v, unit="chain-steps/s", cores=cores, kind="port",
                 sample="%s: %d chains x %d-D, %d burn-in + %d main steps, pl=%.2f (%d Murray passes), samples kept in "
-                       "host memory, OpenMP over chains (%.1f s of %d cores)" % (sample, n, d, nburn, nsamp, pl, passes, dt, cores))
+                       "host memory, OpenMP over chains (%.1f s of %d cores)" % (sample, n, d, nburn, nsamp, pl, passes, dt, cores),
+                reference_equivalent=dict(
+                    value=v / PORT_OVER_REFERENCE, unit="chain-steps/s", port_over_reference=PORT_OVER_REFERENCE,
+                    source="cross-calibration in the build container (8 cores, same job shape): this port 1.49e7 chain-steps/s "
+                           "compute-only, the compiled reference under mpiexec -n 8 6.8e6 compute-only (SURVEY §6 / BASELINE.md); "
+                           "the reference itself cannot run on the GPU box (MKL, MPI and /root/reference do not travel)"))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -194,6 +201,67 @@ def find_kernel(table, *needles):
 
 
 # ---------------------------------------------------------------------------------------------
+# N = 1 extras that put DESIGN.md's remaining claims under the driver's clock
+# ---------------------------------------------------------------------------------------------
+def spd_covariance(d):
+    """a fixed, well-conditioned full covariance: 0.01 (I + 0.5 a a^T / d) with a from a seeded generator"""
+    import numpy as np
+    a = np.random.default_rng(1234 + d).normal(size=(d, d))
+    return (0.01 * (np.eye(d) + 0.5 * a @ a.T / d)).astype(np.float32)
+
+
+def time_job(eng, vl, p, nsamp, nburn, incov=None, reps=3):
+    """mean wall time of `reps` runs after one warm run (run() returns when the stream has drained)"""
+    eng.stage_pinit(p)
+    eng.run(nsamp, nburn, None, vl, incov)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.run(nsamp, nburn, None, vl, incov)
+    return (time.perf_counter() - t0) / reps
+
+
+def claims_under_the_clock(M, E, headline_ms, headline_n, nburn, nsamp):
+    """full-covariance cost against diagonal (16-D, 32-D), the strong-scaling proxy (8192 x 16-D), and the accept
+    rate of the shape the survey measured on the compiled reference (100 + 20 steps)"""
+    out = {}
+    fc = {}
+    for d in (16, 32):
+        n = 65536
+        vl, _k = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+        p = pinit_for(d, n, 0)
+        eng = M.Engine(d, n, pl=1.0)
+        eng.set_option(E.OPT_SAMPLES, 0)  # summary only: the 32-D rows of 1000 steps would be 8.7 GB
+        t_diag = time_job(eng, vl, p, nsamp, nburn)
+        t_full = time_job(eng, vl, p, nsamp, nburn, incov=spd_covariance(d))
+        eng.close()
+        fc["d%d" % d] = dict(diagonal_ms=t_diag * 1e3, full_ms=t_full * 1e3, ratio=t_full / t_diag)
+    fc["what"] = ("Rosenbrock1(d) x 65 536 chains, R-local job (nburn %d, nsamp %d), no sample rows kept; full = run(..., incov) with "
+                  "a dense SPD covariance (x' = x + T z, T its Cholesky factor, src/mcpar.cc:302-312,454-484)" % (nburn, nsamp))
+    out["full_cov"] = fc
+    d, n = 16, 8192
+    vl, _k = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eng = M.Engine(d, n, pl=1.0)
+    t_small = time_job(eng, vl, pinit_for(d, n, 0), nsamp, nburn, reps=10)
+    launches = eng.counters["kernel_launches"]
+    eng.close()
+    out["strong_proxy"] = dict(chains=n, ms_per_job=t_small * 1e3, value=n * (nburn + nsamp) / t_small, unit="chain-steps/s",
+                               kernel_launches_per_run=launches, headline_chains=headline_n, headline_ms_per_job=headline_ms,
+                               speedup_vs_headline_job=headline_ms / (t_small * 1e3),
+                               what="the per-GPU share of the headline job strong-scaled over 8 GPUs (65 536 / 8 chains x 16-D, same "
+                                    "nburn / nsamp, sample rows kept), timed in this process next to the headline job; the exchange "
+                                    "is not included (one 1 MiB-per-rank all-gather per run in the default schedule)")
+    d, n = 16, 65536
+    eng = M.Engine(d, n, pl=1.0)
+    eng.run(20, 100, pinit_for(d, n, 0), vl)
+    acc = eng.counters["naccept_main"] / float(n * 20)
+    eng.close()
+    out["accept_rate_reference_shape"] = dict(value=acc, reference=0.0468, workload="Rosenbrock1(16) x 65 536 chains, nburn 100 + nsamp 20, pl = 1",
+                                              source="BASELINE.md: derived from the samples of the unmodified reference in the survey "
+                                                     "container (RNG differs by design: statistical agreement)")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 # one configuration on this rank's engine
 # ---------------------------------------------------------------------------------------------
 class Job:
@@ -260,21 +328,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    # stdout carries exactly ONE line, the JSON.  gloo announces its connections and RCCL prints its version banner
+    # on the C-level stdout whenever a communicator is made (also the later ones: the Murray and strong-scaling
+    # jobs), child profilers chatter too: file descriptor 1 points at stderr from here to the end of the run and
+    # the line is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world > 1:
         # torch.distributed is the launcher-side plumbing only (rendezvous, barrier, MAX over ranks, shipping the
         # RCCL unique id) on a gloo group; the data path is libmcx's own ncclAllGather
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
-        # gloo announces its connections on the C-level stdout: keep stdout for the one JSON line
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo")
-            dist.barrier()
-        finally:
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+        dist.init_process_group("gloo")
+        dist.barrier()
         if args.one_device:
             local_rank = 0
             if not args.try_rccl:
@@ -294,7 +361,18 @@ def main():
     emit = not args.no_samples
 
     # ---- inter-shard exchange -------------------------------------------------------------------
-    state = {"backend": None}
+    state = {"backend": None, "rccl_ranks": None}
+    pci = None
+    try:
+        buf = C.create_string_buffer(64)
+        if lib.mcx_device_pci_bus_id(buf, 64) == 0:
+            pci = buf.value.decode()
+    except Exception:  # noqa: BLE001
+        pass
+    pci_ids = [pci]
+    if world > 1:  # which GPU every rank sits on (two ranks on one GPU cannot form an RCCL communicator)
+        pci_ids = [None] * world
+        dist.all_gather_object(pci_ids, pci)
 
     def bcast_bytes(b):
         t = torch.frombuffer(bytearray(b), dtype=torch.uint8).clone()
@@ -360,8 +438,10 @@ def main():
         if uid is None:
             staged_exchange(j.eng)
             state["backend"] = "gloo, host-staged (%s)" % why
+            state["rccl_ranks"] = None
         else:
             state["backend"] = "rccl (libmcx in-place ncclAllGather on a side stream)"
+            state["rccl_ranks"] = j.eng.rccl_info()[0]  # ncclCommCount of the communicator the gathers run on
         return j
 
     def sync():
@@ -433,11 +513,16 @@ def main():
                     unit="TFLOP/s", frac=ach / FP32_VALU_PEAK, pairs=sw["chain_steps"], exp_per_pair=1,
                     flop_per_pair=3 * dd + 4, launches=sw["launches"], total_ms=sw["ms"],
                     remote_steps=cn["remote_steps"], passes=cn["remote_passes"], whole_genremote_ms=pr["remote"]["ms"],
-                    formula="achieved = pairs * (3d+4) / sum of k_remote_sweep durations (HIP events, this run); "
+                    pairs_evaluated=cn.get("remote_pairs_evaluated"),
+                    pairs_evaluated_frac=(cn.get("remote_pairs_evaluated", 0) / float(cn["remote_pairs"]) if cn.get("remote_pairs") else None),
+                    formula="ALGORITHMIC flops, exclusions and early-outs included: achieved = pairs * (3d+4) / sum of k_remote_sweep "
+                            "durations (HIP events, this run), pairs = every (chain, Q_i) pair the reference loops over "
+                            "(src/mcpar.cc:367-395, 421-437) whether or not the kernel had to finish it; pairs_evaluated = the "
+                            "pairs left after the exact exclusion bound (mcx_counters.remote_pairs_evaluated); "
                             "peak = fp32 vector peak 157.3 TFLOP/s (MI355X_MICROARCH.md); the polynomial exp per pair is "
                             "not counted as flops")
 
-    roofline = murray = cpu = end_to_end = None
+    roofline = murray = cpu = end_to_end = claims = None
     others = {}
     if rank == 0:
         fm, fb, rs = prof["fused_main"], prof["fused_burn"], prof["run_small"]
@@ -686,6 +771,8 @@ def main():
                     murray["valu_issue"] = dict(kernels=vi, formula="per kernel, mean per launch of the measured child job: (2*plain + "
                                                 "4*packed_f32) issue cycles / (1024 SIMDs * GRBM_GUI_ACTIVE/8), as roofline.frac; the second "
                                                 "figure prices the same counts with the issue intervals tools/ubench.hip measured (2.7 / 4.7)")
+        if not args.no_extras and args.config == "c3" and not args.chains and args.dim == 0:
+            claims = claims_under_the_clock(M, E, dt / args.steps * 1e3, n, nburn, nsamp)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg)
 
@@ -702,7 +789,8 @@ def main():
                        "parallelism": ("chains sharded x%d (contiguous blocks, g = shard*n + j), in-place all-gather of the "
                                        "(mu, sig^2) slots: default schedule gathers the snapshots a Murray step or the end of "
                                        "the run reads" % world) if world > 1 else "single GPU",
-                       "exchange_backend": state["backend"],
+                       "exchange_backend": state["backend"], "rccl_comm_ranks": state["rccl_ranks"],
+                       "pci_bus_ids": pci_ids,
                        "reference_schedule": ref_sched,
                        "murray": murray_multi,
                        "strong_scaling": strong_multi,
@@ -710,10 +798,13 @@ def main():
                        "remote_steps": cnt["remote_steps"], "remote_passes": cnt["remote_passes"],
                        "value_with_host_pinit": value_host_pinit,
                        "exchanges_per_run": cnt["exchanges"], "kernel_launches_per_run": cnt["kernel_launches"],
-                       "other_configs": others or None},
+                       "other_configs": others or None,
+                       "full_cov": (claims or {}).get("full_cov"), "strong_proxy": (claims or {}).get("strong_proxy"),
+                       "accept_rate_reference_shape": (claims or {}).get("accept_rate_reference_shape")},
             "end_to_end": end_to_end, "roofline": roofline, "murray_roofline": murray, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if job is not None:
         job.close()
     if world > 1:

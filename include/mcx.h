@@ -129,6 +129,9 @@ int mcx_rccl_unique_id(void *id);
 int mcx_exchange_rccl_init(mcx_engine *e, const void *id);
 int mcx_exchange_rccl_adopt(mcx_engine *e, void *nccl_comm);
 int mcx_exchange_rccl_destroy(mcx_engine *e); /* also done by mcx_destroy */
+/* what the installed RCCL exchange sees: ncclCommCount / ncclCommUserRank of its communicator (a launcher's
+ * start-up check that every rank really joined); MCX_ERR_EXCHANGE when no RCCL exchange is installed */
+int mcx_exchange_rccl_info(mcx_engine *e, int *nranks, int *rank);
 /* run the installed exchange hook once, now (BEGIN, WAIT, drain): start-up self-check / tests */
 int mcx_debug_exchange(mcx_engine *e);
 

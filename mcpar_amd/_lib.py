@@ -96,6 +96,7 @@ def load():
         "mcx_exchange_rccl_init": [vp, vp],
         "mcx_exchange_rccl_adopt": [vp, vp],
         "mcx_exchange_rccl_destroy": [vp],
+        "mcx_exchange_rccl_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "mcx_debug_exchange": [vp],
         "mcx_debug_copy_bandwidth": [C.c_size_t, C.c_int, C.POINTER(C.c_double)],
         "mcx_debug_numerics": [C.c_int, C.c_int, u32p, u32p],

@@ -1066,6 +1066,15 @@ extern "C" int mcx_exchange_rccl_destroy(mcx_engine *e)
   return MCX_OK;
 }
 
+extern "C" int mcx_exchange_rccl_info(mcx_engine *e, int *nranks, int *rank)
+{
+  if (!e || !nranks || !rank) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (!e->xcomm) return fail(MCX_ERR_EXCHANGE, "no RCCL exchange installed");
+  NCCLCHK(g_rccl.CommCount(e->xcomm, nranks));
+  NCCLCHK(g_rccl.CommUserRank(e->xcomm, rank));
+  return MCX_OK;
+}
+
 // One exchange right now (publish is the caller's business): BEGIN + WAIT + drain.  Lets a test (or a
 // start-up self-check) push the installed hook through the device without running a job.
 extern "C" int mcx_debug_exchange(mcx_engine *e)

@@ -151,6 +151,12 @@ class Engine:
     def rccl_init_raw(self, ptr):
         check(load().mcx_exchange_rccl_init(self.h, ptr))
 
+    def rccl_info(self):
+        """(ncclCommCount, ncclCommUserRank) of the installed RCCL exchange"""
+        nr, rk = C.c_int(0), C.c_int(0)
+        check(load().mcx_exchange_rccl_info(self.h, C.byref(nr), C.byref(rk)))
+        return nr.value, rk.value
+
     def rccl_destroy(self):
         check(load().mcx_exchange_rccl_destroy(self.h))
 

@@ -140,7 +140,7 @@ class Hip:
         return e
 
 
-def run_sharded_async(d, n, nshards, nburn, nsamp, pl, eager, vlspec=None, sync=10):
+def run_sharded_async(d, n, nshards, nburn, nsamp, pl, eager, vlspec=None, sync=10, setup=None):
     """One engine per shard in its own thread.  BEGIN only ENQUEUES: an event on the engine's stream, a side
     stream that waits for every shard's event and then pulls the peers' slots with asynchronous device
     copies.  Nothing waits on the host for the device; WAIT makes the engine's stream wait for every shard's
@@ -163,7 +163,7 @@ def run_sharded_async(d, n, nshards, nburn, nsamp, pl, eager, vlspec=None, sync=
             if phase == E.XCHG_BEGIN:
                 ptrs[s] = ptr
                 assert hip.h.hipEventRecord(pub[s], stream) == 0
-                bar.wait(timeout=120)  # host-side only: every shard has recorded its event
+                bar.wait(timeout=600)  # host-side only: every shard has recorded its event
                 for r in range(ns):
                     assert hip.h.hipStreamWaitEvent(side[s], pub[r], 0) == 0
                 for r in range(ns):
@@ -172,7 +172,7 @@ def run_sharded_async(d, n, nshards, nburn, nsamp, pl, eager, vlspec=None, sync=
                         assert hip.h.hipMemcpyAsync(ptr + off, ptrs[r] + off, slot * 4, 3, side[s]) == 0
                 assert hip.h.hipEventRecord(done[s], side[s]) == 0
                 nbegin[s] += 1
-                bar.wait(timeout=120)  # every shard's `done` is recorded before anybody's WAIT can run
+                bar.wait(timeout=600)  # every shard's `done` is recorded before anybody's WAIT can run
             else:
                 for r in range(ns):
                     assert hip.h.hipStreamWaitEvent(stream, done[r], 0) == 0
@@ -182,6 +182,8 @@ def run_sharded_async(d, n, nshards, nburn, nsamp, pl, eager, vlspec=None, sync=
     def work(s):
         try:
             engs[s].set_option(E.OPT_EAGER_EXCHANGE, eager)
+            if setup:
+                setup(s, engs[s])
             engs[s].set_exchange(make_hook(s))
             engs[s].run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
         except Exception as ex:  # pragma: no cover
