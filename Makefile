@@ -2,7 +2,7 @@
 HIPCC    ?= hipcc
 ARCH     ?= gfx950
 CSRC      = mcpar_amd/csrc
-# -ffp-contract=off, no fast-math: "MCX arithmetic v1" is bit-reproducible only with explicit fma
+# -ffp-contract=off, no fast-math: the MCX arithmetic is bit-reproducible only with explicit fma
 HIPFLAGS  = -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-fast-math \
             -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function -Iinclude
 
@@ -17,6 +17,9 @@ HDRS = $(CSRC)/mcx_device.hpp $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_launch.hpp $(
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+# the Murray kernels are seen by the engine's translation unit only
+$(CSRC)/mcx_engine.o: $(CSRC)/mcx_remote.hpp
 
 mcpar_amd/libmcx.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS)

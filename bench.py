@@ -210,14 +210,17 @@ def spd_covariance(d):
     return (0.01 * (np.eye(d) + 0.5 * a @ a.T / d)).astype(np.float32)
 
 
-def time_job(eng, vl, p, nsamp, nburn, incov=None, reps=3):
-    """mean wall time of `reps` runs after one warm run (run() returns when the stream has drained)"""
+def time_job(eng, vl, p, nsamp, nburn, incov=None, reps=5):
+    """median wall time of `reps` runs after two warm runs (run() returns when the stream has drained; the first
+    run of a kernel family also loads its code object)"""
     eng.stage_pinit(p)
-    eng.run(nsamp, nburn, None, vl, incov)
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    ts = []
+    for r in range(reps + 2):
+        t0 = time.perf_counter()
         eng.run(nsamp, nburn, None, vl, incov)
-    return (time.perf_counter() - t0) / reps
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[2:])
+    return ts[len(ts) // 2]
 
 
 def claims_under_the_clock(M, E, headline_ms, headline_n, nburn, nsamp):
@@ -241,7 +244,7 @@ def claims_under_the_clock(M, E, headline_ms, headline_n, nburn, nsamp):
     d, n = 16, 8192
     vl, _k = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eng = M.Engine(d, n, pl=1.0)
-    t_small = time_job(eng, vl, pinit_for(d, n, 0), nsamp, nburn, reps=10)
+    t_small = time_job(eng, vl, pinit_for(d, n, 0), nsamp, nburn, reps=11)
     launches = eng.counters["kernel_launches"]
     eng.close()
     out["strong_proxy"] = dict(chains=n, ms_per_job=t_small * 1e3, value=n * (nburn + nsamp) / t_small, unit="chain-steps/s",
@@ -306,6 +309,8 @@ def main():
     ap.add_argument("--try-rccl", action="store_true", help="with --one-device: attempt the RCCL communicator anyway (RCCL refuses two "
                     "ranks on one GPU: rehearses the collective fallback to the staged exchange)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses device 0 (implies --exchange staged)")
+    ap.add_argument("--cull", type=int, default=-1, choices=(-1, 0, 1), help="MCX_OPT_CULL of the measured job (Murray sweeps: exact "
+                    "exclusion of far Gaussians): -1 auto (default), 0 off, 1 on")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -464,6 +469,8 @@ def main():
 
     job = make_job(cfg, n, emit)
     eng = job.eng
+    if args.cull != -1:
+        eng.set_option(E.OPT_CULL, args.cull)
     for _ in range(args.warmup):
         job.run()
     dt = timed(job, args.steps)

@@ -179,6 +179,9 @@ enum {
                               workgroup that is not resident (CU mask, partitioned device, foreign kernel) before
                               the launch is abandoned and the run repeated on the per-segment kernels (same bits;
                               mcx_counters.meet_timeouts counts it) [default 2000] */
+  MCX_OPT_CULL = 13,       /* Murray sweeps: exclude, exactly, the Gaussians that are too far from all 128 chains of a
+                              wavefront to matter (the chains are sorted spatially first; same bits).  -1 auto [default:
+                              np = 16 or 32, >= 4096 chains still rejected, >= 4096 Gaussians], 0 off, 1 whenever np allows */
   MCX_OPT_DEBUG_MEET = 12    /* test hook: the meetings wait for `value` workgroups more than the grid has, i.e.
                               they can never complete [default 0] */
 };

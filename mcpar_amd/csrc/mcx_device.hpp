@@ -1041,455 +1041,6 @@ static __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsi
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// genRemote (src/mcpar.cc:315-451).  One lane per chain (two chains per lane at 16-D and 32-D), chain vector in registers, the N
-// per-chain Gaussians Q_i staged through LDS a block at a time and read back as broadcasts.
-// ---------------------------------------------------------------------------------------------
-// qpar[i] = (mu_i, w_i), w = 1/sig2: sum_k (mu_k - x_k)^2 / sig2_k (src/mcpar.cc:369-383) is formed the way the
-// reference forms it -- xm = mu - x first, so a chain on a Gaussian's mean gives exactly 0 however narrow the
-// Gaussian, then xm * xm -- with the division replaced by a multiplication with w (arithmetic v3: sub, mul,
-// fma per pair-dimension; v2's fma(-x, s, mu s) lost the cancellation when |mu| s was large).  One Q_i is 2d
-// contiguous floats.
-static __global__ void k_remote_prep(const float *__restrict__ musigall, float *__restrict__ qpar, size_t nd)
-{
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nd) {
-    const float2 ms = reinterpret_cast<const float2 *>(musigall)[i];
-    reinterpret_cast<float2 *>(qpar)[i] = make_float2(ms.x, 1.0f / ms.y);
-  }
-}
-
-// The sweep loop over the rows of Gaussians staged in LDS (row stride 2*DMAX floats, zero-padded past 2*DD), with
-// wave-uniform early outs.  The partial sums of arg only grow (every term is a square), so once every chain of
-// the wavefront has `arg > bound(lane)` after a group of dimensions the remaining dimensions cannot bring any of
-// them back under its bound, and this Q_i is dropped for the whole wavefront; completed sums are the same bits
-// as the oracle's qarg().  One Q_i against 64 chains is mostly far away from all of them, so most of the
-// sweep ends after the first group.  use(arg) consumes a completed sum; bound() is re-read per Q_i.
-// Every lane reads the same address (a broadcast ds_read_b128 = two dimensions), so both operands of
-// xm = mu - x, fma(xm xm, w, arg) arrive in VGPRs.  Round 1 streamed the rows through wave-uniform scalar loads instead:
-// VALU instructions take one scalar operand, so m' went through a v_mov (3 instead of 2 instructions per
-// pair-dimension), and scalar loads return out of order -- every wait is a wait for all of them -- which
-// exposed their full latency once per group (VALU 60 % busy).  Same operations in the same order: same bits.
-// `valid` = the lane holds a chain; lanes without one take part in the wave-uniform tests as "out of range".
-template <int DMAX, bool EXACT, typename Bound, typename Use>
-__device__ __forceinline__ void sweep_rows(const float *rows, int nrow, const float x[DMAX], int DD, bool valid,
-                                           Bound bound, Use use)
-{
-  constexpr int G = DMAX >= 16 ? DMAX / 4 : DMAX;  // dimensions per group: 4 groups from 16-D up
-  constexpr int G4 = G / 2, R4 = DMAX / 2;          // float4 per group / per row
-  const float4 *rp = reinterpret_cast<const float4 *>(rows);
-  float4 cur[G4];
-#pragma unroll
-  for (int k = 0; k < G4; ++k) cur[k] = rp[k];
-  auto two_dims = [&](float4 v, int k, float arg) {  // dimensions k, k + 1 (k even)
-    if (EXACT || k < DD) {
-      const float xm = v.x - x[k];
-      arg = __builtin_fmaf(xm * xm, v.y, arg);
-    }
-    if (EXACT || k + 1 < DD) {
-      const float xm = v.z - x[k + 1];
-      arg = __builtin_fmaf(xm * xm, v.w, arg);
-    }
-    return arg;
-  };
-  const unsigned long long everyone = __ballot(true), nochain = __ballot(!valid);
-  for (int r = 0; r < nrow; ++r, rp += R4) {
-    const float4 *rn = r + 1 < nrow ? rp + R4 : rp;
-    float arg = 0.0f;
-#pragma unroll
-    for (int k = 0; k < G4; ++k) arg = two_dims(cur[k], 2 * k, arg);
-    // the next row's first group, into the registers that have just been read (loads issued any earlier would
-    // need a second set and a copy per row); in flight during this row's other groups / the next wavefronts' turn
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < G4; ++k) cur[k] = rn[k];
-    __builtin_amdgcn_sched_barrier(0);
-    const float b = bound();
-    bool live = (__ballot(arg > b) | nochain) != everyone;
-    if (live && G < DMAX) {
-#pragma unroll
-      for (int c = G; c < DMAX; c += G) {
-#pragma unroll
-        for (int k = 0; k < G4; ++k) arg = two_dims(rp[c / 2 + k], c + 2 * k, arg);
-        if ((__ballot(arg > b) | nochain) == everyone) {  // also after the last group: the consumer's exp is skipped
-          live = false;
-          break;
-        }
-      }
-    }
-    if (live) use(arg);
-  }
-}
-
-// Two chains per lane (components .x / .y of every pair): a row read from LDS then serves 128 chains of the
-// wavefront instead of 64 -- the broadcast reads are what the one-chain loop is bound by (LDS 82-90 % busy at
-// d = 32, VALU 70 %) -- and the arithmetic is packed (v_pk_fma_f32 with the row's m', s selected by op_sel:
-// component-wise the same fused operations in the same order, hence the same bits).  d == DMAX only.
-template <int DMAX, typename Bound, typename Use>
-__device__ __forceinline__ void sweep_rows2(const float *rows, int nrow, const f32x2 x[DMAX], bool valid_a, bool valid_b,
-                                            Bound bound, Use use)
-{
-  constexpr int G = DMAX >= 16 ? DMAX / 4 : DMAX;
-  constexpr int G4 = G / 2, R4 = DMAX / 2;
-  const float4 *rp = reinterpret_cast<const float4 *>(rows);
-  float4 cur[G4];
-#pragma unroll
-  for (int k = 0; k < G4; ++k) cur[k] = rp[k];
-  auto two_dims = [&](float4 v, int k, f32x2 arg) {
-    const f32x2 xm0 = splat2(v.x) - x[k];
-    arg = fma2(xm0 * xm0, splat2(v.y), arg);
-    const f32x2 xm1 = splat2(v.z) - x[k + 1];
-    arg = fma2(xm1 * xm1, splat2(v.w), arg);
-    return arg;
-  };
-  const unsigned long long everyone = __ballot(true), no_a = __ballot(!valid_a), no_b = __ballot(!valid_b);
-  for (int r = 0; r < nrow; ++r, rp += R4) {
-    const float4 *rn = r + 1 < nrow ? rp + R4 : rp;
-    f32x2 arg = {0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < G4; ++k) arg = two_dims(cur[k], 2 * k, arg);
-    __builtin_amdgcn_sched_barrier(0);  // (see sweep_rows)
-#pragma unroll
-    for (int k = 0; k < G4; ++k) cur[k] = rn[k];
-    __builtin_amdgcn_sched_barrier(0);
-    const f32x2 b = bound();
-    bool live = ((__ballot(arg.x > b.x) | no_a) & (__ballot(arg.y > b.y) | no_b)) != everyone;
-    if (live && G < DMAX) {
-#pragma unroll
-      for (int c = G; c < DMAX; c += G) {
-#pragma unroll
-        for (int k = 0; k < G4; ++k) arg = two_dims(rp[c / 2 + k], c + 2 * k, arg);
-        if (((__ballot(arg.x > b.x) | no_a) & (__ballot(arg.y > b.y) | no_b)) == everyone) {
-          live = false;
-          break;
-        }
-      }
-    }
-    if (live) use(arg);
-  }
-}
-
-// arg > ZERO_ARG  =>  expf_v2(-arg/2) == 0 exactly: -arg/2 < -88 gives n = floor(-88 log2(e) + 1/2) <= -127 < -125
-constexpr float ZERO_ARG = 176.0f;
-
-constexpr int QBLOCK = 256;  // block length of the qisum summation order
-
-struct RemoteArgs {
-  const int *active_in;  // compacted list of still-rejected chains (null = all chains, pass 0)
-  int nact;
-  int *active_out;
-  int *nact_out;
-  const float *musigall, *winv, *cmax;  // winv = qpar: (mu, 1/sig2) pairs
-  float *ptrial, *mutrial, *sigtrial, *cfac;
-  float *racpt;        // [n] rejection threshold of this pass, by chain
-  float *psum, *pmax;  // [S][nact] per-block partial sums / maxima, by position in the active list
-  int n, d, N, pass, S;
-  uint32_t g0, t, seed;
-};
-
-// Murray draw for every still-rejected chain (src/mcpar.cc:337-352): pick a component, draw from
-// its diagonal Gaussian, keep (mutrial, sigtrial); one lane per chain.
-template <int DMAX>
-__global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
-{
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= a.nact) return;
-  const int j = a.active_in ? a.active_in[i] : i;
-  const int d = a.d;
-  const uint32_t g = a.g0 + (uint32_t)j;
-  const u32x4 w = philox4x32_10(a.t, g, (uint32_t)a.pass, 0u, a.seed, ST_RSEL);
-  const int sel = (int)(((uint64_t)w.x * (uint64_t)a.N) >> 32);  // src/mcpar.cc:337
-  for (int qb = 0; 4 * qb < d; ++qb) {
-    float z[4];
-    normal4_from_words(philox4x32_10(a.t, g, (uint32_t)a.pass, (uint32_t)qb, a.seed, ST_RNORM), z);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int k = 4 * qb + c;
-      if (k < d) {  // src/mcpar.cc:339-352
-        const float m = a.musigall[2 * ((size_t)sel * d + k)];
-        const float sg = __builtin_sqrtf(a.musigall[2 * ((size_t)sel * d + k) + 1]);
-        a.mutrial[(size_t)j * d + k] = m;
-        a.sigtrial[(size_t)j * d + k] = sg;
-        a.ptrial[(size_t)j * d + k] = __builtin_fmaf(sg, z[c], m);
-      }
-    }
-  }
-  a.racpt[j] = u24(w.y);  // src/mcpar.cc:401
-}
-
-// The all-pairs sweep (src/mcpar.cc:367-395 for ptrial, :421-437 for pvals): lanes = chains (vector
-// in registers), blockIdx.y = one block of QBLOCK consecutive Q_i, staged through LDS by the workgroup's four
-// wavefronts and read back with broadcast ds_read_b128 (sweep_rows): one fetch serves 256 chains.  SUMS: writes the block's partial
-// sum and maximum of Q = exp(-arg/2); blocks are combined in index order by k_remote_decide (fixed
-// summation order).  !SUMS (the cfac numerator max_i Q_i = exp(-min_i arg_i / 2)): writes the block's
-// minimum of arg -- no exp per pair; k_remote_cmax_combine takes the one exp per chain.
-template <int DMAX, bool SUMS, bool EXACT, int CPL = 1>
-__global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict__ xrows,
-                                                        const int *__restrict__ active, int nact,
-                                                        const float *__restrict__ qpar,
-                                                        float *__restrict__ psum,
-                                                        float *__restrict__ pmax, int d, int N, int own0)
-{
-  static_assert(CPL == 1 || (CPL == 2 && EXACT), "two chains per lane: d == DMAX only");
-  // the block's Gaussians pass through LDS 16 KB (8 KB with two chains per lane) at a time
-  constexpr int QSUB = DMAX >= 8 ? (2048 / CPL) / DMAX : QBLOCK;
-  __shared__ __attribute__((aligned(16))) float qlds[QSUB * 2 * DMAX];
-  // chain c of this lane = position blockIdx.x * CPL * BLOCK + c * BLOCK + threadIdx.x of the (active) list;
-  // every lane stays for the staging and its barriers
-  int pos[CPL], jj[CPL];
-  bool valid[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    pos[c] = (blockIdx.x * CPL + c) * BLOCK + threadIdx.x;
-    valid[c] = pos[c] < nact;
-    jj[c] = valid[c] ? (active ? active[pos[c]] : pos[c]) : 0;
-  }
-  const int sb = blockIdx.y;
-  const int DD = EXACT ? DMAX : d;
-  float x[CPL == 1 ? DMAX : 1];
-  f32x2 xx[CPL == 2 ? DMAX : 1];
-  if constexpr (CPL == 1) {
-#pragma unroll
-    for (int k = 0; k < DMAX; ++k) x[k] = 0.0f;
-    if (valid[0]) {
-#pragma unroll
-      for (int k = 0; k < DMAX; ++k)
-        if (EXACT || k < DD) x[k] = xrows[(size_t)jj[0] * DD + k];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < DMAX; ++k) xx[k] = f32x2{0.0f, 0.0f};
-    if (valid[0]) {
-#pragma unroll
-      for (int k = 0; k < DMAX; ++k) xx[k].x = xrows[(size_t)jj[0] * DMAX + k];
-    }
-    if (valid[CPL - 1]) {
-#pragma unroll
-      for (int k = 0; k < DMAX; ++k) xx[k].y = xrows[(size_t)jj[CPL - 1] * DMAX + k];
-    }
-  }
-  const int q0 = sb * QBLOCK, q1 = (q0 + QBLOCK < N) ? q0 + QBLOCK : N;
-  const bool wave_idle = !__any(valid[0]);
-  // d == DMAX: a stage is one contiguous piece of qpar, PER float4 per thread, fetched into registers while the
-  // previous stage is being swept and written to LDS between two barriers
-  constexpr int PER = (QSUB * (DMAX / 2) + BLOCK - 1) / BLOCK;
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 hold[PER];
-  if (EXACT) {
-    const int n4 = (q1 - q0 < QSUB ? q1 - q0 : QSUB) * (DMAX / 2);
-    const v4 *src = reinterpret_cast<const v4 *>(qpar + 2 * (size_t)q0 * DMAX);
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int t = (int)threadIdx.x + u * BLOCK;
-      hold[u] = src[t < n4 ? t : n4 - 1];  // (unconditional: the PER loads go out back to back)
-    }
-  }
-  f32x2 part = {0.0f, 0.0f}, m = {0.0f, 0.0f};              // SUMS: the block's sum and maximum of Q, per chain
-  f32x2 amin = {__builtin_inff(), __builtin_inff()};         // !SUMS: the block's minimum of arg
-  if (!SUMS && own0 >= 0) {
-    // Every block starts from the chain's arg against its OWN Gaussian (global index own0 + j, one of the N: the
-    // combined minimum over the blocks is unchanged), which is small -- the chain sits inside its own running
-    // posterior -- so nearly every other Q_i is abandoned after its first group of dimensions.
-#pragma unroll
-    for (int c = 0; c < CPL; ++c)
-      if (valid[c]) {
-        const float *qo = qpar + 2 * (size_t)(own0 + jj[c]) * DD;
-        float a0 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < DMAX; ++k)
-          if (EXACT || k < DD) {
-            const float xk = CPL == 1 ? x[CPL == 1 ? k : 0] : (c == 0 ? xx[CPL == 2 ? k : 0].x : xx[CPL == 2 ? k : 0].y);
-            const float xm = qo[2 * k] - xk;
-            a0 = __builtin_fmaf(xm * xm, qo[2 * k + 1], a0);
-          }
-        const float old = c == 0 ? amin.x : amin.y;
-        const float now = a0 < old ? a0 : old;  // a NaN stays out, like below
-        if (c == 0) amin.x = now;
-        else amin.y = now;
-      }
-  }
-  for (int c0 = q0; c0 < q1; c0 += QSUB) {
-    const int nrow = q1 - c0 < QSUB ? q1 - c0 : QSUB;
-    __syncthreads();  // the previous rows have been consumed
-    if (EXACT) {
-      v4 *dst = reinterpret_cast<v4 *>(qlds);
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int t = (int)threadIdx.x + u * BLOCK;
-        if (t < nrow * (DMAX / 2)) dst[t] = hold[u];
-      }
-    } else {
-      const float *src = qpar + 2 * (size_t)c0 * DD;
-      for (int t = threadIdx.x; t < nrow * 2 * DMAX; t += BLOCK) {
-        const int r = t / (2 * DMAX), k = t % (2 * DMAX);
-        qlds[t] = k < 2 * DD ? src[(size_t)r * 2 * DD + k] : 0.0f;
-      }
-    }
-    __syncthreads();
-    if (EXACT && c0 + QSUB < q1) {
-      const int cn = c0 + QSUB;
-      const int n4 = (q1 - cn < QSUB ? q1 - cn : QSUB) * (DMAX / 2);
-      const v4 *src = reinterpret_cast<const v4 *>(qpar + 2 * (size_t)cn * DMAX);
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int t = (int)threadIdx.x + u * BLOCK;
-        hold[u] = src[t < n4 ? t : n4 - 1];
-      }
-    }
-    if (wave_idle) continue;
-    // a dropped Q_i is +0 for every chain of the wavefront: part + 0 = part, m unchanged; an arg equal to the
-    // bound cannot lower the minimum either: `>` serves both sweeps
-    if constexpr (CPL == 1) {
-      if (SUMS) {
-        sweep_rows<DMAX, EXACT>(qlds, nrow, x, DD, valid[0], [] { return ZERO_ARG; }, [&](float av) {
-          const float gv = expf_v2(-0.5f * av);
-          part.x = part.x + gv;
-          m.x = gv > m.x ? gv : m.x;
-        });
-      } else {
-        sweep_rows<DMAX, EXACT>(qlds, nrow, x, DD, valid[0], [&] { return amin.x; },
-                                [&](float av) { amin.x = av < amin.x ? av : amin.x; });
-      }
-    } else {
-      if (SUMS) {
-        sweep_rows2<DMAX>(qlds, nrow, xx, valid[0], valid[CPL - 1], [] { return splat2(ZERO_ARG); }, [&](f32x2 av) {
-          const f32x2 gv = expf_v2x2(splat2(-0.5f) * av);
-          part = part + gv;
-          m.x = gv.x > m.x ? gv.x : m.x;
-          m.y = gv.y > m.y ? gv.y : m.y;
-        });
-      } else {
-        sweep_rows2<DMAX>(qlds, nrow, xx, valid[0], valid[CPL - 1], [&] { return amin; }, [&](f32x2 av) {
-          amin.x = av.x < amin.x ? av.x : amin.x;
-          amin.y = av.y < amin.y ? av.y : amin.y;
-        });
-      }
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < CPL; ++c)
-    if (valid[c]) {
-      const size_t o = (size_t)sb * nact + pos[c];  // [block][position]: coalesced here and in the combining kernels
-      if (SUMS) {
-        psum[o] = c == 0 ? part.x : part.y;
-        pmax[o] = c == 0 ? m.x : m.y;
-      } else {
-        pmax[o] = c == 0 ? amin.x : amin.y;
-      }
-    }
-}
-
-// numerator of cfac: max_i Q_i(pvals_j) = exp(-min_i arg_i / 2) (src/mcpar.cc:421-437); does not depend on the pass
-static __global__ void k_remote_cmax_combine(const float *__restrict__ pmin, float *__restrict__ cmax, int n, int S)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  float amin = __builtin_inff();
-  for (int sb = 0; sb < S; ++sb) {
-    const float v = pmin[(size_t)sb * n + j];
-    amin = v < amin ? v : amin;
-  }
-  cmax[j] = expf_v2(-0.5f * amin);
-}
-
-// rejection test of the pass (src/mcpar.cc:397-441); survivors are compacted for the next pass
-static __global__ void k_remote_decide(const RemoteArgs a)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.nact) return;
-  const int j = a.active_in ? a.active_in[i] : i;
-  float qs = FPEPS, qm = FPEPS;  // src/mcpar.cc:355-365
-  for (int sb = 0; sb < a.S; ++sb) {
-    qs = qs + a.psum[(size_t)sb * a.nact + i];
-    const float v = a.pmax[(size_t)sb * a.nact + i];
-    qm = v > qm ? v : qm;
-  }
-  const float pacpt = qm / qs;
-  if (a.racpt[j] < pacpt) {
-    a.cfac[j] = a.cmax[j] / qm;
-  } else {
-    const int slot = atomicAdd(a.nact_out, 1);
-    a.active_out[slot] = j;
-  }
-}
-
-// np > 32: the chain vector does not fit the register budget; it is re-read from global memory
-// (L1/L2-resident).  Same arithmetic and order as the register kernels.
-__device__ __forceinline__ float q_arg_mem(const float *__restrict__ qp, const float *__restrict__ x, int d)
-{
-  float arg = 0.0f;
-  for (int k = 0; k < d; ++k) {
-    const float xm = qp[2 * k] - x[k];
-    arg = __builtin_fmaf(xm * xm, qp[2 * k + 1], arg);
-  }
-  return arg;
-}
-
-static __global__ __launch_bounds__(BLOCK) void k_remote_cmax_big(const float *__restrict__ pvals,
-                                                           const float *__restrict__ qpar,
-                                                           float *__restrict__ cmax, int n, int d, int N)
-{
-  const int j = blockIdx.x * BLOCK + threadIdx.x;
-  if (j >= n) return;
-  const float *x = pvals + (size_t)j * d;
-  float amin = __builtin_inff();
-  for (int qi = 0; qi < N; ++qi) {
-    const float av = q_arg_mem(qpar + 2 * (size_t)qi * d, x, d);
-    amin = av < amin ? av : amin;
-  }
-  cmax[j] = expf_v2(-0.5f * amin);
-}
-
-static __global__ __launch_bounds__(BLOCK) void k_remote_pass_big(const RemoteArgs a)
-{
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= a.nact) return;
-  const int j = a.active_in ? a.active_in[i] : i;
-  const int d = a.d;
-  const uint32_t g = a.g0 + (uint32_t)j;
-  const u32x4 w = philox4x32_10(a.t, g, (uint32_t)a.pass, 0u, a.seed, ST_RSEL);
-  const int sel = (int)(((uint64_t)w.x * (uint64_t)a.N) >> 32);
-  float *x = a.ptrial + (size_t)j * d;
-  for (int qb = 0; 4 * qb < d; ++qb) {
-    float z[4];
-    normal4_from_words(philox4x32_10(a.t, g, (uint32_t)a.pass, (uint32_t)qb, a.seed, ST_RNORM), z);
-    for (int c = 0; c < 4; ++c) {
-      const int k = 4 * qb + c;
-      if (k < d) {
-        const float m = a.musigall[2 * ((size_t)sel * d + k)];
-        const float sg = __builtin_sqrtf(a.musigall[2 * ((size_t)sel * d + k) + 1]);
-        x[k] = __builtin_fmaf(sg, z[c], m);
-        a.mutrial[(size_t)j * d + k] = m;
-        a.sigtrial[(size_t)j * d + k] = sg;
-      }
-    }
-  }
-  float qs = FPEPS, qm = FPEPS;
-  for (int b0 = 0; b0 < a.N; b0 += QBLOCK) {  // blocked summation order, DESIGN.md §3.5
-    float part = 0.0f;
-    for (int qi = b0; qi < a.N && qi < b0 + QBLOCK; ++qi) {
-      const float gv = expf_v2(-0.5f * q_arg_mem(a.winv + 2 * (size_t)qi * d, x, d));
-      part = part + gv;
-      qm = gv > qm ? gv : qm;
-    }
-    qs = qs + part;
-  }
-  const float pacpt = qm / qs;
-  if (u24(w.y) < pacpt) {
-    a.cfac[j] = a.cmax[j] / qm;
-  } else {
-    const int slot = atomicAdd(a.nact_out, 1);
-    a.active_out[slot] = j;
-  }
-}
-
-// src/mcpar.cc:447-448
-static __global__ void k_square(float *v, size_t n)
-{
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = v[i] * v[i];
-}
-
 // MCout row format (src/mcout.cc:129-137): (np parameters, log-likelihood) per (step, chain)
 static __global__ void k_rows_interleave(const float *__restrict__ sx, const float *__restrict__ sl,
                                   float *__restrict__ rows, size_t nrows, int d)

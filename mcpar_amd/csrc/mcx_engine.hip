@@ -7,6 +7,7 @@
 #include "mcx_device.hpp"
 #include "mcx_launch.hpp"
 #include "mcx_persist.hpp"
+#include "mcx_remote.hpp"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -376,13 +377,24 @@ struct mcx_engine {
   DevBuf<uint32_t> acc_cnt, acc_slots;
   int nslots = 0;
   DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
-  DevBuf<int> active0, active1, nact, ntrace;
+  DevBuf<int> active0, active1, nact, ntrace;  // nact: [0] survivors of the pass; as u64: [1 .. 1 + CULL_NCOUNT) / the next
+                                               // CULL_NCOUNT cells: pairs kept by the exclusion tests of the min-arg sweep /
+                                               // of the sum sweeps of this genRemote call (spread: same-address atomics are slow)
+  // exact exclusion of far Gaussians in the Murray sweeps (mcx_remote.hpp, k_cull_*)
+  DevBuf<unsigned> cull_keys, cull_hist;
+  DevBuf<int> cull_sorted;
+  DevBuf<float> cull_stats, cull_box, cull_lim;
+  DevBuf<unsigned long long> cull_excl;
+  int opt_cull = -1;  // -1 auto (many chains, many Gaussians, np = 16 or 32), 0 off, 1 whenever the kernels allow
+  int cull_skip[2] = {0, 0};  // auto mode: genRemote calls for which the min-arg / sum sweeps go without the test,
+                              // because it excluded too little last time it was tried (then it is tried again)
   DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev, zpre, upre, trash;
   bool pinit_staged = false;
   DevBuf<uint8_t> mask;
   // host staging
   PinBuf<float> h_ptrial, h_lytrial;
   PinBuf<unsigned long long> h_ctr;  // the run's counters, read back once at its end
+  PinBuf<unsigned long long> h_nact;  // a Murray pass's survivor count (and the exclusion tests' counters)
   std::vector<float> h_cov, h_cov_dev, h_winv;  // h_cov_dev = what cov0 holds
   bool cov_pending = false;  // cov has not been reset to cov0 for the current run yet
   bool cov_offdiag = false;  // cov (device) may hold non-zero entries below the diagonal
@@ -558,7 +570,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   A(e->ctr.alloc((size_t)CTR_WORDS * CTR_RING));
   e->nslots = (int)(((size_t)nc * e->lpc + 63) / 64);
   A(e->acc_slots.alloc((size_t)e->nslots));
-  A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(1)); A(e->ntrace.alloc(1));
+  A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(2 * (1 + 2 * CULL_NCOUNT))); A(e->ntrace.alloc(1));
   if (st == MCX_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipStreamCreate failed");
   if (st != MCX_OK) { mcx_destroy(e); return st; }
@@ -597,8 +609,10 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->lylast.release(); e->lytrial.release(); e->cfac.release(); e->cmax.release(); e->cov.release(); e->cov0.release();
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
+  e->cull_keys.release(); e->cull_hist.release(); e->cull_sorted.release(); e->cull_stats.release(); e->cull_box.release();
+  e->cull_lim.release(); e->cull_excl.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
-  e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->zpre.release(); e->upre.release(); e->trash.release();
+  e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release();
   for (int b = 0; b < 2; ++b) {
     e->sink_stage[b].release();
     e->sink_pin[b].release();
@@ -648,6 +662,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
   case MCX_OPT_EAGER_EXCHANGE: e->opt_eager = value ? 1 : 0; break;
   case MCX_OPT_SPLIT_RNG: e->opt_split = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_PERSIST: e->opt_persist = value < 0 ? -1 : (value ? 1 : 0); break;
+  case MCX_OPT_CULL: e->opt_cull = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_MEET_TIMEOUT_MS:
     if (value < 1) return fail(MCX_ERR_INVALID, "MEET_TIMEOUT_MS must be >= 1");
     e->opt_meet_timeout_ms = (int)std::min<int64_t>(value, 600000);
@@ -796,6 +811,40 @@ static int launch_accept(mcx_engine *e, const StepArgs &a, bool main)
   return MCX_OK;
 }
 
+// Sort the active chains by their spatial key, box every group of CULL_W of them and test every (group, Q_i)
+// pair (mcx_remote.hpp, "Exact exclusion of far Gaussians").  Leaves the sorted list in e->cull_sorted and the
+// masks in e->cull_excl ([group][words]); the pairs kept are added to the device counter behind e->nact.
+constexpr int CULL_MIN_CHAINS = 4096, CULL_MIN_GAUSSIANS = 4096;
+
+template <int DMAX>
+static int cull_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, hipStream_t st)
+{
+  const int d = e->nparam, N = e->tchains;
+  const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64;
+  HIPCHK(hipMemsetAsync(e->cull_stats.p, 0, 2 * CULL_KD * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(e->cull_hist.p, 0, CULL_BINS * sizeof(unsigned), st));
+  hipLaunchKernelGGL(k_cull_stats, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p);
+  hipLaunchKernelGGL(k_cull_keys, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p,
+                     e->cull_keys.p, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
+                     e->cull_sorted.p);
+  const dim3 gb((unsigned)((ng + BLOCK / 64 - 1) / (BLOCK / 64)));
+  if (sums)
+    hipLaunchKernelGGL((k_cull_boxes<DMAX, true>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
+                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p);
+  else
+    hipLaunchKernelGGL((k_cull_boxes<DMAX, false>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
+                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p);
+  const int gchunk = 16;
+  hipLaunchKernelGGL((k_cull_test<DMAX>), dim3((unsigned)((nw + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)((ng + gchunk - 1) / gchunk)),
+                     dim3(BLOCK), 0, st, (const float *)e->winvall.p, N, (const float *)e->cull_box.p, (const float *)e->cull_lim.p, ng, nact,
+                     gchunk, e->cull_excl.p, nw, reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
+  HIPCHK(hipGetLastError());
+  e->cnt.kernel_launches += 6;
+  return MCX_OK;
+}
+
 // MCPar::genRemote on device buffers (src/mcpar.cc:315-451)
 static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
                          float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
@@ -812,28 +861,66 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     MCXCHK(e->pmax.alloc((size_t)n * S));
     MCXCHK(e->racpt.alloc((size_t)n));
   }
+  // exclusion of far Gaussians: the two-chains-per-lane sweeps (np = 16, 32) over enough chains and Gaussians to
+  // pay for the sort and the tests (or whenever possible: MCX_OPT_CULL = 1, for the tests)
+  const bool cull_can = !big && d == dm && SWEEP_CPL(dm) == 2 && e->opt_cull != 0;
+  auto cull_now = [&](int na) { return cull_can && (e->opt_cull > 0 || (na >= CULL_MIN_CHAINS && N >= CULL_MIN_GAUSSIANS)); };
+  if (cull_can) {
+    const size_t ngmax = ((size_t)n + CULL_W - 1) / CULL_W, nw = ((size_t)N + 63) / 64;
+    MCXCHK(e->cull_keys.alloc((size_t)n)); MCXCHK(e->cull_hist.alloc(CULL_BINS)); MCXCHK(e->cull_sorted.alloc((size_t)n));
+    MCXCHK(e->cull_stats.alloc(2 * CULL_KD)); MCXCHK(e->cull_box.alloc(ngmax * 2 * CULL_KD)); MCXCHK(e->cull_lim.alloc(ngmax));
+    MCXCHK(e->cull_excl.alloc(ngmax * nw));
+  }
+  HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
+  uint64_t evaluated_host = 0;  // pairs of the sweeps that ran without an exclusion test
+  // auto mode gives the test up where it excludes too little to pay for itself (the 32-D mixture: per-chain
+  // Gaussians too broad for any 128-chain box), per kind of sweep, and tries again every eighth call
+  constexpr double CULL_USELESS = 0.85;
+  bool cull_min = true, cull_sums = true;
+  if (e->opt_cull < 0) {
+    if (e->cull_skip[0] > 0) { cull_min = false; e->cull_skip[0]--; }
+    if (e->cull_skip[1] > 0) { cull_sums = false; e->cull_skip[1]--; }
+  }
+  uint64_t tested_min = 0, tested_sums = 0;
   hipLaunchKernelGGL(k_remote_prep, dim3(nblocks((size_t)N * d)), dim3(BLOCK), 0, st, musigall,
                      e->winvall.p, (size_t)N * d);
+  const int own0 = e->rank * e->nchain;
   if (big) {
     hipLaunchKernelGGL(k_remote_cmax_big, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, pvals, e->winvall.p,
                        e->cmax.p, n, d, N);
+    evaluated_host += (uint64_t)n * (uint64_t)N;
   } else {
-    ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)n * (uint64_t)N);
-    if (d == dm) {
-      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, true, SWEEP_CPL(DMAX_)>), dim3(nblocks(((size_t)n + SWEEP_CPL(DMAX_) - 1) / SWEEP_CPL(DMAX_)), S), dim3(BLOCK),
-                                           0, st, pvals, (const int *)nullptr, n, e->winvall.p,
-                                           (float *)nullptr, e->pmax.p, d, N, e->rank * e->nchain));
+    const bool cull = cull_now(n) && cull_min;
+    if (cull) tested_min = (uint64_t)n * (uint64_t)N;
+    const int *order = nullptr;
+    const unsigned long long *excl = nullptr;
+    if (cull) {
+      DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
+      order = e->cull_sorted.p;
+      excl = e->cull_excl.p;
     } else {
-      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
-                                           0, st, pvals, (const int *)nullptr, n, e->winvall.p,
-                                           (float *)nullptr, e->pmax.p, d, N, e->rank * e->nchain));
+      evaluated_host += (uint64_t)n * (uint64_t)N;
     }
+    {
+      ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)n * (uint64_t)N);
+      if (d == dm) {
+        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, true, SWEEP_CPL(DMAX_)>), dim3(nblocks(((size_t)n + SWEEP_CPL(DMAX_) - 1) / SWEEP_CPL(DMAX_)), S), dim3(BLOCK),
+                                             0, st, pvals, order, n, e->winvall.p,
+                                             (float *)nullptr, e->pmax.p, d, N, own0, excl, (n + CULL_W - 1) / CULL_W));
+      } else {
+        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
+                                             0, st, pvals, (const int *)nullptr, n, e->winvall.p,
+                                             (float *)nullptr, e->pmax.p, d, N, own0, (const unsigned long long *)nullptr, 0));
+      }
+    }
+    hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S, order);
   }
-  if (!big) hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S);
   HIPCHK(hipGetLastError());
   e->cnt.remote_pairs += (uint64_t)n * (uint64_t)N;
   int nact = n, pass = 0;
   int *ain = nullptr, *aout = e->active0.p;
+  unsigned long long kept_min = 0, kept_sums = 0;
+  MCXCHK(e->h_nact.alloc(1 + 2 * CULL_NCOUNT));  // pinned: the per-pass read-back queues behind the pass's last kernel
   while (nact > 0) {
     HIPCHK(hipMemsetAsync(e->nact.p, 0, sizeof(int), st));
     RemoteArgs a;
@@ -845,30 +932,59 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     a.g0 = (uint32_t)(e->rank * e->nchain); a.t = t; a.seed = e->seed;
     if (big) {
       hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
+      evaluated_host += (uint64_t)nact * (uint64_t)N;
     } else {
       DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
+      const bool cull = cull_now(nact) && cull_sums;
+      const int *list = ain;
+      const unsigned long long *excl = nullptr;
+      if (cull) {  // the proposals have just been drawn: sort, box and test them
+        DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
+        list = e->cull_sorted.p;
+        excl = e->cull_excl.p;
+        a.active_in = list;  // positions of psum / pmax are positions of the sorted list
+      } else {
+        evaluated_host += (uint64_t)nact * (uint64_t)N;
+      }
       {
       ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)nact * (uint64_t)N);
       if (d == dm) {
         DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, true, SWEEP_CPL(DMAX_)>), dim3(nblocks(((size_t)nact + SWEEP_CPL(DMAX_) - 1) / SWEEP_CPL(DMAX_)), S), dim3(BLOCK),
-                                             0, st, ptrial, (const int *)ain, nact, e->winvall.p,
-                                             e->psum.p, e->pmax.p, d, N, -1));
+                                             0, st, ptrial, list, nact, e->winvall.p,
+                                             e->psum.p, e->pmax.p, d, N, -1, excl, (nact + CULL_W - 1) / CULL_W));
       } else {
         DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, false>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
                                              0, st, ptrial, (const int *)ain, nact, e->winvall.p,
-                                             e->psum.p, e->pmax.p, d, N, -1));
+                                             e->psum.p, e->pmax.p, d, N, -1, (const unsigned long long *)nullptr, 0));
       }
       }
       hipLaunchKernelGGL(k_remote_decide, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     e->cnt.remote_pairs += (uint64_t)nact * (uint64_t)N;
-    HIPCHK(hipMemcpyAsync(&nact, e->nact.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    unsigned long long *back = e->h_nact.p;  // survivors (low word), cells of the pairs kept by the min-arg / sum tests so far
+    HIPCHK(hipMemcpyAsync(back, e->nact.p, (cull_can ? 1 + 2 * CULL_NCOUNT : 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const unsigned long long before = kept_sums;
+    const uint64_t pairs_now = (uint64_t)nact * (uint64_t)N;
+    nact = (int)(unsigned)back[0];
+    if (cull_can) {
+      kept_min = kept_sums = 0;
+      for (int c = 0; c < CULL_NCOUNT; ++c) { kept_min += back[1 + c]; kept_sums += back[1 + CULL_NCOUNT + c]; }
+    }
+    if (pairs_now && kept_sums > before) {  // this pass was tested
+      tested_sums += pairs_now;
+      if (e->opt_cull < 0 && (double)(kept_sums - before) > CULL_USELESS * (double)pairs_now) cull_sums = false;
+    }
     ain = aout;
     aout = (aout == e->active0.p) ? e->active1.p : e->active0.p;
     ++pass;
     e->cnt.kernel_launches += big ? 1 : 2;  // (+1: the sweep's own scope)
+  }
+  e->cnt.remote_pairs_evaluated += evaluated_host + (uint64_t)kept_min + (uint64_t)kept_sums;
+  if (e->opt_cull < 0) {
+    if (tested_min && (double)kept_min > CULL_USELESS * (double)tested_min) e->cull_skip[0] = 7;
+    if (tested_sums && (double)kept_sums > CULL_USELESS * (double)tested_sums) e->cull_skip[1] = 7;
   }
   hipLaunchKernelGGL(k_square, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, sigtrial, (size_t)e->ntot);
   HIPCHK(hipGetLastError());

@@ -13,6 +13,7 @@ OPT_SPLIT_RNG = 9
 OPT_PERSIST = 10
 OPT_MEET_TIMEOUT_MS = 11
 OPT_DEBUG_MEET = 12
+OPT_CULL = 13
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 

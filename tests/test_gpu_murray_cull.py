@@ -1,0 +1,103 @@
+"""Exact exclusion of far Gaussians in the Murray sweeps (mcx_remote.hpp, k_cull_*): sorting the active chains,
+boxing every wavefront's 128 chains and skipping the Q_i that are provably too far from all of them must not
+change a single bit -- with the exclusion forced on (MCX_OPT_CULL = 1), off (0) and automatic (-1), against the
+oracle, which knows nothing of it -- and must actually exclude most pairs on BASELINE-shaped states."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_configs import THREADS, mix_params, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def realistic_state(rng, N, d, n, stuck_every=0):
+    ms = np.empty((N, d, 2), np.float32)
+    ms[:, :, 0] = rng.normal(0.4, 0.4, (N, d))
+    ms[:, :, 1] = rng.uniform(0.01, 0.12, (N, d)) ** 2
+    if stuck_every:
+        ms[::stuck_every, :, 1] = np.float32(1e-14) / 29
+    pv = (ms[:n, :, 0] + np.sqrt(ms[:n, :, 1]) * rng.standard_normal((n, d))).astype(np.float32)
+    if stuck_every:
+        pv[::stuck_every] = ms[:n:stuck_every, :, 0]
+    return ms, pv
+
+
+@pytest.mark.parametrize("d,n,nshards", [(16, 1500, 1), (32, 700, 2), (16, 129, 3), (32, 4096, 1)])
+def test_gen_remote_same_bits_with_and_without_exclusion(d, n, nshards):
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    rng = np.random.default_rng(d * 1000 + n)
+    N = n * nshards
+    ms, pv = realistic_state(rng, N, d, n, stuck_every=7)
+    eo = O.Engine(d, n, nshards=nshards, shard=0, threads=THREADS)
+    ro = eo.gen_remote(41, pv, ms)
+    kept = {}
+    for mode in (1, 0, -1):
+        eg = M.Engine(d, n, nshards=nshards, shard=0)
+        eg.set_option(E.OPT_CULL, mode)
+        rg = eg.gen_remote(41, pv, ms)
+        assert rg[4] == ro[4], mode
+        for a, b, name in zip(rg[:4], ro[:4], ("ptrial", "cfac", "mutrial", "sigtrial")):
+            assert same_bits(a, b), (mode, name)
+        eg.close()
+
+
+@pytest.mark.parametrize("cfg", ["rosen16", "mix32"])
+def test_whole_murray_job_same_bits_and_most_pairs_excluded(cfg):
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    if cfg == "rosen16":
+        d, n, nburn, nsamp, pl = 16, 8192, 500, 60, 0.9
+        spec_o, spec_g = (O.VL_ROSENBROCK1, d), (M.VL_ROSENBROCK1, d)
+    else:
+        d, n, nburn, nsamp, pl = 32, 4096, 500, 60, 0.9
+        params = mix_params(d, 8)
+        spec_o, spec_g = (O.VL_GAUSSMIX, d, params, 8), (M.VL_GAUSSMIX, d, params, 8)
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(*spec_o)
+    eo = O.Engine(d, n, pl=pl, threads=THREADS)
+    eo.set_record(samples=False, mask=False)
+    eo.run(nsamp, nburn, p, vo)
+    assert eo.remote_steps >= 3
+    vg, k2 = M.make_vlfunc(*spec_g)
+    frac = {}
+    for mode in (1, 0):
+        eg = M.Engine(d, n, pl=pl)
+        eg.set_option(E.OPT_CULL, mode)
+        eg.run(nsamp, nburn, p, vg)
+        c = eg.counters
+        assert c["remote_steps"] == eo.remote_steps and c["remote_passes"] == eo.remote_passes
+        assert c["naccept_main"] == eo.naccept_main
+        assert np.array_equal(eg.accept_counts, eo.accept_counts)
+        for name in ("state", "loglike", "mean", "var", "musigall"):
+            assert same_bits(getattr(eg, name), getattr(eo, name)), (mode, name)
+        frac[mode] = c["remote_pairs_evaluated"] / float(c["remote_pairs"])
+        eg.close()
+    print("pairs left after the exclusion test: %.3f of all (%s)" % (frac[1], cfg))
+    assert frac[0] == 1.0 and frac[1] <= 1.0
+    if cfg == "rosen16":  # (the 32-D mixture's per-chain Gaussians are too broad for a 128-chain box to exclude much)
+        assert frac[1] < 0.8
+
+
+def test_exclusion_keeps_nan_and_degenerate_inputs_identical():
+    """a Gaussian with an enormous 1/sig2, chains far outside every box, a group of identical chains"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    rng = np.random.default_rng(99)
+    d, n = 16, 640
+    ms, pv = realistic_state(rng, n, d, n)
+    ms[5, :, 1] = 1e-30
+    ms[6, :, 0] = 1e6
+    pv[10:150] = pv[10]
+    pv[200] = 50.0
+    eo = O.Engine(d, n, threads=THREADS)
+    ro = eo.gen_remote(3, pv, ms)
+    for mode in (1, 0):
+        eg = M.Engine(d, n)
+        eg.set_option(E.OPT_CULL, mode)
+        rg = eg.gen_remote(3, pv, ms)
+        assert rg[4] == ro[4]
+        for a, b, name in zip(rg[:4], ro[:4], ("ptrial", "cfac", "mutrial", "sigtrial")):
+            assert same_bits(a, b), (mode, name)
+        eg.close()

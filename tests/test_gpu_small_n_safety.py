@@ -26,46 +26,52 @@ def oracle_run(d, n, nburn, nsamp, pl=1.0):
     return eo
 
 
-def check_against(eg, eo):
-    c = eg.counters
-    assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
-    assert np.array_equal(eg.tuner_trace, eo.tuner_trace)
-    for name in ("state", "loglike", "mean", "var", "samples"):
-        assert same_bits(getattr(eg, name), getattr(eo, name)), name
-
-
 def test_meeting_that_cannot_complete_is_abandoned_and_the_run_repeated():
     import mcpar_amd as M
     from mcpar_amd import engine as E
     d, n, nburn, nsamp = 8, 4096, 160, 40
-    eo = oracle_run(d, n, nburn, nsamp)
-    vg, k = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     p = O.default_pinit(d, n)
+    vo, k0 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=1.0, threads=8)
+    eo.set_record(samples=False, mask=False)
+    vg, k = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eg = M.Engine(d, n, pl=1.0)
     eg.set_option(E.OPT_PERSIST, 1)
+    eg.set_option(E.OPT_SAMPLES, 0)
+
+    def same_as_oracle():
+        c = eg.counters
+        assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+        assert np.array_equal(eg.tuner_trace, eo.tuner_trace)
+        for name in ("state", "loglike", "mean", "var"):
+            assert same_bits(getattr(eg, name), getattr(eo, name)), name
+
+    eo.run(nsamp, nburn, p, vo)
     eg.run(nsamp, nburn, p, vg)  # the one-launch kernel as it normally runs
     assert eg.counters["meet_timeouts"] == 0 and eg.counters["kernel_launches"] <= 3
-    check_against(eg, eo)
+    same_as_oracle()
     # now every meeting waits for one workgroup more than the grid has: it can never complete
     eg.set_option(E.OPT_DEBUG_MEET, 1)
     eg.set_option(E.OPT_MEET_TIMEOUT_MS, 50)
+    eo.run(nsamp, nburn, p, vo)  # (a second run continues the RNG step counter, on both sides)
     t0 = time.time()
     eg.run(nsamp, nburn, p, vg)
     dt = time.time() - t0
     assert dt < 1.0, "abandoning a meeting took %.2f s" % dt
     assert eg.counters["meet_timeouts"] == 1
     assert eg.counters["kernel_launches"] > 3  # the per-segment kernels did the job
-    check_against(eg, eo)
-    # the engine keeps to the per-segment kernels afterwards ...
+    same_as_oracle()
+    # the engine keeps to the per-segment kernels afterwards
+    eo.run(nsamp, nburn, p, vo)
     eg.run(nsamp, nburn, p, vg)
     assert eg.counters["meet_timeouts"] == 0 and eg.counters["kernel_launches"] > 3
-    # ... (a second run continues the RNG step counter: compare with the oracle doing the same)
-    eo2 = oracle_run(d, n, nburn, nsamp)
-    vo, k2 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
-    eo2.run(nsamp, nburn, p, vo)
-    eo2.run(nsamp, nburn, p, vo)
-    for name in ("state", "loglike", "mean", "var"):
-        assert same_bits(getattr(eg, name), getattr(eo2, name)), name
+    same_as_oracle()
+    # switching the hook off gives the one-launch kernel back
+    eg.set_option(E.OPT_DEBUG_MEET, 0)
+    eo.run(nsamp, nburn, p, vo)
+    eg.run(nsamp, nburn, p, vg)
+    assert eg.counters["meet_timeouts"] == 0 and eg.counters["kernel_launches"] <= 3
+    same_as_oracle()
 
 
 def test_abandoned_meeting_with_a_sample_sink_delivers_only_good_rows():
