@@ -11,7 +11,7 @@ all: lib oracle
 lib:
 	$(MAKE) -j6 mcpar_amd/libmcx.so
 
-OBJS = $(CSRC)/mcx_engine.o $(CSRC)/mcx_k_fast.o $(CSRC)/mcx_k_fast_full.o $(CSRC)/mcx_k_pregen.o $(CSRC)/mcx_k_generic_burn.o \
+OBJS = $(CSRC)/mcx_engine.o $(CSRC)/mcx_k_fast.o $(CSRC)/mcx_k_fastb.o $(CSRC)/mcx_k_fast_full.o $(CSRC)/mcx_k_pregen.o $(CSRC)/mcx_k_generic_burn.o \
        $(CSRC)/mcx_k_generic_main.o $(CSRC)/mcx_k_persist.o
 HDRS = $(CSRC)/mcx_device.hpp $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_launch.hpp $(CSRC)/mcx_persist.hpp include/mcx.h
 
@@ -20,6 +20,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 
 # the Murray kernels are seen by the engine's translation unit only
 $(CSRC)/mcx_engine.o: $(CSRC)/mcx_remote.hpp
+$(CSRC)/mcx_k_fastb.o: $(CSRC)/mcx_fastb.hpp
 
 mcpar_amd/libmcx.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS)

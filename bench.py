@@ -49,6 +49,10 @@ CONFIGS = {
     "c3": dict(name="mcpar-rosen2 (C3)", lik=1, d=16, n=65536, pl=1.0, nburn=500, nsamp=1000),
     "c5": dict(name="mcpar-dgauss mixture (C5 per-GPU shape)", lik=5, d=32, K=8, n=32768, pl=0.9, nburn=500, nsamp=100),
     "c3-murray": dict(name="mcpar-rosen2 (C3), R-murray", lik=1, d=16, n=65536, pl=0.9, nburn=500, nsamp=100),
+    # flagged variant, not reference behaviour: the overlapping Rosenbrock with the sign of
+    # src/rosenbrock.cc:38 corrected and the loop kept inside each set (MCX_VL_ROSENBROCK2_FIXED)
+    "c3-rosen2fixed": dict(name="mcpar-rosen2 (C3) with the well-posed overlapping Rosenbrock2 (flagged deviation)", lik=6, d=16,
+                           n=65536, pl=1.0, nburn=500, nsamp=1000),
 }
 
 
@@ -83,11 +87,14 @@ def lpc_for(d):
 def make_lik(mod, cfg):
     if cfg["lik"] == 5:
         return mod.make_vlfunc(mod.VL_GAUSSMIX, cfg["d"], mix_params(cfg["d"], cfg["K"]), cfg["K"])
+    if cfg["lik"] == 6:
+        return mod.make_vlfunc(6, cfg["d"])  # MCX_VL_ROSENBROCK2_FIXED (same id in the oracle)
     return mod.make_vlfunc(mod.VL_ROSENBROCK1, cfg["d"])
 
 
 def workload_text(cfg, n):
-    lik = "Rosenbrock1(%d)" % cfg["d"] if cfg["lik"] == 1 else "%d-D %d-component Gaussian mixture" % (cfg["d"], cfg["K"])
+    lik = ("Rosenbrock1(%d)" % cfg["d"] if cfg["lik"] == 1 else "Rosenbrock2Fixed(%d)" % cfg["d"] if cfg["lik"] == 6 else
+           "%d-D %d-component Gaussian mixture" % (cfg["d"], cfg["K"]))
     return ("%s: %s x %d chains/GPU, %s job (pl=%.2f, nburn=%d, nsamp=%d, sync=10), one bench step = one full run()"
             % (cfg["name"], lik, n, "R-local" if cfg["pl"] >= 1.0 else "R-murray", cfg["pl"], cfg["nburn"], cfg["nsamp"]))
 
@@ -535,7 +542,7 @@ def main():
         fm, fb, rs = prof["fused_main"], prof["fused_burn"], prof["run_small"]
         split = prof["gen_normals"]["launches"] > 0
         lpc = lpc_for(d)
-        likname = {1: "LIK_ROSEN1", 5: "LIK_MIX"}[cfg["lik"]]
+        likname = {1: "LIK_ROSEN1", 5: "LIK_MIX", 6: "LIK_ROSEN2F"}[cfg["lik"]]
         if rs["launches"] > 0 and rs["ms"] > 0:
             # small-n mode: burn-in and main-loop steps run in ONE launch of k_run_small (mcx_persist.hpp)
             kmatch = "k_run_small<%d, %d" % (lpc, cfg["lik"])

@@ -58,6 +58,30 @@ public:
   }
 };
 
+/* NOT in the reference -- a flagged variant: the overlapping Rosenbrock function made well-posed.  The reference's
+ * Rosenbrock2 subtracts its second term (src/rosenbrock.cc:38; compare the '+' at :18), which leaves log L unbounded
+ * above, and its flat loop reads x[i+1] across the boundary of a parameter set (:32-35).  This one is
+ * - sum_{k < n-1} (1 - x_k)^2 + 100 (x_{k+1} - x_k^2)^2 per set. */
+class Rosenbrock2Fixed : public VLFunc {
+  const int n;
+public:
+  Rosenbrock2Fixed(int nc) : n(nc)
+  {
+    if (n < 2) throw("N for Rosenbrock2 must be >= 2");
+  }
+  bool device_descriptor(int, mcx_vlfunc *o) const
+  {
+    *o = mcx_vlfunc{MCX_VL_ROSENBROCK2_FIXED, n, 0, 0, 0, 0};
+    return true;
+  }
+  int operator()(int npset, const float *x, float *restrict fx)
+  {
+    mcx_vlfunc f;
+    device_descriptor(n, &f);
+    return mcpar_detail::eval_builtin(f, npset, x, fx);
+  }
+};
+
 /* Diagonal Gaussian (src/rosenbrock.hh:35-50).  The reference insists on N == 2; any N works here. */
 class Gaussian : public VLFunc {
   const int n;

@@ -45,6 +45,10 @@ enum {
   MCX_VL_GAUSSIAN = 3,    /* Gaussian::operator()     src/rosenbrock.cc:44-61  any d      (fused) */
   MCX_VL_DUALGAUSS = 4,   /* DualGaussian::operator() src/rosenbrock.cc:63-78             (fused) */
   MCX_VL_GAUSSMIX = 5,    /* N-D K-component unit-variance mixture (BASELINE config 5)    (fused) */
+  MCX_VL_ROSENBROCK2_FIXED = 6, /* NOT reference behaviour, a flagged variant: the overlapping Rosenbrock function made
+                             well-posed -- src/rosenbrock.cc:25-41 with '+' on the second term (the '-' at :38 leaves
+                             log L unbounded above) and the loop kept inside each parameter set:
+                             - sum_{k < d-1} (1 - x_k)^2 + 100 (x_{k+1} - x_k^2)^2                      (fused) */
   MCX_VL_HOST = 100,      /* any user VLFunc subclass: device -> host callback -> device  */
   MCX_VL_DEVICE = 101     /* user likelihood as a GPU kernel: stays on the device (see mcx_vlfunc.ctx) */
 };
@@ -182,6 +186,9 @@ enum {
   MCX_OPT_CULL = 13,       /* Murray sweeps: exclude, exactly, the Gaussians that are too far from all 128 chains of a
                               wavefront to matter (the chains are sorted spatially first; same bits).  -1 auto [default:
                               np = 16 or 32, >= 4096 chains still rejected, >= 4096 Gaussians], 0 off, 1 whenever np allows */
+  MCX_OPT_BLOCKS_PER_LANE = 14, /* hot-path kernel: consecutive 4-parameter blocks of a chain held by one lane -- 1: one
+                              (np/4 lanes per chain), 2 or 4: fewer lanes per chain, the per-chain work (acceptance test,
+                              selects, counters) paid once per 2 / 4 blocks (same bits).  0 auto [default] */
   MCX_OPT_DEBUG_MEET = 12    /* test hook: the meetings wait for `value` workgroups more than the grid has, i.e.
                               they can never complete [default 0] */
 };

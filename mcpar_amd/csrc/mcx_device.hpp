@@ -23,7 +23,7 @@ constexpr int BLOCK = 256;  // 4 wavefronts per workgroup
 constexpr int MAXD_LDS = 32;  // full-covariance factor is staged in LDS up to this np, read from L2 above
 constexpr int MAXD = 256;     // lanes per chain <= 64
 
-enum LikKind : int { LIK_ROSEN1 = 1, LIK_ROSEN2 = 2, LIK_GAUSS = 3, LIK_MIX = 5 };
+enum LikKind : int { LIK_ROSEN1 = 1, LIK_ROSEN2 = 2, LIK_GAUSS = 3, LIK_MIX = 5, LIK_ROSEN2F = 6 };
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
@@ -72,6 +72,29 @@ struct Lik<LIK_ROSEN1, LPC> {  // src/rosenbrock.cc:4-21
       acc = acc + __builtin_fmaf(100.0f * t2, t2, t1 * t1);
     }
     return 0.0f - group_sum<LPC>(acc);  // 0 - s like the reference's fx = 0; fx -= ...: never -0
+  }
+};
+
+// The overlapping Rosenbrock function made well-posed (MCX_VL_ROSENBROCK2_FIXED: src/rosenbrock.cc:25-41 with '+' at
+// :38 and the loop kept inside the set): term k = (1 - x_k)^2 + 100 (x_{k+1} - x_k^2)^2 for k < d - 1 belongs to
+// block k / 4; the block's last term takes x_{k+1} from the next lane of the chain.
+template <int LPC>
+struct Lik<LIK_ROSEN2F, LPC> {
+  int d, k0;
+  __device__ __forceinline__ void init(const float *, int d_, int k0_, int, int) { d = d_; k0 = k0_; }
+  __device__ __forceinline__ float eval(const float xb[4], int) const
+  {
+    const float nxt = __shfl_down(xb[0], 1);  // (every lane of the wavefront is here; the chain's last block ignores it)
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (k0 + c + 1 < d) {
+        const float a = xb[c], b = c < 3 ? xb[c < 3 ? c + 1 : 0] : nxt;
+        const float t1 = 1.0f - a;
+        const float t2 = __builtin_fmaf(-a, a, b);
+        acc = acc + __builtin_fmaf(100.0f * t2, t2, t1 * t1);
+      }
+    return 0.0f - group_sum<LPC>(acc);
   }
 };
 
@@ -524,8 +547,8 @@ __device__ __forceinline__ float quad_bcast(float v, int qq)
 template <int LPC, bool MAIN, int LIK = LIK_ROSEN1, bool PREGEN = false, bool FULL = false>
 __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
 {
-  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX,
-                "fast path: Rosenbrock1, diagonal Gaussian, or a mixture of <= 8 unit Gaussians");
+  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX || (LIK == LIK_ROSEN2F && !PREGEN && !FULL),
+                "fast path: Rosenbrock1, diagonal Gaussian, a mixture of <= 8 unit Gaussians, or (plain kernel only) the overlapping Rosenbrock");
   static_assert(!(FULL && PREGEN), "the pre-generated normals are laid out for diagonal proposals");
   __shared__ __attribute__((aligned(16))) float4 lds_T[FULL ? 4 * LPC * LPC : 1];
   __shared__ __attribute__((aligned(16))) float4 lds_z[FULL && LPC == 8 ? (BLOCK / 8) * 9 : 1];
@@ -626,6 +649,20 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
       const f32x2 t2 = fma2(-pe, pe, po);
       const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
       if (live) acc = term.x + term.y;  // == (0 + term.x) + term.y: the terms are >= +0
+    } else if (LIK == LIK_ROSEN2F) {
+      // the overlapping Rosenbrock (MCX_VL_ROSENBROCK2_FIXED): terms k = k0 .. k0+3 on the pairs (x0,x1), (x1,x2),
+      // (x2,x3), (x3, x4) with x4 = the first parameter of the chain's next lane (DPP row_shl 1); the chain's last
+      // block has no fourth term
+      const float nx = dpp_mov<0x101>(pe.x);
+      const f32x2 b2 = f32x2{pe.y, nx};
+      const f32x2 u1 = splat2(1.0f) - pe, v1 = splat2(1.0f) - po;
+      const f32x2 u2 = fma2(-pe, pe, po), v2 = fma2(-po, po, b2);
+      const f32x2 te_ = fma2(splat2(100.0f) * u2, u2, u1 * u1);  // terms k0, k0+2
+      const f32x2 to_ = fma2(splat2(100.0f) * v2, v2, v1 * v1);  // terms k0+1, k0+3
+      if (live) {
+        acc = (te_.x + to_.x) + te_.y;
+        if (k0 + 4 < d) acc = acc + to_.y;
+      }
     } else if (LIK == LIK_GAUSS) {
       // src/rosenbrock.cc:44-61: acc = fma((0.5 a) a, 1/sigma^2, acc) for k = 0..3 in order
       const f32x2 ae = pe - gme, ao = po - gmo;

@@ -199,7 +199,7 @@ struct LikDev {
   std::vector<float> host;  // staging for the asynchronous upload (must outlive it)
   mcx_host_fn fn = nullptr;
   void *ctx = nullptr;
-  bool fusable() const { return kind == LIK_ROSEN1 || kind == LIK_GAUSS || kind == LIK_MIX; }
+  bool fusable() const { return kind == LIK_ROSEN1 || kind == LIK_GAUSS || kind == LIK_MIX || kind == LIK_ROSEN2F; }
 };
 
 // uploads asynchronously on st; the caller synchronises before L.host is touched again
@@ -221,6 +221,10 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   case MCX_VL_ROSENBROCK2:
     if (d < 2) return fail(MCX_ERR_INVALID, "N for Rosenbrock2 must be >= 2");  // src/rosenbrock.hh:27-30
     L.kind = LIK_ROSEN2;
+    break;
+  case MCX_VL_ROSENBROCK2_FIXED:
+    if (d < 2) return fail(MCX_ERR_INVALID, "N for Rosenbrock2 must be >= 2");
+    L.kind = LIK_ROSEN2F;
     break;
   case MCX_VL_GAUSSIAN:
     L.kind = LIK_GAUSS;
@@ -305,11 +309,12 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
 
 // The fused-kernel families are compiled in their own translation units (mcx_k_fast.hip,
 // mcx_k_pregen.hip, mcx_k_generic_*.hip) so that the library builds in parallel; see mcx_launch.hpp.
-static int launch_fused_plain(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st, bool fast)
+static int launch_fused_plain(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st, bool fast, int bpl = 1)
 {
   hipError_t err;
   const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
-  if (fast) err = mcxk_launch_fast(lpc, lik, main, a, st);  // hot path
+  if (fast && fast_lik && bpl > 1 && bpl <= lpc) err = mcxk_launch_fastb(lpc, bpl, lik, main, a, st);  // hot path, several blocks per lane
+  else if (fast) err = mcxk_launch_fast(lpc, lik, main, a, st);  // hot path
   else if (lpc <= 8 && fast_lik && !a.diag && a.vec4 && !a.mask) err = mcxk_launch_fast_full(lpc, lik, main, a, st);
   else err = main ? mcxk_launch_generic_main(lpc, lik, a, st) : mcxk_launch_generic_burn(lpc, lik, a, st);
   if (err == hipErrorInvalidValue) return fail(MCX_ERR_UNSUPPORTED, "no fused kernel for lanes/chain = %d, likelihood %d", lpc, lik);
@@ -331,6 +336,9 @@ static int launch_eval(int lik, const float *x, float *y, int n, int d, const fl
     break;
   case LIK_MIX:
     hipLaunchKernelGGL((k_eval<LPC, LIK_MIX>), grid, block, 0, st, x, y, n, d, params, ncomp, vec4);
+    break;
+  case LIK_ROSEN2F:
+    hipLaunchKernelGGL((k_eval<LPC, LIK_ROSEN2F>), grid, block, 0, st, x, y, n, d, params, ncomp, vec4);
     break;
   case LIK_ROSEN2:
     hipLaunchKernelGGL(k_eval_rosen2, dim3(nblocks((size_t)n)), block, 0, st, x, y, n, d);
@@ -410,6 +418,7 @@ struct mcx_engine {
   bool own_stream = false;
   int opt_stride = 1;
   int opt_split = -1;  // small-n mode: -1 auto, 0 off, 1 on (when the hot-path kernel applies)
+  int opt_bpl = 0;     // 4-parameter blocks per lane of the hot-path kernel: 0 auto, 1, 2, 4
   int opt_persist = -1;  // small-n mode, one launch per stretch of local steps (k_run_small): -1 auto, 0 off, 1 on
   int ncu = 0;           // compute units of the device (the persistent grid must be resident at once)
   int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0;
@@ -486,10 +495,21 @@ static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t 
 {
   const int lik = e->lik.kind, lpc = e->lpc;
   const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
-  const bool fast = lpc <= 8 && fast_lik && a.diag && a.vec4 && !a.mask;
+  // (the overlapping Rosenbrock has the plain hot-path kernel only: no small-n modes, no several blocks per lane)
+  const bool fast = lpc <= 8 && (fast_lik || lik == LIK_ROSEN2F) && a.diag && a.vec4 && !a.mask;
   const size_t waves = ((size_t)a.n * lpc + 63) / 64;
-  const bool split = fast && (e->opt_split > 0 || (e->opt_split < 0 && waves < SPLIT_AUTO_MAX_WAVES));
-  if (!split) return launch_fused_plain(lpc, lik, main, a, st, fast);
+  const bool split = fast && fast_lik && (e->opt_split > 0 || (e->opt_split < 0 && waves < SPLIT_AUTO_MAX_WAVES));
+  if (!split) {
+    // blocks per lane of the hot-path kernel: MCX_OPT_BLOCKS_PER_LANE, or what was measured best (mcx_fastb.hpp)
+    // Measured (tools/bpl_sweep.py, 65 536 chains): Rosenbrock1 / Gaussian 16-D 2.51 ms per job with one block per
+    // lane, 2.67 with two, 2.81 with four -- the step is bound by the Philox / Box-Muller issue slots, which do not
+    // care how the lanes are cut; the 32-D mixture 2.63 -> 1.97 ms with two -- its eight per-component reductions
+    // over 8 lanes (DPP + row operations each) become reductions over 4.
+    int bpl = e->opt_bpl;
+    if (bpl == 0) bpl = (lik == LIK_MIX && lpc == 8) ? 2 : 1;
+    while (bpl > lpc) bpl >>= 1;
+    return launch_fused_plain(lpc, lik, main, a, st, fast, bpl);
+  }
   // generator and step kernel alternate on the engine's stream (overlapping them on two streams was
   // measured slower: the cross-stream event waits cost more than the generator, which is ~10 % of a chunk)
   const size_t per_step = (size_t)a.n * a.d * sizeof(float);
@@ -663,6 +683,10 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
   case MCX_OPT_SPLIT_RNG: e->opt_split = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_PERSIST: e->opt_persist = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_CULL: e->opt_cull = value < 0 ? -1 : (value ? 1 : 0); break;
+  case MCX_OPT_BLOCKS_PER_LANE:
+    if (value != 0 && value != 1 && value != 2 && value != 4) return fail(MCX_ERR_INVALID, "BLOCKS_PER_LANE must be 0 (auto), 1, 2 or 4");
+    e->opt_bpl = (int)value;
+    break;
   case MCX_OPT_MEET_TIMEOUT_MS:
     if (value < 1) return fail(MCX_ERR_INVALID, "MEET_TIMEOUT_MS must be >= 1");
     e->opt_meet_timeout_ms = (int)std::min<int64_t>(value, 600000);

@@ -19,6 +19,7 @@ static hipError_t by_lik(int lik, bool main, const SegArgs &a, hipStream_t st)
   case LIK_ROSEN1: return go<LPC, LIK_ROSEN1>(main, a, st);
   case LIK_GAUSS: return go<LPC, LIK_GAUSS>(main, a, st);
   case LIK_MIX: return go<LPC, LIK_MIX>(main, a, st);
+  case LIK_ROSEN2F: return go<LPC, LIK_ROSEN2F>(main, a, st);
   default: return hipErrorInvalidValue;
   }
 }

@@ -12,6 +12,7 @@ static hipError_t by_lik(int lik, const SegArgs &a, hipStream_t st)
   case LIK_ROSEN1: hipLaunchKernelGGL((k_fused_steps<LPC, LIK_ROSEN1, true>), grid, block, 0, st, a); break;
   case LIK_GAUSS: hipLaunchKernelGGL((k_fused_steps<LPC, LIK_GAUSS, true>), grid, block, 0, st, a); break;
   case LIK_MIX: hipLaunchKernelGGL((k_fused_steps<LPC, LIK_MIX, true>), grid, block, 0, st, a); break;
+  case LIK_ROSEN2F: hipLaunchKernelGGL((k_fused_steps<LPC, LIK_ROSEN2F, true>), grid, block, 0, st, a); break;
   default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -5,6 +5,8 @@
 #include "mcx_device.hpp"
 
 hipError_t mcxk_launch_fast(int lpc, int lik, bool main, const mcx::SegArgs &a, hipStream_t st);   // mcx_k_fast.hip
+// the same with bpl = 2 or 4 consecutive blocks per lane (mcx_fastb.hpp), bpl <= lpc
+hipError_t mcxk_launch_fastb(int lpc, int bpl, int lik, bool main, const mcx::SegArgs &a, hipStream_t st);  // mcx_k_fastb.hip
 // full lower-triangular factor a.T (a.diag == 0), np <= 32, np % 4 == 0
 hipError_t mcxk_launch_fast_full(int lpc, int lik, bool main, const mcx::SegArgs &a, hipStream_t st);  // mcx_k_fast_full.hip
 // small-n mode: a.zpre / a.upre must hold the output of mcxk_launch_gen for the same (t0, nsteps)

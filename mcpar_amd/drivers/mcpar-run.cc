@@ -1,6 +1,6 @@
 // mcpar-run -- the BASELINE configurations as a first-class driver (the reference reaches them
 // only through its library API: SURVEY fact 3).
-//   mcpar-run [--func rosen1|rosen2|gauss|dgauss|mix] [--np D] [--nc CHAINS] [--nsamp N]
+//   mcpar-run [--func rosen1|rosen2|rosen2fixed|gauss|dgauss|mix] [--np D] [--nc CHAINS] [--nsamp N]
 //             [--nburn B] [--pl P] [--sync S] [--ncomp K] [--quiet] [--iter]
 // Output: the reference's row format (src/mcout.cc:41-45); --iter prepends the iteration index
 // that src/anly/mcpar-analysis.R:80-120 reconstructs; --quiet prints only the summary (stderr).
@@ -49,6 +49,7 @@ int main(int argc, char *argv[])
   try {
     if (func == "rosen1") L = new Rosenbrock1(np);
     else if (func == "rosen2") L = new Rosenbrock2(np);
+    else if (func == "rosen2fixed") L = new Rosenbrock2Fixed(np);  // flagged variant, not reference behaviour
     else if (func == "gauss") L = new Gaussian(np);
     else if (func == "dgauss") { np = 2; L = new DualGaussian(5.0f); }
     else if (func == "mix") {  // means 5k/(K-1) * 1, weights (5,1,...,1)

@@ -7,6 +7,7 @@ from ._lib import (HOSTFN, K_NAMES, OUTFN, SINKFN, XCHGFN, Counters, PlanItem, P
 
 VL_ROSENBROCK1, VL_ROSENBROCK2, VL_GAUSSIAN, VL_DUALGAUSS, VL_GAUSSMIX, VL_HOST = 1, 2, 3, 4, 5, 100
 VL_DEVICE = 101
+VL_ROSENBROCK2_FIXED = 6
 OPT_SAMPLES, OPT_ACCEPT_MASK, OPT_FUSE, OPT_MAX_SEGMENT, OPT_PROFILE, OPT_STREAM, OPT_EAGER_EXCHANGE = 1, 2, 3, 4, 5, 6, 7
 OPT_SAMPLE_STRIDE = 8
 OPT_SPLIT_RNG = 9
@@ -14,6 +15,7 @@ OPT_PERSIST = 10
 OPT_MEET_TIMEOUT_MS = 11
 OPT_DEBUG_MEET = 12
 OPT_CULL = 13
+OPT_BLOCKS_PER_LANE = 14
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 

@@ -178,7 +178,17 @@ def gen_oracle_runs():
     w = np.array([5, 1, 1, 1, 1, 1, 1, 1], np.float32)
     one("mix_c5_small", O.VL_GAUSSMIX, 32, 32, 60, 30, 0.8, params=np.concatenate([means.ravel(), w]),
         ncomp=8)
-    return dict(source="oracle/mcx_oracle.c (MCX arithmetic v3), seed 8675309", runs=runs)
+    one("rosen2fixed_d16_local", O.VL_ROSENBROCK2_FIXED, 16, 64, 120, 40, 1.0)
+    # the flagged well-posed overlapping Rosenbrock (not in the reference): its values as the oracle computes them
+    rng = np.random.default_rng(20261004)
+    vl_cases = []
+    for d in (2, 3, 7, 16, 18):
+        x = rng.normal(0.0, 1.1, (12, d)).astype(np.float32)
+        x[0] = 1.0
+        x[1] = 0.0
+        vl_cases.append(dict(name="rosenbrock2_fixed", d=d, npset=12, x=f32list(x),
+                             y=f32list(O.vl_eval(O.VL_ROSENBROCK2_FIXED, d, x))))
+    return dict(source="oracle/mcx_oracle.c (MCX arithmetic v3), seed 8675309", runs=runs, vlfunc_cases=vl_cases)
 
 
 if __name__ == "__main__":

@@ -208,6 +208,28 @@ static float rosen1_one(int d, const float *x)
   return 0.0f - butterfly_sum(part, nb); /* 0 - s like the reference's fx = 0; fx -= ...: never -0 */
 }
 
+/* The well-posed overlapping N-D Rosenbrock function: the reference's Rosenbrock2 (src/rosenbrock.cc:25-41) with the
+ * sign of its second term corrected ('+' like :18 instead of the '-' at :38, which makes log L unbounded above)
+ * and the loop kept inside each parameter set (the reference's flat loop reads x[i+1] across the set boundary):
+ * fx = - sum_{k=0}^{d-2} (1 - x_k)^2 + 100 (x_{k+1} - x_k^2)^2.  NOT in the reference: a flagged variant
+ * (SURVEY §7 step 1, §8d), written here, not a patched copy.  Term k belongs to block k / 4. */
+static float rosen2f_one(int d, const float *x)
+{
+  float part[64];
+  int nb = (d + 3) / 4;
+  for (int q = 0; q < nb; ++q) {
+    float acc = 0.0f;
+    for (int k = 4 * q; k + 1 < d && k < 4 * q + 4; ++k) {
+      float t1 = 1.0f - x[k];
+      float t2 = fmaf(-x[k], x[k], x[k + 1]);
+      float term = fmaf(100.0f * t2, t2, t1 * t1);
+      acc = acc + term;
+    }
+    part[q] = acc;
+  }
+  return 0.0f - butterfly_sum(part, nb);
+}
+
 /* src/rosenbrock.cc:44-61, any d (reference throws unless d == 2: src/rosenbrock.hh:43) */
 static float gauss_one(int d, const float *x, const float *mu, const float *s2inv)
 {
@@ -279,6 +301,11 @@ int mcxo_vlfunc_eval(const mcxo_vlfunc *f, int npset, const float *x, float *y)
     }
     return 0;
   }
+  case MCXO_VL_ROSENBROCK2_FIXED:
+    if (d < 2) return -1;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int j = 0; j < npset; ++j) y[j] = rosen2f_one(d, x + (size_t)j * d);
+    return 0;
   case MCXO_VL_GAUSSIAN: {
     float mu[256], s2inv[256];
     for (int k = 0; k < d; ++k) {

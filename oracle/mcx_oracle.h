@@ -36,6 +36,8 @@ enum {
   MCXO_VL_GAUSSIAN = 3,    /* src/rosenbrock.cc:44-61, generalised to any d */
   MCXO_VL_DUALGAUSS = 4,   /* src/rosenbrock.cc:63-78  */
   MCXO_VL_GAUSSMIX = 5,    /* N-D K-component unit-variance mixture (BASELINE C5) */
+  MCXO_VL_ROSENBROCK2_FIXED = 6, /* the well-posed overlapping Rosenbrock: src/rosenbrock.cc:25-41 with '+' at :38 and
+                              the loop kept inside each set -- a flagged variant, not reference behaviour */
   MCXO_VL_HOST = 100       /* user callback, VLFunc::operator() src/vlfunc.hh:9-12 */
 };
 

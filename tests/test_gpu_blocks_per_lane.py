@@ -1,0 +1,93 @@
+"""k_fused_fastb (mcx_fastb.hpp): the hot-path kernel with two or four 4-parameter blocks per lane must give the
+bits of the one-block kernel -- i.e. of the oracle -- for every likelihood of the hot path, ragged chains
+(d = 12, 20: a lane with a live and a dead block), thinned sample stores and the in-kernel exchange snapshot."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_configs import mix_params, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def specs(kind, d):
+    import mcpar_amd as M
+    if kind == "rosen":
+        return (O.VL_ROSENBROCK1, d), (M.VL_ROSENBROCK1, d)
+    if kind == "gauss":
+        p = np.concatenate([np.linspace(-1, 1, d), np.linspace(0.5, 2.0, d)]).astype(np.float32)
+        return (O.VL_GAUSSIAN, d, p), (M.VL_GAUSSIAN, d, p)
+    p = mix_params(d, 8)
+    return (O.VL_GAUSSMIX, d, p, 8), (M.VL_GAUSSMIX, d, p, 8)
+
+
+@pytest.mark.parametrize("bpl", [2, 4])
+@pytest.mark.parametrize("kind,d,n", [("rosen", 16, 3000), ("rosen", 8, 1111), ("rosen", 12, 700), ("rosen", 32, 640),
+                                      ("rosen", 20, 513), ("gauss", 16, 900), ("gauss", 24, 300), ("mix", 32, 512),
+                                      ("mix", 8, 777)])
+def test_blocks_per_lane_same_bits_as_oracle(kind, d, n, bpl):
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    so, sg = specs(kind, d)
+    nburn, nsamp = 130, 70
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(*so)
+    eo = O.Engine(d, n, pl=1.0, threads=8)
+    eo.run(nsamp, nburn, p, vo)
+    vg, k2 = M.make_vlfunc(*sg)
+    eg = M.Engine(d, n, pl=1.0)
+    eg.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
+    eg.set_option(E.OPT_PERSIST, 0)
+    eg.set_option(E.OPT_SPLIT_RNG, 0)  # the plain hot-path kernel, not the small-n modes
+    eg.run(nsamp, nburn, p, vg)
+    c = eg.counters
+    assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+    assert np.array_equal(eg.accept_counts, eo.accept_counts)
+    assert np.array_equal(eg.tuner_trace, eo.tuner_trace)
+    for name in ("state", "loglike", "mean", "var", "musigall", "samples"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
+    eg.close()
+
+
+@pytest.mark.parametrize("bpl", [2, 4])
+def test_blocks_per_lane_thinned_store_and_second_run(bpl):
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    d, n, nburn, nsamp, stride = 16, 2048, 60, 45, 4
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=1.0, threads=8)
+    eo.set_record(samples=True, mask=False, stride=stride)
+    vg, k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eg = M.Engine(d, n, pl=1.0)
+    for o, v in ((E.OPT_BLOCKS_PER_LANE, bpl), (E.OPT_PERSIST, 0), (E.OPT_SPLIT_RNG, 0), (E.OPT_SAMPLE_STRIDE, stride)):
+        eg.set_option(o, v)
+    for rep in range(2):
+        eo.run(nsamp, nburn, p, vo)
+        eg.run(nsamp, nburn, p, vg)
+        kept = (nsamp + stride - 1) // stride
+        assert same_bits(eg.samples, eo.samples[-kept * n:]), rep
+        for name in ("state", "mean", "var"):
+            assert same_bits(getattr(eg, name), getattr(eo, name)), (rep, name)
+
+
+@pytest.mark.parametrize("bpl", [2, 4])
+def test_blocks_per_lane_multishard_snapshot(bpl):
+    """two shards on one GPU, lazy schedule: fused segments span sync points and the kernel snapshots the slot"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    from test_gpu_configs import run_sharded_async
+    d, n, nshards, nburn, nsamp, pl = 16, 2048, 2, 100, 55, 0.93
+    vo, keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl, threads=8) for s in range(nshards)]
+    O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+
+    def setup(s, e):
+        e.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
+        e.set_option(E.OPT_PERSIST, 0)
+        e.set_option(E.OPT_SPLIT_RNG, 0)
+    egs, nbegin = run_sharded_async(d, n, nshards, nburn, nsamp, pl, 0, setup=setup)
+    for s in range(nshards):
+        assert egs[s].counters["remote_passes"] == eos[s].remote_passes
+        for name in ("state", "mean", "var", "samples", "musigall"):
+            assert same_bits(getattr(egs[s], name), getattr(eos[s], name)), (s, name)

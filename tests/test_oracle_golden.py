@@ -57,6 +57,27 @@ def test_known_answers():
     np.testing.assert_allclose(y, [np.log(5 + np.exp(-25.0)), np.log(5 * np.exp(-25.0) + 1)], rtol=1e-6, atol=1e-7)
 
 
+def test_rosenbrock2_fixed_known_answers_float64_and_pinned_values(golden_dir):
+    """MCX_VL_ROSENBROCK2_FIXED is NOT reference behaviour (the reference's Rosenbrock2 has the sign error and the
+    boundary crossing of src/rosenbrock.cc:32-38): the flagged well-posed variant, pinned by its closed form."""
+    for d in (2, 5, 16):
+        assert O.vl_eval(O.VL_ROSENBROCK2_FIXED, d, np.ones((1, d)))[0] == 0.0
+        assert O.vl_eval(O.VL_ROSENBROCK2_FIXED, d, np.zeros((1, d)))[0] == -(d - 1)
+    rng = np.random.default_rng(8)
+    for d in (2, 3, 9, 16, 40):
+        x = rng.normal(0, 1.2, (50, d)).astype(np.float32)
+        x64 = x.astype(np.float64)
+        ref = -(((1 - x64[:, :-1]) ** 2) + 100 * (x64[:, 1:] - x64[:, :-1] ** 2) ** 2).sum(1)
+        np.testing.assert_allclose(O.vl_eval(O.VL_ROSENBROCK2_FIXED, d, x), ref, rtol=3e-6)
+    # two sets side by side: nothing leaks across the set boundary (the reference's Rosenbrock2 does)
+    x = rng.normal(0, 1, (2, 6)).astype(np.float32)
+    both = O.vl_eval(O.VL_ROSENBROCK2_FIXED, 6, x)
+    assert both[0] == O.vl_eval(O.VL_ROSENBROCK2_FIXED, 6, x[:1])[0]
+    for c in load(golden_dir, "oracle_runs.json")["vlfunc_cases"]:
+        xx = np.array(c["x"], np.float32).reshape(c["npset"], c["d"])
+        assert np.array_equal(O.vl_eval(O.VL_ROSENBROCK2_FIXED, c["d"], xx), np.array(c["y"], np.float32))
+
+
 def test_empty_batch():
     assert O.vl_eval(O.VL_ROSENBROCK1, 4, np.zeros((0, 4))).shape == (0,)
 
