@@ -515,9 +515,11 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t owner, int 
 //
 // FULL: proposals x' = x + T z with the full lower-triangular Cholesky factor (src/mcpar.cc:302-312 with
 // covar_setup's factor, :454-484).  A lane needs its four rows of T and the whole z of its chain:
-//   * T is staged in LDS as [row in block k][column block qq][lane of the chain q][4 columns]: for a given
-//     (k, qq) the lanes of a wavefront read LPC consecutive 16-byte slots -- every ds_read_b128 lane group
-//     sees each slot's address on all its readers (broadcast) and no bank twice;
+//   * T is staged in LDS as [column block qq][column c][lane of the chain q][rows 0, 2, 1, 3 of the lane]: for a given
+//     column the lanes of a wavefront read LPC consecutive 16-byte slots -- every ds_read_b128 lane group sees each
+//     slot's address on all its readers (broadcast) and no bank twice -- and one read is the pair of packed operands
+//     (rows 0, 2 | rows 1, 3) of the two v_pk_fma_f32 that column costs (round 2 read rows and issued scalar
+//     multiply-adds plus the moves that packed them: 741 -> ~600 instructions per wavefront-step at 32-D);
 //   * z travels by DPP quad permutes for chains of <= 4 lanes (no memory: 4 moves per column block, the multiply-adds
 //     packed by the compiler; feeding z as the DPP operand of v_fmac_f32 through inline asm measured the same); chains of 8 lanes write
 //     their z block to LDS (9 slots per chain, so the four chains of a ds_read_b128 lane group sit on
@@ -554,9 +556,11 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
   __shared__ __attribute__((aligned(16))) float4 lds_z[FULL && LPC == 8 ? (BLOCK / 8) * 9 : 1];
   if (FULL) {
     const int dd = a.d;
+    // slot [(qq * 4 + c) * LPC + qv] = column 4 qq + c of the four rows of lane qv, as (row 0, row 2, row 1, row 3):
+    // the two halves are the packed operands of the lane's (x0, x2) / (x1, x3) accumulators
     for (int i = threadIdx.x; i < 16 * LPC * LPC; i += BLOCK) {
-      const int c = i & 3, qv = (i >> 2) % LPC, qq = ((i >> 2) / LPC) % LPC, k = (i >> 2) / (LPC * LPC);
-      const int row = 4 * qv + k, col = 4 * qq + c;
+      const int h = i & 3, qv = (i >> 2) % LPC, c = ((i >> 2) / LPC) & 3, qq = (i >> 2) / (4 * LPC);
+      const int row = 4 * qv + (h == 0 ? 0 : (h == 1 ? 2 : (h == 2 ? 1 : 3))), col = 4 * qq + c;
       reinterpret_cast<float *>(lds_T)[i] = (row < dd && col < dd) ? a.T[row * dd + col] : 0.0f;
     }
     if (LIK != LIK_MIX) __syncthreads();
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
       pe = fma2(te, ze, xe);  // src/mcpar.cc:302-312
       po = fma2(to, zo, xo);
     } else {
-      float p[4] = {xe.x, xo.x, xe.y, xo.y};
+      f32x2 ae = xe, ao = xo;  // rows (0, 2) and (1, 3): every row accumulates its columns in ascending order
       const float zv[4] = {ze.x, zo.x, ze.y, zo.y};
       const int zslot = ((int)threadIdx.x >> 3) * 9;
       if (LPC == 8) {
@@ -629,18 +633,17 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
         if (LPC == 8) zz = lds_z[zslot + qq];
         else if (LPC == 1) zz = make_float4(zv[0], zv[1], zv[2], zv[3]);
         else zz = make_float4(quad_bcast<LPC>(zv[0], qq), quad_bcast<LPC>(zv[1], qq), quad_bcast<LPC>(zv[2], qq), quad_bcast<LPC>(zv[3], qq));
+        const float zc[4] = {zz.x, zz.y, zz.z, zz.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 tr = lds_T[(k * LPC + qq) * LPC + q];
-          p[k] = __builtin_fmaf(tr.x, zz.x, p[k]);
-          p[k] = __builtin_fmaf(tr.y, zz.y, p[k]);
-          p[k] = __builtin_fmaf(tr.z, zz.z, p[k]);
-          p[k] = __builtin_fmaf(tr.w, zz.w, p[k]);
+        for (int c = 0; c < 4; ++c) {  // one read = column 4 qq + c of the lane's four rows: two packed multiply-adds
+          const float4 tr = lds_T[(qq * 4 + c) * LPC + q];
+          ae = fma2(f32x2{tr.x, tr.y}, splat2(zc[c]), ae);
+          ao = fma2(f32x2{tr.z, tr.w}, splat2(zc[c]), ao);
         }
       }
       if (LPC == 8) __builtin_amdgcn_wave_barrier();  // this step's reads precede the next step's write
-      pe = f32x2{p[0], p[2]};
-      po = f32x2{p[1], p[3]};
+      pe = ae;
+      po = ao;
     }
     float acc = 0.0f;
     if (LIK == LIK_ROSEN1) {

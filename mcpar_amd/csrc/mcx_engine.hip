@@ -835,6 +835,19 @@ static int launch_accept(mcx_engine *e, const StepArgs &a, bool main)
   return MCX_OK;
 }
 
+// the all-pairs sweep over chains whose np is a power of two (d == DMAX): one or two chains per lane (SWEEP_CPL).
+// Workgroups of 512 / 1024 threads (fewer copies of a block's Gaussians staged through LDS) were measured on the
+// two-chain kernels: C3 R-murray 39.2 ms with 256 threads, 40.0 with 512, 49.4 with 1024; the 32-D mixture 43.4 / 42.7
+// / 42.7 -- the staging is not what a sweep waits for.
+template <int DM, bool SUMS>
+static void launch_sweep_exact(const float *x, const int *list, int cnt, const float *qpar, float *psum, float *pmax,
+                               int N, int own0, const unsigned long long *excl, int ngroups, int S, hipStream_t st)
+{
+  constexpr int CPL = SWEEP_CPL(DM);
+  hipLaunchKernelGGL((k_remote_sweep<DM, SUMS, true, CPL>), dim3(nblocks(((size_t)cnt + CPL - 1) / CPL), S), dim3(BLOCK), 0, st, x,
+                     list, cnt, qpar, psum, pmax, DM, N, own0, excl, ngroups);
+}
+
 // Sort the active chains by their spatial key, box every group of CULL_W of them and test every (group, Q_i)
 // pair (mcx_remote.hpp, "Exact exclusion of far Gaussians").  Leaves the sorted list in e->cull_sorted and the
 // masks in e->cull_excl ([group][words]); the pairs kept are added to the device counter behind e->nact.
@@ -928,9 +941,8 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     {
       ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)n * (uint64_t)N);
       if (d == dm) {
-        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, true, SWEEP_CPL(DMAX_)>), dim3(nblocks(((size_t)n + SWEEP_CPL(DMAX_) - 1) / SWEEP_CPL(DMAX_)), S), dim3(BLOCK),
-                                             0, st, pvals, order, n, e->winvall.p,
-                                             (float *)nullptr, e->pmax.p, d, N, own0, excl, (n + CULL_W - 1) / CULL_W));
+        DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, false>(pvals, order, n, e->winvall.p, (float *)nullptr, e->pmax.p,
+                                                           N, own0, excl, (n + CULL_W - 1) / CULL_W, S, st)));
       } else {
         DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
                                              0, st, pvals, (const int *)nullptr, n, e->winvall.p,
@@ -973,9 +985,8 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
       {
       ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)nact * (uint64_t)N);
       if (d == dm) {
-        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, true, SWEEP_CPL(DMAX_)>), dim3(nblocks(((size_t)nact + SWEEP_CPL(DMAX_) - 1) / SWEEP_CPL(DMAX_)), S), dim3(BLOCK),
-                                             0, st, ptrial, list, nact, e->winvall.p,
-                                             e->psum.p, e->pmax.p, d, N, -1, excl, (nact + CULL_W - 1) / CULL_W));
+        DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, true>(ptrial, list, nact, e->winvall.p, e->psum.p, e->pmax.p, N,
+                                                          -1, excl, (nact + CULL_W - 1) / CULL_W, S, st)));
       } else {
         DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, false>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
                                              0, st, ptrial, (const int *)ain, nact, e->winvall.p,

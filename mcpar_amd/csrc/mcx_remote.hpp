@@ -91,6 +91,9 @@ __device__ __forceinline__ void sweep_rows(const float *rows, int nrow, const fl
 // selected by op_sel: component-wise the same operations in the same order, hence the same bits).  d == DMAX only.
 // `todo` names the rows of the stage to sweep, one bit per row (wave-uniform): the rows the wavefront's exclusion
 // test (k_cull_test) could not rule out, or all of them.
+// (Testing for the early out once per Q_i instead of after every group of dimensions, for the regime where the
+// exclusion masks exclude nothing -- the 32-D mixture -- was measured slower, 47.0 against 43.3 ms per job: the
+// tests after the second and third group do fire there.)
 template <int DMAX, typename Bound, typename Use>
 __device__ __forceinline__ void sweep_rows2(const float *rows, unsigned long long todo, const f32x2 x[DMAX], bool valid_a,
                                             bool valid_b, Bound bound, Use use)
@@ -202,8 +205,10 @@ __global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
 // farther than the wavefront's bound from the bounding box of its 128 chains, i.e. from every one of them: its
 // term is exactly +0 in every chain's sum (SUMS) or cannot lower any chain's minimum (!SUMS), so skipping it
 // leaves every result bit as it was.  null = sweep everything.
-template <int DMAX, bool SUMS, bool EXACT, int CPL = 1>
-__global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict__ xrows,
+// NT = threads of the workgroup (every workgroup stages all of its block's Gaussians through LDS whichever rows its
+// wavefronts then skip; larger workgroups = fewer copies were measured and are not faster: mcx_engine.hip).
+template <int DMAX, bool SUMS, bool EXACT, int CPL = 1, int NT = BLOCK>
+__global__ __launch_bounds__(NT) void k_remote_sweep(const float *__restrict__ xrows,
                                                         const int *__restrict__ active, int nact,
                                                         const float *__restrict__ qpar,
                                                         float *__restrict__ psum,
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
   constexpr int QSUB = DMAX >= 8 ? (2048 / CPL) / DMAX : QBLOCK;
   static_assert(CPL == 1 || QSUB <= 64, "a stage's rows are named by one 64-bit mask");
   __shared__ __attribute__((aligned(16))) float qlds[QSUB * 2 * DMAX];
-  // one chain per lane: chain = position blockIdx.x * BLOCK + threadIdx.x of the (active) list; two: the wavefront
+  // one chain per lane: chain = position blockIdx.x * NT + threadIdx.x of the (active) list; two: the wavefront
   // holds CULL_W = 128 CONSECUTIVE positions (lane l: its first 64 + l and its second 64 + l) -- neighbours in the
   // sorted list the exclusion test was made for.  Every lane stays for the staging and its barriers.
   int pos[CPL], jj[CPL];
@@ -223,14 +228,14 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
-    pos[c] = CPL == 1 ? (int)(blockIdx.x * BLOCK + threadIdx.x)
-                      : (int)blockIdx.x * (CPL * BLOCK) + wv * (CPL * 64) + c * 64 + (int)(threadIdx.x & 63u);
+    pos[c] = CPL == 1 ? (int)(blockIdx.x * NT + threadIdx.x)
+                      : (int)blockIdx.x * (CPL * NT) + wv * (CPL * 64) + c * 64 + (int)(threadIdx.x & 63u);
     valid[c] = pos[c] < nact;
     jj[c] = valid[c] ? (active ? active[pos[c]] : pos[c]) : 0;
   }
   const unsigned long long *exw = nullptr;  // this wavefront's mask words: [word][group], excl_words = groups
   if constexpr (CPL == 2)
-    if (excl) exw = excl + (size_t)((int)blockIdx.x * (BLOCK / 64) + wv);
+    if (excl) exw = excl + (size_t)((int)blockIdx.x * (NT / 64) + wv);
   const int sb = blockIdx.y;
   const int DD = EXACT ? DMAX : d;
   float x[CPL == 1 ? DMAX : 1];
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
   const bool wave_idle = !__any(valid[0]);
   // d == DMAX: a stage is one contiguous piece of qpar, PER float4 per thread, fetched into registers while the
   // previous stage is being swept and written to LDS between two barriers
-  constexpr int PER = (QSUB * (DMAX / 2) + BLOCK - 1) / BLOCK;
+  constexpr int PER = (QSUB * (DMAX / 2) + NT - 1) / NT;
   typedef float v4 __attribute__((ext_vector_type(4)));
   v4 hold[PER];
   if (EXACT) {
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
     const v4 *src = reinterpret_cast<const v4 *>(qpar + 2 * (size_t)q0 * DMAX);
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int t = (int)threadIdx.x + u * BLOCK;
+      const int t = (int)threadIdx.x + u * NT;
       hold[u] = src[t < n4 ? t : n4 - 1];  // (unconditional: the PER loads go out back to back)
     }
   }
@@ -302,12 +307,12 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
       v4 *dst = reinterpret_cast<v4 *>(qlds);
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const int t = (int)threadIdx.x + u * BLOCK;
+        const int t = (int)threadIdx.x + u * NT;
         if (t < nrow * (DMAX / 2)) dst[t] = hold[u];
       }
     } else {
       const float *src = qpar + 2 * (size_t)c0 * DD;
-      for (int t = threadIdx.x; t < nrow * 2 * DMAX; t += BLOCK) {
+      for (int t = threadIdx.x; t < nrow * 2 * DMAX; t += NT) {
         const int r = t / (2 * DMAX), k = t % (2 * DMAX);
         qlds[t] = k < 2 * DD ? src[(size_t)r * 2 * DD + k] : 0.0f;
       }
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
       const v4 *src = reinterpret_cast<const v4 *>(qpar + 2 * (size_t)cn * DMAX);
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const int t = (int)threadIdx.x + u * BLOCK;
+        const int t = (int)threadIdx.x + u * NT;
         hold[u] = src[t < n4 ? t : n4 - 1];
       }
     }
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
           m.x = gv > m.x ? gv : m.x;
         });
       } else {
-        sweep_rows<DMAX, EXACT>(qlds, nrow, x, DD, valid[0], [&] { return amin.x; },
+        sweep_rows<DMAX, EXACT>(qlds, nrow, x, DD, valid[0], [&] { return amin.x < ZERO_ARG ? amin.x : ZERO_ARG; },
                                 [&](float av) { amin.x = av < amin.x ? av : amin.x; });
       }
     } else {
@@ -353,7 +358,9 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep(const float *__restrict_
           m.y = gv.y > m.y ? gv.y : m.y;
         });
       } else {
-        sweep_rows2<DMAX>(qlds, todo, xx, valid[0], valid[CPL - 1], [&] { return amin; }, [&](f32x2 av) {
+        // (an arg beyond ZERO_ARG cannot matter: k_remote_cmax_combine's exp1(-min / 2) is exactly 0 from there on)
+        sweep_rows2<DMAX>(qlds, todo, xx, valid[0], valid[CPL - 1],
+                          [&] { return f32x2{amin.x < ZERO_ARG ? amin.x : ZERO_ARG, amin.y < ZERO_ARG ? amin.y : ZERO_ARG}; }, [&](f32x2 av) {
           amin.x = av.x < amin.x ? av.x : amin.x;
           amin.y = av.y < amin.y ? av.y : amin.y;
         });
@@ -603,7 +610,9 @@ __global__ __launch_bounds__(BLOCK) void k_cull_boxes(const float *__restrict__ 
       box[(size_t)g * 2 * CULL_KD + 2 * c] = lo[c];
       box[(size_t)g * 2 * CULL_KD + 2 * c + 1] = hi[c];
     }
-    lim[g] = SUMS ? ZERO_ARG : worst;
+    // min-arg sweep: beyond ZERO_ARG an arg cannot matter either -- exp1(-arg / 2) is exactly 0 there, whatever
+    // the minimum turns out to be (if every arg of a chain is beyond it, its cfac numerator is 0 both ways)
+    lim[g] = SUMS ? ZERO_ARG : (worst < ZERO_ARG ? worst : ZERO_ARG);
   }
 }
 
