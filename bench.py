@@ -834,15 +834,17 @@ def fm_unavoidable(d, n, chain_steps_per_launch, emit):
 
 def fallback_from_profiles(roofline, why, config_name="c3"):
     """counters not collected in this run: use the committed summaries of the same command, and say so"""
-    try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r02_%s_fused_kernel_counters.json" % config_name)))
+    try:  # the latest round's committed summary
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_fused_kernel_counters.json" % config_name)))
+        sq = json.load(open(cands[-1]))
+        rel = os.path.relpath(cands[-1], ROOT)
     except Exception:  # noqa: BLE001
         roofline.setdefault("traffic", None)
         roofline.setdefault("frac", None)
         roofline["counters_note"] = "no live PMC (%s) and no committed summary" % why
         return
     t_launch = roofline["avg_launch_ms"] * 1e-3
-    src = "profiles/r02_%s_fused_kernel_counters.json (committed rocprofv3 --pmc passes of this command; live collection: %s)" % (config_name, why)
+    src = "%s (committed rocprofv3 --pmc passes of this command; live collection: %s)" % (rel, why)
     if "traffic" not in roofline and sq.get("traffic_bytes_per_launch"):
         tr = sq["traffic_bytes_per_launch"]
         roofline["traffic"] = tr

@@ -26,7 +26,7 @@ rnd = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(pr, exist_ok=True)
-KT_DIR = {"c3": "c3", "c2": "c2", "c5": "c5", "c3-murray": "c3m"}
+KT_DIR = {"c3": "c3", "c2": "c2", "c5": "c5", "c3-murray": "c3m", "c3-rosen2fixed": "c3r2f"}
 
 
 def lpc_for(d):
@@ -36,7 +36,7 @@ def lpc_for(d):
     return l
 
 
-for cfg in ("c3", "c2", "c5", "c3-murray"):
+for cfg in ("c3", "c2", "c5", "c3-murray", "c3-rosen2fixed"):
     bj = os.path.join(go, "%s_bench_%s.json" % (rnd, cfg))
     line = None
     if os.path.exists(bj):
