@@ -757,6 +757,16 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
     }
   };
 
+  // Every load of the chain state is awaited here, once: the compiler's s_waitcnt bookkeeping is path-insensitive, so
+  // a wait left to the first use inside the step loop stays there for every later step -- where the only vector-memory
+  // operations in flight are the previous step's sample STORES, and "vmcnt(0)" means "until they have reached HBM".
+  asm volatile("" ::"v"(xe), "v"(xo), "v"(te), "v"(to), "v"(me), "v"(mo), "v"(se), "v"(so), "v"(gme), "v"(gmo), "v"(gs0),
+               "v"(gs1), "v"(gs2), "v"(gs3), "v"(ly));
+  // 1/pwgt of the launch's steps: read through the CONSTANT address space, i.e. by scalar loads.  As a plain global
+  // load (what the compiler made of the uniform address) it sat in the vector-memory queue behind the previous
+  // step's sample stores, and the wait for it was a wait for those stores to reach HBM: 21 % of the wavefronts'
+  // cycles parked in s_waitcnt (SQ_WAIT_ANY) on the headline job.
+  const __attribute__((address_space(4))) float *wtab = (const __attribute__((address_space(4))) float *)a.winv;
   if (!PREGEN) {
     for (int s = 0; s < a.nsteps; ++s) {
       const uint32_t t = a.t0 + (uint32_t)s;
@@ -774,7 +784,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
       const uint32_t wi = t & 3u;
       const float mine = wi == 0u ? al01.x : (wi == 1u ? al01.y : (wi == 2u ? al23.x : al23.y));
       const float lu = as_f32(group_bcast<LPC>(as_u32(mine), blk & (uint32_t)(LPC - 1), q));
-      step(s, ze, zo, lu, MAIN ? a.winv[a.isamp0 + s] : 1.0f);
+      step(s, ze, zo, lu, MAIN ? wtab[a.isamp0 + s] : 1.0f);
     }
   } else {
     // Batches of P steps, double buffered: at the top of a batch every load of it (issued one whole

@@ -844,6 +844,13 @@ static void launch_sweep_exact(const float *x, const int *list, int cnt, const f
                                int N, int own0, const unsigned long long *excl, int ngroups, int S, hipStream_t st)
 {
   constexpr int CPL = SWEEP_CPL(DM);
+  if constexpr (DM == 16) {
+    if (excl) {  // masked: every wavefront reads its own surviving rows through the scalar cache (no LDS, no barriers)
+      hipLaunchKernelGGL((k_remote_sweep_srow16<SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), S), dim3(BLOCK), 0, st,
+                         x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups);
+      return;
+    }
+  }
   hipLaunchKernelGGL((k_remote_sweep<DM, SUMS, true, CPL>), dim3(nblocks(((size_t)cnt + CPL - 1) / CPL), S), dim3(BLOCK), 0, st, x,
                      list, cnt, qpar, psum, pmax, DM, N, own0, excl, ngroups);
 }

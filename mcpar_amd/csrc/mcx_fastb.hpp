@@ -80,6 +80,14 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fastb(const SegArgs a)
     return group_sum<LPC2>((p[0] + p[1]) + (p[BPL == 4 ? 2 : 0] + p[BPL == 4 ? 3 : 1]));
   };
 
+  // every load of the chain state is awaited here, once (see k_fused_fast): no vmcnt wait may end up in the step loop
+#pragma unroll
+  for (int b = 0; b < BPL; ++b)
+    asm volatile("" ::"v"(xe[b]), "v"(xo[b]), "v"(te[b]), "v"(to[b]), "v"(me[b]), "v"(mo[b]), "v"(se[b]), "v"(so[b]),
+                 "v"(gme[b]), "v"(gmo[b]), "v"(gs[b][0]), "v"(gs[b][1]), "v"(gs[b][2]), "v"(gs[b][3]));
+  asm volatile("" ::"v"(ly));
+  // 1/pwgt by scalar loads (constant address space): a plain global load would queue behind the sample stores
+  const __attribute__((address_space(4))) float *wtab = (const __attribute__((address_space(4))) float *)a.winv;
   for (int s = 0; s < a.nsteps; ++s) {
     const uint32_t t = a.t0 + (uint32_t)s;
     f32x2 pe[BPL], po[BPL];
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fastb(const SegArgs a)
     cnt += take ? 1u : 0u;
     wacc += (uint32_t)__popcll(__ballot(take && q2 == 0));
     if (MAIN) {
-      const f32x2 w2 = splat2(a.winv[a.isamp0 + s]);  // src/mcpar.cc:186-187
+      const f32x2 w2 = splat2(wtab[a.isamp0 + s]);  // src/mcpar.cc:186-187
 #pragma unroll
       for (int b = 0; b < BPL; ++b) {
         const f32x2 de = xe[b] - me[b], dO = xo[b] - mo[b];  // src/mcpar.cc:199-202

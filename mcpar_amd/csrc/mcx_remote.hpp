@@ -149,6 +149,10 @@ __device__ __forceinline__ void sweep_rows2(const float *rows, unsigned long lon
 constexpr float ZERO_ARG = 176.0f;
 
 constexpr int QBLOCK = 256;  // block length of the qisum summation order
+// exact exclusion of far Gaussians (further down): chains per group = the chains of one wavefront of the two-chain sweeps,
+// key dimensions and bits per key dimension of the spatial sort
+constexpr int CULL_W = 128, CULL_KD = 4, CULL_BITS = 3, CULL_BINS = 1 << (CULL_KD * CULL_BITS);
+constexpr int CULL_NCOUNT = 64;  // cells of a "pairs kept" counter (the host adds them up): same-address atomics are slow
 
 struct RemoteArgs {
   const int *active_in;  // compacted list of still-rejected chains (null = all chains, pass 0)
@@ -380,6 +384,165 @@ __global__ __launch_bounds__(NT) void k_remote_sweep(const float *__restrict__ x
     }
 }
 
+// The masked sweep at 16-D without LDS: when the exclusion masks leave a wavefront a third of its block's Gaussians,
+// staging all 256 of them through LDS behind two workgroup barriers per 64 rows is what the wavefronts wait for (VALU
+// issue 0.39 / 0.58 of the slots, min-arg / sum sweep).  Here every wavefront walks its OWN surviving rows and reads
+// each straight from L2 through the scalar cache: the row index comes from the mask (wave-uniform), so the 32 numbers
+// of a row arrive in SGPRs, and with arithmetic v3 every packed operation needs at most one scalar operand
+// (xm = mu - x; q = xm xm; arg = fma(q, w, arg)) -- no v_mov, no barrier, no row fetched that nobody wants.
+// One wavefront = one group of 128 consecutive chains x one block of QBLOCK Gaussians; same operations in the same
+// order as sweep_rows2, same early outs, hence the same bits.
+template <bool SUMS>
+__global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow16(const float *__restrict__ xrows, const int *__restrict__ active,
+                                                               int nact, const float *__restrict__ qpar,
+                                                               float *__restrict__ psum, float *__restrict__ pmax, int N,
+                                                               int own0, const unsigned long long *__restrict__ excl,
+                                                               int ngroups)
+{
+  constexpr int DMAX = 16, G = 4;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
+  const int g = (int)blockIdx.x * (BLOCK / 64) + wv;
+  if (g >= ngroups) return;  // (no barriers in this kernel)
+  const int sb = blockIdx.y;
+  int pos[2], jj[2];
+  bool valid[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    pos[c] = g * CULL_W + c * 64 + lane;
+    valid[c] = pos[c] < nact;
+    jj[c] = valid[c] ? (active ? active[pos[c]] : pos[c]) : 0;
+  }
+  f32x2 xx[DMAX];
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) xx[k] = f32x2{0.0f, 0.0f};
+  if (valid[0]) {
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) xx[k].x = xrows[(size_t)jj[0] * DMAX + k];
+  }
+  if (valid[1]) {
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) xx[k].y = xrows[(size_t)jj[1] * DMAX + k];
+  }
+  f32x2 part = {0.0f, 0.0f}, m = {0.0f, 0.0f};
+  f32x2 amin = {__builtin_inff(), __builtin_inff()};
+  if (!SUMS && own0 >= 0) {  // (see k_remote_sweep)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (valid[c]) {
+        const float *qo = qpar + 2 * (size_t)(own0 + jj[c]) * DMAX;
+        float a0 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+          const float xm = qo[2 * k] - (c == 0 ? xx[k].x : xx[k].y);
+          a0 = __builtin_fmaf(xm * xm, qo[2 * k + 1], a0);
+        }
+        const float old = c == 0 ? amin.x : amin.y;
+        const float now = a0 < old ? a0 : old;
+        if (c == 0) amin.x = now;
+        else amin.y = now;
+      }
+  }
+  const unsigned long long everyone = __ballot(true), no_a = __ballot(!valid[0]), no_b = __ballot(!valid[1]);
+  const int q0 = sb * QBLOCK;
+  // the block's four mask words (bits beyond N are clear: k_cull_test), as scalars
+  unsigned long long words[QBLOCK / 64];
+#pragma unroll
+  for (int wd = 0; wd < QBLOCK / 64; ++wd) {
+    unsigned long long w = 0;
+    if (q0 + 64 * wd < N) w = excl[(size_t)((q0 >> 6) + wd) * (size_t)ngroups + g];
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)w), hi = __builtin_amdgcn_readfirstlane((unsigned)(w >> 32));
+    words[wd] = ((unsigned long long)hi << 32) | lo;
+  }
+  int wd = 0;
+  unsigned long long todo = words[0];
+  // next surviving row of the block (index within the block), or -1
+  auto next_row = [&]() -> int {
+#pragma unroll
+    for (int u = 1; u < QBLOCK / 64; ++u)
+      if (!todo && wd + 1 < QBLOCK / 64) { ++wd; todo = wd == 1 ? words[1] : (wd == 2 ? words[2] : words[3]); }
+    if (!todo) return -1;
+    const int r = 64 * wd + __builtin_ctzll(todo);
+    todo &= todo - 1;
+    return r;
+  };
+  // one row = 32 floats read through the CONSTANT address space at a wave-uniform address: scalar loads
+  // (s_load_dwordx4 .. x16 into SGPRs), waited for by the compiler's own s_waitcnt
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  struct Row { v4 v[DMAX / 2]; };
+  auto fetch = [&](int r, Row &row) {
+    const __attribute__((address_space(4))) v4 *rp =
+        (const __attribute__((address_space(4))) v4 *)(qpar + 2 * (size_t)(q0 + r) * DMAX);
+#pragma unroll
+    for (int k = 0; k < DMAX / 2; ++k) row.v[k] = rp[k];
+  };
+  auto sweep_one = [&](const Row &row) {
+    auto two_dims = [&](v4 v, int k, f32x2 arg) {  // (mu_k, w_k, mu_k+1, w_k+1)
+      const f32x2 xm0 = splat2(v.x) - xx[k];
+      arg = fma2(xm0 * xm0, splat2(v.y), arg);
+      const f32x2 xm1 = splat2(v.z) - xx[k + 1];
+      arg = fma2(xm1 * xm1, splat2(v.w), arg);
+      return arg;
+    };
+    const f32x2 b = SUMS ? splat2(ZERO_ARG)
+                         : f32x2{amin.x < ZERO_ARG ? amin.x : ZERO_ARG, amin.y < ZERO_ARG ? amin.y : ZERO_ARG};
+    f32x2 arg = {0.0f, 0.0f};
+    bool live = true;
+#pragma unroll
+    for (int c = 0; c < DMAX; c += G) {
+#pragma unroll
+      for (int k = 0; k < G / 2; ++k) arg = two_dims(row.v[c / 2 + k], c + 2 * k, arg);
+      if (((__ballot(arg.x > b.x) | no_a) & (__ballot(arg.y > b.y) | no_b)) == everyone) {
+        live = false;
+        break;
+      }
+    }
+    if (live) {
+      if (SUMS) {
+        const f32x2 gv = expf_v2x2(splat2(-0.5f) * arg);
+        part = part + gv;
+        m.x = gv.x > m.x ? gv.x : m.x;
+        m.y = gv.y > m.y ? gv.y : m.y;
+      } else {
+        amin.x = arg.x < amin.x ? arg.x : amin.x;
+        amin.y = arg.y < amin.y ? arg.y : amin.y;
+      }
+    }
+  };
+  // Two row buffers in turn: the next surviving row is requested before this one is swept.  Scalar loads return
+  // out of order, so the only wait there is is "all of them": the wait for THIS row must come before the request
+  // for the next one, or it would wait for that too -- `landed` is a use of the row's first and last number that the
+  // compiler has to satisfy at that point.
+  auto landed = [&](const Row &row) { asm volatile("" ::"s"(row.v[0].x), "s"(row.v[DMAX / 2 - 1].w)); };
+  Row ra, rb;
+  int r = next_row();
+  if (r >= 0) {
+    fetch(r, ra);
+    for (;;) {
+      landed(ra);
+      r = next_row();
+      if (r >= 0) fetch(r, rb);
+      sweep_one(ra);
+      if (r < 0) break;
+      landed(rb);
+      r = next_row();
+      if (r >= 0) fetch(r, ra);
+      sweep_one(rb);
+      if (r < 0) break;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    if (valid[c]) {
+      const size_t o = (size_t)sb * nact + pos[c];
+      if (SUMS) {
+        psum[o] = c == 0 ? part.x : part.y;
+        pmax[o] = c == 0 ? m.x : m.y;
+      } else {
+        pmax[o] = c == 0 ? amin.x : amin.y;
+      }
+    }
+}
+
 // numerator of cfac: max_i Q_i(pvals_j) = exp(-min_i arg_i / 2) (src/mcpar.cc:421-437); does not depend on the pass
 // (position i of the list the sweep ran over holds chain order[i]; null = identity)
 static __global__ void k_remote_cmax_combine(const float *__restrict__ pmin, float *__restrict__ cmax, int n, int S,
@@ -446,8 +609,6 @@ static __global__ void k_remote_decide(const RemoteArgs a)
 //   4. the sweep skips the excluded rows.  Results do not depend on the order of the chains or on what was skipped:
 //      the bit-exact tests against the oracle (which knows nothing of this) are the proof.
 // ---------------------------------------------------------------------------------------------
-constexpr int CULL_W = 128, CULL_KD = 4, CULL_BITS = 3, CULL_BINS = 1 << (CULL_KD * CULL_BITS);
-constexpr int CULL_NCOUNT = 64;  // cells of a "pairs kept" counter (the host adds them up): same-address atomics are slow
 
 __device__ __forceinline__ int cull_keydim(int c, int d) { return d >= CULL_KD ? c * (d / CULL_KD) : (c < d ? c : d - 1); }
 
