@@ -835,6 +835,8 @@ static int launch_accept(mcx_engine *e, const StepArgs &a, bool main)
   return MCX_OK;
 }
 
+constexpr int SROW_UNMASKED_MAX_CHAINS = 8192;  // see launch_sweep_exact
+
 // the all-pairs sweep over chains whose np is a power of two (d == DMAX): one or two chains per lane (SWEEP_CPL).
 // Workgroups of 512 / 1024 threads (fewer copies of a block's Gaussians staged through LDS) were measured on the
 // two-chain kernels: C3 R-murray 39.2 ms with 256 threads, 40.0 with 512, 49.4 with 1024; the 32-D mixture 43.4 / 42.7
@@ -845,7 +847,9 @@ static void launch_sweep_exact(const float *x, const int *list, int cnt, const f
 {
   constexpr int CPL = SWEEP_CPL(DM);
   if constexpr (DM == 16) {
-    if (excl) {  // masked: every wavefront reads its own surviving rows through the scalar cache (no LDS, no barriers)
+    // masked, or few chains: every wavefront reads its own rows through the scalar cache (no LDS, no barriers);
+    // unmasked over many chains the rows are better staged once per 512 chains (4.3 GB through L2 otherwise)
+    if (excl || cnt <= SROW_UNMASKED_MAX_CHAINS) {
       hipLaunchKernelGGL((k_remote_sweep_srow16<SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), S), dim3(BLOCK), 0, st,
                          x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups);
       return;

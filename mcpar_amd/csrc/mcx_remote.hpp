@@ -391,7 +391,9 @@ __global__ __launch_bounds__(NT) void k_remote_sweep(const float *__restrict__ x
 // of a row arrive in SGPRs, and with arithmetic v3 every packed operation needs at most one scalar operand
 // (xm = mu - x; q = xm xm; arg = fma(q, w, arg)) -- no v_mov, no barrier, no row fetched that nobody wants.
 // One wavefront = one group of 128 consecutive chains x one block of QBLOCK Gaussians; same operations in the same
-// order as sweep_rows2, same early outs, hence the same bits.
+// order as sweep_rows2, same early outs, hence the same bits.  excl == null sweeps every row: used for the late
+// rejection passes over a few thousand chains, where the LDS kernel's grid is too small to hide its barriers (VALU
+// issue 0.25) and the rows every wavefront then pulls through L2 are few.
 template <bool SUMS>
 __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow16(const float *__restrict__ xrows, const int *__restrict__ active,
                                                                int nact, const float *__restrict__ qpar,
@@ -449,7 +451,14 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow16(const float *__re
 #pragma unroll
   for (int wd = 0; wd < QBLOCK / 64; ++wd) {
     unsigned long long w = 0;
-    if (q0 + 64 * wd < N) w = excl[(size_t)((q0 >> 6) + wd) * (size_t)ngroups + g];
+    if (q0 + 64 * wd < N) {
+      if (excl) {
+        w = excl[(size_t)((q0 >> 6) + wd) * (size_t)ngroups + g];
+      } else {  // no masks: every Gaussian of the block that exists
+        const int left = N - (q0 + 64 * wd);
+        w = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+      }
+    }
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)w), hi = __builtin_amdgcn_readfirstlane((unsigned)(w >> 32));
     words[wd] = ((unsigned long long)hi << 32) | lo;
   }
