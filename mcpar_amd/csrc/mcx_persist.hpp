@@ -104,14 +104,20 @@ __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *wo
       const unsigned long long add = (1ull << 40) | (unsigned long long)s;
       unsigned long long v = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
       if ((int)((v & ~MEET_ABORT_BIT) >> 40) < nwg && !(v & MEET_ABORT_BIT)) {
-        // bounded wait: the constant-rate wall clock, read once per poll
-        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        // bounded wait: the constant-rate wall clock, looked at once per 64 polls (reading it is a scalar memory
+        // operation of its own: once per poll it stretched every meeting of a healthy run)
+        unsigned long long t_start = 0;
+        unsigned polls = 0;
         do {
           __builtin_amdgcn_s_sleep(4);
           v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((int)((v & ~MEET_ABORT_BIT) >> 40) >= nwg || (v & MEET_ABORT_BIT)) break;
-          if (__builtin_amdgcn_s_memrealtime() - t_start > timeout)  // someone never arrived: tell everybody
-            v = __hip_atomic_fetch_or(word, MEET_ABORT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | MEET_ABORT_BIT;
+          if ((++polls & 63u) == 0u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t_start == 0) t_start = now;
+            else if (now - t_start > timeout)  // someone never arrived: tell everybody
+              v = __hip_atomic_fetch_or(word, MEET_ABORT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | MEET_ABORT_BIT;
+          }
         } while (!(v & MEET_ABORT_BIT));
       }
       total = (v & MEET_ABORT_BIT) ? MEET_ABORTED : (v & ((1ull << 40) - 1ull));
@@ -353,8 +359,12 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   for (int p = 0; p < nphase + (REC ? 1 : 0); ++p) {
     const int buf = p & 1;
     // a tuner meeting was abandoned during the last phase: every wavefront of the workgroup reads the same flag
-    // (written before the barrier that ended that phase) and leaves here
-    if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { aborted = true; break; }
+    // (written before the barrier that ended that phase) and leaves here.  Meetings happen in burn-in steps only:
+    // phases that follow a phase without any need no look.
+    if (p > 0 && (p - 1) * K < a.nburn && __hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+      aborted = true;
+      break;
+    }
     if (owner) {
       if (working && p < nphase) {
         const int tau0 = p * K;
