@@ -768,8 +768,11 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
   // cycles parked in s_waitcnt (SQ_WAIT_ANY) on the headline job.
   const __attribute__((address_space(4))) float *wtab = (const __attribute__((address_space(4))) float *)a.winv;
   if (!PREGEN) {
+    float wnext = MAIN ? wtab[a.isamp0] : 1.0f;  // requested one step ahead (the table is padded past nsamp)
     for (int s = 0; s < a.nsteps; ++s) {
       const uint32_t t = a.t0 + (uint32_t)s;
+      const float wthis = wnext;
+      if (MAIN) wnext = wtab[a.isamp0 + s + 1];
       f32x2 ze, zo;
       normal4_packed(philox4x32_10(t, g, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
       // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
       const uint32_t wi = t & 3u;
       const float mine = wi == 0u ? al01.x : (wi == 1u ? al01.y : (wi == 2u ? al23.x : al23.y));
       const float lu = as_f32(group_bcast<LPC>(as_u32(mine), blk & (uint32_t)(LPC - 1), q));
-      step(s, ze, zo, lu, MAIN ? wtab[a.isamp0 + s] : 1.0f);
+      step(s, ze, zo, lu, wthis);
     }
   } else {
     // Batches of P steps, double buffered: at the top of a batch every load of it (issued one whole
