@@ -434,7 +434,9 @@ def main():
             err = ""
             try:
                 j.eng.rccl_init(uid)
-                j.eng.debug_exchange()
+                # one real gather with known contents: every slot must arrive, whole, at every rank
+                if not j.eng.exchange_self_check():
+                    err = "RCCL all-gather self-check failed: a slot did not arrive as sent"
             except Exception as ex:  # MCX_ERR_EXCHANGE with the RCCL error string
                 err = str(ex)
             flag = torch.tensor([1 if err else 0], dtype=torch.int32)

@@ -138,6 +138,9 @@ int mcx_exchange_rccl_destroy(mcx_engine *e); /* also done by mcx_destroy */
 int mcx_exchange_rccl_info(mcx_engine *e, int *nranks, int *rank);
 /* run the installed exchange hook once, now (BEGIN, WAIT, drain): start-up self-check / tests */
 int mcx_debug_exchange(mcx_engine *e);
+/* fill this shard's musigall slot with `value` (start-up self-check of an exchange: every shard fills its slot with
+ * its own number, mcx_debug_exchange, then mcx_get_musigall must show slot r full of shard r's number) */
+int mcx_debug_fill_slot(mcx_engine *e, float value);
 
 /* called where the reference dumps output (isamp % outstep == 0 && isamp > 0, and after the
  * last step: src/mcpar.cc:110-119,212) with the number of main-loop steps completed. */

@@ -1249,6 +1249,23 @@ extern "C" int mcx_debug_exchange(mcx_engine *e)
   return MCX_OK;
 }
 
+static __global__ void k_fill(float *p, size_t n, float v)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+extern "C" int mcx_debug_fill_slot(mcx_engine *e, float value)
+{
+  MCXCHK(enter(e));
+  MCXCHK(exchange_wait(e));  // (a gather in flight still reads the slot)
+  const size_t slot = 2 * (size_t)e->ntot;
+  hipLaunchKernelGGL(k_fill, dim3(nblocks(slot)), dim3(BLOCK), 0, e->stream, e->musigall.p + slot * (size_t)e->rank, slot, value);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MCX_OK;
+}
+
 extern "C" int mcx_device_count(int *n)
 {
   if (!n) return fail(MCX_ERR_INVALID, "n is NULL");

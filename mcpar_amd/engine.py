@@ -166,6 +166,14 @@ class Engine:
     def debug_exchange(self):
         check(load().mcx_debug_exchange(self.h))
 
+    def exchange_self_check(self):
+        """every shard fills its slot with shard + 1, one exchange, then slot r must be full of r + 1 on every
+        shard: True / False.  Collective over the shards (each calls it)."""
+        check(load().mcx_debug_fill_slot(self.h, float(self.shard + 1)))
+        self.debug_exchange()
+        ms = self.musigall.reshape(self.nshards, -1)
+        return bool(all(np.all(ms[r] == np.float32(r + 1)) for r in range(self.nshards)))
+
     def set_output_hook(self, pyfn):
         def tramp(ctx, steps_done):
             try:

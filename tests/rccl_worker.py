@@ -34,6 +34,8 @@ def main():
     eng = M.Engine(d, n, nshards=nshards, shard=rank, pl=pl)
     eng.rccl_init(uid)  # collective
     eng.debug_exchange()
+    assert eng.rccl_info() == (nshards, rank)
+    assert eng.exchange_self_check(), "rank %d: a slot did not arrive as sent" % rank
     eng.set_option(E.OPT_EAGER_EXCHANGE, eager)
     vl, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eng.run(nsamp, nburn, O.default_pinit(d, n, g0=rank * n), vl)

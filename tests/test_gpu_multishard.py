@@ -152,3 +152,45 @@ def test_c5_shape_mixture_four_shards():
         assert c["remote_passes"] == eos[s].remote_passes and c["naccept_main"] == eos[s].naccept_main
         for name in ("state", "mean", "var", "samples", "musigall"):
             assert np.array_equal(getattr(egs[s], name).view(np.uint32), getattr(eos[s], name).view(np.uint32)), name
+
+
+def test_exchange_self_check_sees_every_slot_and_a_broken_exchange():
+    """mcx_debug_fill_slot + mcx_debug_exchange + mcx_get_musigall: the start-up check bench.py (and any launcher) runs
+    on a freshly made exchange before trusting it -- every shard fills its slot with shard + 1, one gather, slot r must
+    be full of r + 1 everywhere.  A hook that forgets one peer must be caught."""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipDeviceSynchronize.argtypes = []
+    d, n, nshards = 8, 300, 4
+    for forget in (None, 2):
+        engs = [M.Engine(d, n, nshards=nshards, shard=s) for s in range(nshards)]
+        ptrs = [None] * nshards
+        bar = threading.Barrier(nshards)
+        res = [None] * nshards
+
+        def make_hook(s):
+            def hook(phase, ptr, slot, shard, ns, stream):
+                if phase != E.XCHG_BEGIN:
+                    return 0
+                ptrs[s] = ptr
+                hip.hipDeviceSynchronize()
+                bar.wait(timeout=60)
+                for r in range(ns):
+                    if r != s and not (s == 0 and r == forget):  # shard 0 "forgets" peer `forget`
+                        hip.hipMemcpy(ptr + r * slot * 4, ptrs[r] + r * slot * 4, slot * 4, 3)
+                bar.wait(timeout=60)
+                return 0
+            return hook
+
+        def work(s):
+            engs[s].set_exchange(make_hook(s))
+            res[s] = engs[s].exchange_self_check()
+
+        th = [threading.Thread(target=work, args=(s,)) for s in range(nshards)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert res == ([True] * nshards if forget is None else [False] + [True] * (nshards - 1)), (forget, res)
+        for e in engs:
+            e.close()

@@ -31,6 +31,8 @@ def test_rccl_is_loadable_and_single_rank_gather_runs():
     eng = M.Engine(d, n, pl=0.8)
     eng.rccl_init(uid)
     eng.debug_exchange()  # BEGIN (side stream, behind the engine's stream) + WAIT + drain
+    assert eng.rccl_info() == (1, 0)
+    assert eng.exchange_self_check()  # slot filled with shard + 1, gathered, read back
     p = O.default_pinit(d, n)
     vg, k1 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eng.run(60, 120, p, vg)
