@@ -258,8 +258,22 @@ void MCPar::create(uint32_t seed)
       MPI_Bcast(id, (int)sizeof id, MPI_BYTE, 0, comm->comm);
       MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, comm->comm);
       if (all_ok) {
-        ok = mcx_exchange_rccl_init(eng, id) == MCX_OK && mcx_debug_exchange(eng) == MCX_OK;
+        // one real gather with known contents before the communicator is trusted: every rank fills its slot with
+        // rank + 1, the gather runs, slot r must then be full of r + 1 on every rank
+        ok = mcx_exchange_rccl_init(eng, id) == MCX_OK && mcx_debug_fill_slot(eng, (float)(rank + 1)) == MCX_OK &&
+             mcx_debug_exchange(eng) == MCX_OK;
         if (!ok) std::cerr << "rank = " << rank << ":  RCCL exchange unavailable (" << mcx_last_error() << "), using MPI\n";
+        if (ok) {
+          std::vector<float> all((size_t)2 * size * nchain * nparam);
+          const size_t slot = (size_t)2 * nchain * nparam;
+          ok = mcx_get_musigall(eng, all.data()) == MCX_OK;
+          for (int r = 0; ok && r < size; ++r)
+            for (size_t i = 0; i < slot; ++i)
+              if (all[(size_t)r * slot + i] != (float)(r + 1)) { ok = 0; break; }
+          if (!ok) std::cerr << "rank = " << rank << ":  RCCL all-gather self-check failed (a slot did not arrive as sent), using MPI\n";
+          (void)mcx_debug_fill_slot(eng, 0.0f);  // leave the slots as a fresh engine has them (collective, like the check)
+          (void)mcx_debug_exchange(eng);
+        }
         MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, comm->comm);
         if (all_ok) {
           comm->rccl = true;
