@@ -23,18 +23,22 @@ def realistic_state(rng, N, d, n, stuck_every=0):
     return ms, pv
 
 
-@pytest.mark.parametrize("d,n,nshards", [(16, 1500, 1), (32, 700, 2), (16, 129, 3), (32, 4096, 1)])
+@pytest.mark.parametrize("d,n,nshards", [(16, 1500, 1), (32, 700, 2), (16, 129, 3), (32, 4096, 1), (16, 1501, 1), (16, 999, 3),
+                                         (16, 65, 5), (32, 333, 4), (16, 8200, 2)])
 def test_gen_remote_same_bits_with_and_without_exclusion(d, n, nshards):
     import mcpar_amd as M
     from mcpar_amd import engine as E
     rng = np.random.default_rng(d * 1000 + n)
     N = n * nshards
+    shard = nshards - 1  # (own Gaussians at offset shard * n: the min-arg sweep's starting point)
     ms, pv = realistic_state(rng, N, d, n, stuck_every=7)
-    eo = O.Engine(d, n, nshards=nshards, shard=0, threads=THREADS)
+    own = slice(shard * n, (shard + 1) * n)
+    pv = (ms[own, :, 0] + np.sqrt(ms[own, :, 1]) * rng.standard_normal((n, d))).astype(np.float32)
+    pv[::7] = ms[own][::7, :, 0]
+    eo = O.Engine(d, n, nshards=nshards, shard=shard, threads=THREADS)
     ro = eo.gen_remote(41, pv, ms)
-    kept = {}
     for mode in (1, 0, -1):
-        eg = M.Engine(d, n, nshards=nshards, shard=0)
+        eg = M.Engine(d, n, nshards=nshards, shard=shard)
         eg.set_option(E.OPT_CULL, mode)
         rg = eg.gen_remote(41, pv, ms)
         assert rg[4] == ro[4], mode
