@@ -211,8 +211,11 @@ __global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
 // leaves every result bit as it was.  null = sweep everything.
 // NT = threads of the workgroup (every workgroup stages all of its block's Gaussians through LDS whichever rows its
 // wavefronts then skip; larger workgroups = fewer copies were measured and are not faster: mcx_engine.hip).
+// (32-D with two chains per lane: asked to fit four workgroups per CU, i.e. 128 VGPRs instead of the 130-146 the
+// compiler takes unasked -- four wavefronts per SIMD instead of three, no spills: the dense sweeps of the 32-D
+// mixture 49 -> 52-54 "TFLOP/s"; five would spill)
 template <int DMAX, bool SUMS, bool EXACT, int CPL = 1, int NT = BLOCK>
-__global__ __launch_bounds__(NT) void k_remote_sweep(const float *__restrict__ xrows,
+__global__ __launch_bounds__(NT, (DMAX == 32 && CPL == 2) ? 4 : 1) void k_remote_sweep(const float *__restrict__ xrows,
                                                         const int *__restrict__ active, int nact,
                                                         const float *__restrict__ qpar,
                                                         float *__restrict__ psum,
