@@ -79,6 +79,41 @@ def test_sink_rows_equal_the_store(d, n, nburn, nsamp, pl, block, stride, persis
     assert same_bits(eng.samples, ref.samples)
 
 
+@pytest.mark.parametrize("d,n,nburn,nsamp,pl,block,stride", [
+    (16, 512, 120, 103, 0.85, 10, 1),    # one-launch kernel with Murray steps between its launches
+    (16, 20000, 55, 45, 0.9, 6, 3),      # hot-path fused kernel, thinned, more blocks than ring slots
+    (6, 100, 30, 25, 0.8, 1, 1),         # generic kernel
+])
+def test_sink_rows_equal_the_oracle(d, n, nburn, nsamp, pl, block, stride):
+    """The streamed rows against the CPU oracle's own sample store (not against the HIP engine's): the rows MCout
+    would hold after src/mcpar.cc:176-182, and its running maximum (src/mcout.cc:140-144)."""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    p = O.default_pinit(d, n)
+    vo, keep_o = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=pl, threads=8)
+    eo.set_record(samples=True, mask=False, stride=stride)
+    eo.run(nsamp, nburn, p, vo)
+    want = eo.samples
+    vg, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eng = M.Engine(d, n, pl=pl)
+    eng.set_option(E.OPT_SAMPLE_STRIDE, stride)
+    got = []
+
+    def sink(first, nsteps, rows):
+        got.append(rows.copy())
+        return 0
+    eng.set_sink(sink, block)
+    eng.run(nsamp, nburn, p, vg)
+    rows = np.concatenate(got)
+    assert rows.shape == want.shape
+    assert same_bits(rows, want)
+    gl, gp = eng.maxlike()
+    el, ep = first_max(want, d)
+    assert gl == el and same_bits(gp, ep)
+    eo.close()
+
+
 def test_sink_failure_is_reported():
     import mcpar_amd as M
     d, n = 8, 256
