@@ -884,7 +884,7 @@ static int cull_prepare(mcx_engine *e, const float *xrows, const int *ain, int n
   else
     hipLaunchKernelGGL((k_cull_boxes<DMAX, false>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
                        (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p);
-  const int gchunk = 16;
+  const int gchunk = 64;  // (every chunk re-reads the Gaussians' key dimensions: 74 us per 65 536 x 65 536 test with 16, 35 with 64)
   hipLaunchKernelGGL((k_cull_test<DMAX>), dim3((unsigned)((nw + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)((ng + gchunk - 1) / gchunk)),
                      dim3(BLOCK), 0, st, (const float *)e->winvall.p, N, (const float *)e->cull_box.p, (const float *)e->cull_lim.p, ng, nact,
                      gchunk, e->cull_excl.p, nw, reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
