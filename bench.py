@@ -670,7 +670,10 @@ def main():
                 c = dict(CONFIGS[name])
                 j = Job(M, E, c, c["n"], 0, 1, True, args.max_segment)
                 j.run()
-                k = 3
+                j.run()
+                # an R-murray job draws its number of remote steps (binomial, 9 +- 3 of the 90 eligible steps) and of
+                # rejection passes: a mean over 3 jobs moved by +-15 % from run to run of this script
+                k = 10 if c["pl"] < 1.0 else 5
                 t0 = time.perf_counter()
                 for _ in range(k):
                     j.run()
