@@ -8,6 +8,8 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
+VL_ROSENBROCK2_FIXED = 6  # MCX_VL_ROSENBROCK2_FIXED / MCXO_VL_ROSENBROCK2_FIXED (flagged variant, not the reference's)
+
 
 def spd(rng, d):
     a = rng.normal(size=(d, d)).astype(np.float32)
@@ -17,15 +19,15 @@ def spd(rng, d):
 def one_case(rng, idx):
     import mcpar_amd as M
     from mcpar_amd import engine as E
-    kind = int(rng.choice([O.VL_ROSENBROCK1, O.VL_GAUSSIAN, O.VL_GAUSSMIX, O.VL_ROSENBROCK2, O.VL_DUALGAUSS]))
+    kind = int(rng.choice([O.VL_ROSENBROCK1, O.VL_GAUSSIAN, O.VL_GAUSSMIX, O.VL_ROSENBROCK2, O.VL_DUALGAUSS, VL_ROSENBROCK2_FIXED]))
     d = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 16, 20, 24, 32, 36, 48]))
     if kind == O.VL_ROSENBROCK1:
         d = max(2, d + (d & 1))
-    if kind == O.VL_ROSENBROCK2:
+    if kind in (O.VL_ROSENBROCK2, VL_ROSENBROCK2_FIXED):
         d = max(2, d)
     if kind == O.VL_DUALGAUSS:
         d = 2
-    n = int(rng.integers(1, 200))
+    n = int(rng.integers(1, 200)) if rng.random() < 0.9 else int(rng.integers(200, 3000))  # (several exclusion groups)
     nburn = int(rng.choice([0, 1, 49, 52, 60, 101, 130]))
     nsamp = int(rng.choice([0, 1, 5, 9, 10, 11, 37, 64]))
     pl = float(rng.choice([1.0, 0.9, 0.7, 0.4]))
@@ -46,11 +48,13 @@ def one_case(rng, idx):
     persist = int(rng.choice([-1, -1, 0, 1]))   # small-n mode: one launch per run / per-segment kernels
     split = int(rng.choice([-1, -1, 0, 1]))     # (persist off:) pre-generated normals or generated in the step kernel
     sink = int(rng.choice([0, 0, 1, 3, 10, 64]))  # > 0: samples streamed through the sink in blocks of that many steps
+    cull = int(rng.choice([-1, -1, 0, 1]))      # exact exclusion of far Gaussians in the Murray sweeps: auto / off / whenever possible
+    bpl = int(rng.choice([0, 0, 1, 2, 4]))      # parameter blocks per lane of the hot-path kernel (0 = automatic)
     desc = dict(idx=idx, kind=kind, d=d, n=n, nburn=nburn, nsamp=nsamp, pl=pl, sync=sync, K=K, fullcov=incov is not None,
-                fuse=fuse, mask=mask, maxseg=maxseg, stride=stride, persist=persist, split=split, sink=sink)
+                fuse=fuse, mask=mask, maxseg=maxseg, stride=stride, persist=persist, split=split, sink=sink, cull=cull, bpl=bpl)
     p = (rng.normal(0, 0.7, (n, d))).astype(np.float32)
     vo, k1 = O.make_vlfunc(kind, d, params, K)
-    eo = O.Engine(d, n, pl=pl, sync=sync)
+    eo = O.Engine(d, n, pl=pl, sync=sync, threads=8 if n >= 200 else 1)
     eo.run(nsamp, nburn, p, vo, incov)
     vg, k2 = M.make_vlfunc(kind, d, params, K)
     eg = M.Engine(d, n, pl=pl, sync=sync)
@@ -60,6 +64,8 @@ def one_case(rng, idx):
     eg.set_option(E.OPT_SAMPLE_STRIDE, stride)
     eg.set_option(E.OPT_PERSIST, persist)
     eg.set_option(E.OPT_SPLIT_RNG, split)
+    eg.set_option(E.OPT_CULL, cull)
+    eg.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
     streamed = []
     if sink:
         eg.set_sink(lambda first, nsteps, rows: streamed.append((first, rows.copy())) and 0, sink)
