@@ -336,7 +336,121 @@ struct SegArgs {
   const float *zpre;  // pre-generated normals Z[nsteps][n][d] and accept thresholds U[nsteps][n] of this
   const float *upre;  // launch (k_gen_normals), or null: small-n mode, see k_fused_fast<..., PREGEN>
   float *trash;       // PREGEN: 16 B per lane where lanes that own no parameters dump their stores
+  int init_moments;   // main loop: start from mu = 0, psum2 = FPEPS (src/mcpar.cc:99-104) instead of loading them
+  float *sig_out;     // with the snapshot after step snap_after: the variances psum2 / (steps so far) as well, or null
+  // The burn-in tuner (src/mcpar.cc:77-96) at the end of this launch, by the workgroup that finishes last -- on the
+  // headline job the ten one-block k_tuner launches and the gaps around them were 4 % of the run.  on = 0: not here;
+  // on = 2 (main loop): the same count, added to the run's accepted main-loop proposals (ctr[4]).
+  struct Tuner {
+    int on, check, ncov, nslots;
+    unsigned long long *ctr;
+    unsigned long long add_trials;
+    float *T, *trace;
+    int *ntrace;
+    unsigned long long *cells;  // TUN_CELLS + 1 words (left at 0): finished workgroups << 40 | their accepted proposals
+    float armin, armax, dfac, ifac;
+  } tun;
 };
+
+// sum (and clear) the per-wavefront accept slots: one block
+__device__ __forceinline__ unsigned long long block_sum_slots(uint32_t *slots, int nslots)
+{
+  __shared__ unsigned long long red[BLOCK / 64];
+  unsigned long long v = 0;
+  for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
+    v += slots[i];
+    slots[i] = 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long t = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
+// src/mcpar.cc:77-96, by one workgroup: the segment's accepted proposals (the wavefronts' slots) join the counters;
+// at a check the acceptance rate since the last rescale decides on a rescale of the factor
+__device__ __forceinline__ void tuner_block(unsigned long long seg, unsigned long long *ctr, float *T, int ncov,
+                                            unsigned long long add_trials, int check, float armin, float armax, float dfac,
+                                            float ifac, float *trace, int *ntrace)
+{
+  __shared__ float fac;
+  if (threadIdx.x == 0) {
+    unsigned long long na = ctr[1] + seg, nt = ctr[2] + add_trials;
+    ctr[3] += seg;
+    float f = 1.0f;
+    if (check) {
+      const float arate = (float)na / (float)nt;
+      if (arate < armin) { na = nt = 0; f = dfac; }
+      else if (arate > armax) { na = nt = 0; f = ifac; }
+    }
+    ctr[1] = na;
+    ctr[2] = nt;
+    fac = f;
+  }
+  __syncthreads();
+  if (check) {
+    const float f = fac;
+    if (f != 1.0f)
+      for (int i = threadIdx.x; i < ncov; i += blockDim.x) T[i] *= f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int k = *ntrace;
+      if (k < 256) trace[k] = T[0];
+      *ntrace = k + 1;
+    }
+  }
+}
+
+// End of a fused burn-in launch with SegArgs::tun.on.  No wavefront has written its accept slot: every workgroup adds
+// (1 << 40 | its accepted proposals) to one of TUN_CELLS words, the workgroup that completes a word carries the word's
+// sum to the root word the same way, and the one that completes the root has the segment's total IN HAND -- nothing
+// that another workgroup wrote has to be visible to it, so no fences (a device-scope release is a write-back of the L2,
+// which holds the whole chain state at that point: +20 us per launch when tried) -- and is the tuner; nobody reads the
+// factor any more.  Same-address atomics cost ~10 ns each on this chip: 64 per word instead of 1024 on one.
+// Reached by EVERY thread of the workgroup (wacc = 0 for wavefronts without chains).
+constexpr int TUN_CELLS = 16;
+__device__ __forceinline__ void tuner_epilogue(const SegArgs &a, uint32_t wacc)
+{
+  if (!a.tun.on) return;
+  constexpr unsigned long long ONE = 1ull << 40, SUM = ONE - 1ull;
+  __shared__ unsigned part[BLOCK / 64];
+  __shared__ unsigned long long lds_seg;
+  __shared__ unsigned is_last;
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = wacc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned last = 0;
+    unsigned long long mine = ONE;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) mine += part[w];
+    const unsigned cell = blockIdx.x % TUN_CELLS, ncell = gridDim.x < TUN_CELLS ? gridDim.x : TUN_CELLS;
+    const unsigned members = (gridDim.x - cell + TUN_CELLS - 1) / TUN_CELLS;  // workgroups with blockIdx % TUN_CELLS == cell
+    const unsigned long long old = atomicAdd(a.tun.cells + cell, mine);
+    if ((unsigned)(old >> 40) + 1u == members) {
+      (void)atomicExch(a.tun.cells + cell, 0ull);  // (complete: nobody adds to it again in this launch)
+      const unsigned long long up = ONE | ((old + mine) & SUM);
+      const unsigned long long oldr = atomicAdd(a.tun.cells + TUN_CELLS, up);
+      if ((unsigned)(oldr >> 40) + 1u == ncell) {
+        (void)atomicExch(a.tun.cells + TUN_CELLS, 0ull);
+        lds_seg = (oldr + up) & SUM;
+        last = 1;
+      }
+    }
+    is_last = last;
+  }
+  __syncthreads();
+  if (is_last) {
+    if (a.tun.on == 1)
+      tuner_block(lds_seg, a.tun.ctr, a.tun.T, a.tun.ncov, a.tun.add_trials, a.tun.check, a.tun.armin, a.tun.armax,
+                  a.tun.dfac, a.tun.ifac, a.tun.trace, a.tun.ntrace);
+    else if (threadIdx.x == 0)
+      a.tun.ctr[4] += lds_seg;  // main loop: accepted proposals of the run so far (what k_reduce_slots adds up otherwise)
+  }
+}
 
 template <int LPC, int LIK, bool MAIN>
 __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
@@ -546,8 +660,20 @@ __device__ __forceinline__ float quad_bcast(float v, int qq)
   return as_f32((uint32_t)r);
 }
 
+template <int LPC, bool MAIN, int LIK, bool PREGEN, bool FULL>
+__device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a);
+
+// (the body returns early for threads without a chain, with the wavefront's accepted proposals otherwise; the tuner
+// at the end is every thread's)
 template <int LPC, bool MAIN, int LIK = LIK_ROSEN1, bool PREGEN = false, bool FULL = false>
 __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
+{
+  const uint32_t wacc = fused_fast_body<LPC, MAIN, LIK, PREGEN, FULL>(a);
+  tuner_epilogue(a, wacc);
+}
+
+template <int LPC, bool MAIN, int LIK, bool PREGEN, bool FULL>
+__device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a)
 {
   static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX || (LIK == LIK_ROSEN2F && !PREGEN && !FULL),
                 "fast path: Rosenbrock1, diagonal Gaussian, a mixture of <= 8 unit Gaussians, or (plain kernel only) the overlapping Rosenbrock");
@@ -578,7 +704,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t chain = gid / LPC;
   const int q = (int)(gid % LPC);
-  if (chain >= (size_t)a.n) return;
+  if (chain >= (size_t)a.n) return 0u;
   const int k0 = 4 * q;
   const bool live = k0 < d;  // d % 4 == 0: a lane owns 4 parameters or none (d = 12, 20, ...)
   const uint32_t g = a.g0 + (uint32_t)chain;
@@ -590,7 +716,9 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
     xe = f32x2{f.x, f.z}; xo = f32x2{f.y, f.w};
     te = f32x2{a.T[(k0 + 0) * d + k0 + 0], a.T[(k0 + 2) * d + k0 + 2]};
     to = f32x2{a.T[(k0 + 1) * d + k0 + 1], a.T[(k0 + 3) * d + k0 + 3]};
-    if (MAIN) {
+    if (MAIN && a.init_moments) {  // src/mcpar.cc:99-104
+      se = f32x2{FPEPS, FPEPS}; so = f32x2{FPEPS, FPEPS};
+    } else if (MAIN) {
       const float4 m = *reinterpret_cast<const float4 *>(a.mu + off);
       const float4 p = *reinterpret_cast<const float4 *>(a.psum2 + off);
       me = f32x2{m.x, m.z}; mo = f32x2{m.y, m.w};
@@ -734,6 +862,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
         float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
         slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
         slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
+        // the run's last step: the variances as mcx_get_var returns them (k_variance otherwise)
+        if (a.sig_out) *reinterpret_cast<float4 *>(a.sig_out + off) = make_float4(ve.x, vo.x, ve.y, vo.y);
       }
       if (sx) {  // src/mcpar.cc:177-182
         if (PREGEN && a.samp_stride <= 1) {
@@ -841,8 +971,10 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
     *reinterpret_cast<float4 *>(a.mu + off) = make_float4(me.x, mo.x, me.y, mo.y);
     *reinterpret_cast<float4 *>(a.psum2 + off) = make_float4(se.x, so.x, se.y, so.y);
   }
-  // one slot per wavefront, owned by it: no atomics (4096 same-address atomics cost ~40 us per launch)
-  if ((threadIdx.x & 63u) == 0 && wacc) a.acc_slots[gid >> 6] += wacc;
+  // one slot per wavefront, owned by it: no atomics (4096 same-address atomics cost ~40 us per launch); with the tuner
+  // inside the launch the count travels through tuner_epilogue instead
+  if ((threadIdx.x & 63u) == 0 && wacc && !a.tun.on) a.acc_slots[gid >> 6] += wacc;
+  return wacc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1035,25 +1167,6 @@ static __global__ void k_variance(const float *psum2, float *sig, size_t ntot, f
 // ntrial, ctr[3] = total burn-in accepts.  Integer counters (the reference's float counters stop
 // counting at 2^24: SURVEY §7).
 // ---------------------------------------------------------------------------------------------
-// sum (and clear) the per-wavefront accept slots: one block
-__device__ __forceinline__ unsigned long long block_sum_slots(uint32_t *slots, int nslots)
-{
-  __shared__ unsigned long long red[BLOCK / 64];
-  unsigned long long v = 0;
-  for (int i = threadIdx.x; i < nslots; i += blockDim.x) {
-    v += slots[i];
-    slots[i] = 0;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  unsigned long long t = 0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-  __syncthreads();
-  return t;
-}
-
 // accepted proposals of the main loop so far: *dst += sum(slots)
 static __global__ void k_reduce_slots(uint32_t *slots, int nslots, unsigned long long *dst)
 {
@@ -1065,33 +1178,7 @@ static __global__ void k_tuner(unsigned long long *ctr, float *T, int ncov, unsi
                         int check, float armin, float armax, float dfac, float ifac, float *trace,
                         int *ntrace, uint32_t *slots, int nslots)
 {
-  __shared__ float fac;
-  const unsigned long long seg = block_sum_slots(slots, nslots);
-  if (threadIdx.x == 0) {
-    unsigned long long na = ctr[1] + seg, nt = ctr[2] + add_trials;
-    ctr[3] += seg;
-    float f = 1.0f;
-    if (check) {
-      const float arate = (float)na / (float)nt;
-      if (arate < armin) { na = nt = 0; f = dfac; }
-      else if (arate > armax) { na = nt = 0; f = ifac; }
-    }
-    ctr[1] = na;
-    ctr[2] = nt;
-    fac = f;
-  }
-  __syncthreads();
-  if (check) {
-    const float f = fac;
-    if (f != 1.0f)
-      for (int i = threadIdx.x; i < ncov; i += blockDim.x) T[i] *= f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int k = *ntrace;
-      if (k < 256) trace[k] = T[0];
-      *ntrace = k + 1;
-    }
-  }
+  tuner_block(block_sum_slots(slots, nslots), ctr, T, ncov, add_trials, check, armin, armax, dfac, ifac, trace, ntrace);
 }
 
 // MCout row format (src/mcout.cc:129-137): (np parameters, log-likelihood) per (step, chain)

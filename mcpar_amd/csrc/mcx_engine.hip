@@ -391,6 +391,7 @@ struct mcx_engine {
   // exact exclusion of far Gaussians in the Murray sweeps (mcx_remote.hpp, k_cull_*)
   DevBuf<unsigned> cull_keys, cull_hist;
   DevBuf<int> cull_sorted;
+  DevBuf<unsigned long long> tun_cells;  // SegArgs::Tuner::cells
   DevBuf<float> cull_stats, cull_box, cull_lim;
   DevBuf<unsigned long long> cull_excl;
   int opt_cull = -1;  // -1 auto (many chains, many Gaussians, np = 16 or 32), 0 off, 1 whenever the kernels allow
@@ -491,6 +492,20 @@ constexpr int SPLIT_CHUNK_MAX = 256;
 constexpr size_t SPLIT_Z_BYTES = (size_t)32 << 20;  // keep a chunk's normals L2-resident (4 MiB per XCD)
 constexpr size_t SPLIT_AUTO_MAX_WAVES = 640;
 
+// Does a segment run on one of the hot-path kernels that take the burn-in tuner and the start of the moments into
+// the launch (SegArgs::tun, SegArgs::init_moments: k_fused_fast plain / full covariance, k_fused_fastb)?  The same
+// tests as launch_fused / launch_fused_plain below.
+static bool fused_takes_epilogue(const mcx_engine *e, const SegArgs &a)
+{
+  const int lik = e->lik.kind, lpc = e->lpc;
+  const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
+  const bool fast = lpc <= 8 && (fast_lik || lik == LIK_ROSEN2F) && a.diag && a.vec4 && !a.mask;
+  const size_t waves = ((size_t)a.n * lpc + 63) / 64;
+  const bool split = fast && fast_lik && (e->opt_split > 0 || (e->opt_split < 0 && waves < SPLIT_AUTO_MAX_WAVES));
+  if (split) return false;
+  return fast || (lpc <= 8 && fast_lik && !a.diag && a.vec4 && !a.mask);
+}
+
 static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t st)
 {
   const int lik = e->lik.kind, lpc = e->lpc;
@@ -590,6 +605,9 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   A(e->ctr.alloc((size_t)CTR_WORDS * CTR_RING));
   e->nslots = (int)(((size_t)nc * e->lpc + 63) / 64);
   A(e->acc_slots.alloc((size_t)e->nslots));
+  A(e->tun_cells.alloc(TUN_CELLS + 1));
+  if (st == MCX_OK && hipMemset(e->tun_cells.p, 0, (TUN_CELLS + 1) * sizeof(unsigned long long)) != hipSuccess)
+    st = fail(MCX_ERR_HIP, "hipMemset failed");
   A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(2 * (1 + 2 * CULL_NCOUNT))); A(e->ntrace.alloc(1));
   if (st == MCX_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipStreamCreate failed");
@@ -630,7 +648,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->cull_keys.release(); e->cull_hist.release(); e->cull_sorted.release(); e->cull_stats.release(); e->cull_box.release();
-  e->cull_lim.release(); e->cull_excl.release();
+  e->cull_lim.release(); e->cull_excl.release(); e->tun_cells.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
   e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release();
   for (int b = 0; b < 2; ++b) {
@@ -1647,6 +1665,13 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   sa.snap_after = -1;
   sa.zpre = sa.upre = nullptr;
   sa.trash = nullptr;
+  sa.init_moments = 0;
+  sa.sig_out = nullptr;
+  sa.tun = SegArgs::Tuner{};
+  sa.tun.ncov = e->ncov; sa.tun.nslots = e->nslots; sa.tun.ctr = ctrp; sa.tun.T = e->cov.p; sa.tun.trace = e->trace.p;
+  sa.tun.ntrace = e->ntrace.p; sa.tun.cells = e->tun_cells.p;
+  sa.tun.armin = e->TGT_ARATE_MIN; sa.tun.armax = e->TGT_ARATE_MAX; sa.tun.dfac = e->SCALE_DEC; sa.tun.ifac = e->SCALE_INC;
+  bool init_pending = false;  // MCX_PLAN_INIT_MOMENTS handed to the next main segment's launch
 
   const PlanCfg cfg = {nsamp, nburn, e->SYNCSTEP, e->PLOCAL, e->seed, e->tbase, e->size > 1, e->opt_eager != 0,
                        fused, e->ofn != nullptr, e->opt_maxseg, sink ? sblock : 0};
@@ -1740,7 +1765,6 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
       }
     }
     const int isamp = it.first, steps = it.nsteps;
-    if (it.kind == MCX_PLAN_BURN_SEGMENT || it.kind == MCX_PLAN_MAIN_SEGMENT || it.kind == MCX_PLAN_REMOTE_STEP) slots_used = true;
     switch (it.kind) {
     case MCX_PLAN_BURN_SEGMENT: {  // src/mcpar.cc:58-75
       const uint32_t t0 = e->tbase + (uint32_t)isamp;
@@ -1748,9 +1772,22 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         sa.samp_x = sa.samp_ly = nullptr;
         sa.mask = e->opt_mask ? e->mask.p + (size_t)isamp * n : nullptr;
         sa.nsteps = steps; sa.t0 = t0; sa.isamp0 = 0; sa.snap_after = -1;
-        ProfScope ps(e, MCX_K_FUSED_BURN, (uint64_t)steps * n);
-        MCXCHK(launch_fused(e, false, sa, st));
+        // the tuner event that follows the segment: inside the launch where the kernel can (its last workgroup)
+        const bool fold = pi + 1 < plan.size() && plan[pi + 1].kind == MCX_PLAN_TUNER && fused_takes_epilogue(e, sa);
+        sa.tun.on = fold ? 1 : 0;
+        if (fold) {
+          sa.tun.check = plan[pi + 1].aux;
+          sa.tun.add_trials = (unsigned long long)plan[pi + 1].nsteps * (unsigned long long)n;
+        }
+        {
+          ProfScope ps(e, MCX_K_FUSED_BURN, (uint64_t)steps * n);
+          MCXCHK(launch_fused(e, false, sa, st));
+        }
+        sa.tun.on = 0;
+        if (fold) ++pi;
+        else slots_used = true;
       } else {
+        slots_used = true;
         for (int s = 0; s < steps; ++s) {
           StepArgs a;
           fill_step(e, a, t0 + (uint32_t)s, 0, false, (size_t)(isamp + s), 0, 0);
@@ -1771,6 +1808,14 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
       break;
     }
     case MCX_PLAN_INIT_MOMENTS:  // src/mcpar.cc:99-104
+      if (fused && pi + 1 < plan.size() && plan[pi + 1].kind == MCX_PLAN_MAIN_SEGMENT) {
+        SegArgs probe = sa;
+        probe.mask = e->opt_mask ? e->mask.p : nullptr;
+        if (fused_takes_epilogue(e, probe)) {  // the segment's kernel starts from (0, FPEPS) instead of loading them
+          init_pending = true;
+          break;
+        }
+      }
       hipLaunchKernelGGL(k_init_moments, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->mu.p,
                          e->psum2.p, (size_t)e->ntot);
       HIPCHK(hipGetLastError());
@@ -1797,6 +1842,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
       StepArgs a;
       fill_step(e, a, t, isamp, true, (size_t)(nburn + isamp), isamp, 1);
       MCXCHK(launch_accept(e, a, true));
+      slots_used = true;
       break;
     }
     case MCX_PLAN_MAIN_SEGMENT: {  // src/mcpar.cc:152-209 with genLocal
@@ -1814,9 +1860,29 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
           MCXCHK(exchange_wait(e));
           e->published_steps = isamp + it.aux + 1;
         }
-        ProfScope ps(e, MCX_K_FUSED_MAIN, (uint64_t)steps * n);
-        MCXCHK(launch_fused(e, true, sa, st));
+        sa.init_moments = init_pending ? 1 : 0;
+        init_pending = false;
+        // hot-path kernels count their accepted proposals themselves (SegArgs::tun.on = 2), and the one that holds the
+        // run's last step leaves the variances and this shard's slot behind (one shard: no gather may want the slot as
+        // of the last sync point): no k_reduce_slots / k_variance / k_publish at the end of the run
+        const bool self = fused_takes_epilogue(e, sa);
+        sa.tun.on = self ? 2 : 0;
+        if (self && e->size == 1 && isamp + steps == nsamp && it.aux < 0) {
+          sa.snap_after = steps - 1;
+          sa.sig_out = e->sig.p;
+          e->published_steps = nsamp;
+          sig_done = true;
+        }
+        {
+          ProfScope ps(e, MCX_K_FUSED_MAIN, (uint64_t)steps * n);
+          MCXCHK(launch_fused(e, true, sa, st));
+        }
+        sa.init_moments = 0;
+        sa.tun.on = 0;
+        sa.sig_out = nullptr;
+        if (!self) slots_used = true;
       } else {
+        slots_used = true;
         for (int s = 0; s < steps; ++s) {
           StepArgs a;
           fill_step(e, a, t + (uint32_t)s, isamp + s, true, (size_t)(nburn + isamp + s), isamp + s, 0);

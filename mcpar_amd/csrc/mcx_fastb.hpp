@@ -20,7 +20,17 @@
 namespace mcx {
 
 template <int LPC2, int BPL, bool MAIN, int LIK>
+__device__ __forceinline__ uint32_t fused_fastb_body(const SegArgs &a);
+
+template <int LPC2, int BPL, bool MAIN, int LIK>
 __global__ __launch_bounds__(BLOCK) void k_fused_fastb(const SegArgs a)
+{
+  const uint32_t wacc = fused_fastb_body<LPC2, BPL, MAIN, LIK>(a);
+  tuner_epilogue(a, wacc);  // (every thread, also those the body let go early)
+}
+
+template <int LPC2, int BPL, bool MAIN, int LIK>
+__device__ __forceinline__ uint32_t fused_fastb_body(const SegArgs &a)
 {
   static_assert(BPL == 2 || BPL == 4, "two or four blocks per lane");
   static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX, "hot-path likelihoods only");
@@ -36,7 +46,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fastb(const SegArgs a)
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t chain = gid / LPC2;
   const int q2 = (int)(gid % LPC2);
-  if (chain >= (size_t)a.n) return;
+  if (chain >= (size_t)a.n) return 0u;
   const uint32_t g = a.g0 + (uint32_t)chain;
   const int k00 = 4 * BPL * q2;                 // first parameter of this lane
   const size_t off = chain * (size_t)d + k00;   // block b lives at off + 4 b
@@ -54,7 +64,9 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fastb(const SegArgs a)
       xe[b] = f32x2{f.x, f.z}; xo[b] = f32x2{f.y, f.w};
       te[b] = f32x2{a.T[(k0 + 0) * d + k0 + 0], a.T[(k0 + 2) * d + k0 + 2]};
       to[b] = f32x2{a.T[(k0 + 1) * d + k0 + 1], a.T[(k0 + 3) * d + k0 + 3]};
-      if (MAIN) {
+      if (MAIN && a.init_moments) {  // src/mcpar.cc:99-104
+        se[b] = f32x2{FPEPS, FPEPS}; so[b] = f32x2{FPEPS, FPEPS};
+      } else if (MAIN) {
         const float4 m = *reinterpret_cast<const float4 *>(a.mu + off + 4 * b);
         const float4 p = *reinterpret_cast<const float4 *>(a.psum2 + off + 4 * b);
         me[b] = f32x2{m.x, m.z}; mo[b] = f32x2{m.y, m.w};
@@ -201,6 +213,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fastb(const SegArgs a)
             float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * (off + 4 * b));
             slot[0] = make_float4(me[b].x, ve.x, mo[b].x, vo.x);
             slot[1] = make_float4(me[b].y, ve.y, mo[b].y, vo.y);
+            if (a.sig_out) *reinterpret_cast<float4 *>(a.sig_out + off + 4 * b) = make_float4(ve.x, vo.x, ve.y, vo.y);
           }
       }
       if (sx) {  // src/mcpar.cc:177-182
@@ -236,7 +249,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fastb(const SegArgs a)
     a.acc_cnt[chain] += cnt;
   }
   // one slot per wavefront, owned by it (no atomics); the tuner adds the slots up whatever their number
-  if ((threadIdx.x & 63u) == 0 && wacc) a.acc_slots[gid >> 6] += wacc;
+  if ((threadIdx.x & 63u) == 0 && wacc && !a.tun.on) a.acc_slots[gid >> 6] += wacc;  // (else: tuner_epilogue)
+  return wacc;
 }
 
 }  // namespace mcx
