@@ -503,6 +503,7 @@ static bool fused_takes_epilogue(const mcx_engine *e, const SegArgs &a)
   const size_t waves = ((size_t)a.n * lpc + 63) / 64;
   const bool split = fast && fast_lik && (e->opt_split > 0 || (e->opt_split < 0 && waves < SPLIT_AUTO_MAX_WAVES));
   if (split) return false;
+  if ((unsigned long long)a.n * (unsigned long long)a.nsteps >= (1ull << 40)) return false;  // tuner_epilogue's 40-bit sums
   return fast || (lpc <= 8 && fast_lik && !a.diag && a.vec4 && !a.mask);
 }
 
@@ -1811,6 +1812,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
       if (fused && pi + 1 < plan.size() && plan[pi + 1].kind == MCX_PLAN_MAIN_SEGMENT) {
         SegArgs probe = sa;
         probe.mask = e->opt_mask ? e->mask.p : nullptr;
+        probe.nsteps = plan[pi + 1].nsteps;
         if (fused_takes_epilogue(e, probe)) {  // the segment's kernel starts from (0, FPEPS) instead of loading them
           init_pending = true;
           break;
