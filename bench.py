@@ -468,6 +468,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(k):
             job.run(host_pinit)
+        job.eng.synchronize()  # a sharded run's last all-gather may still be in flight (MCX_OPT_ASYNC_TAIL): inside the clock
         sync()
         dt = time.perf_counter() - t0
         if world > 1:

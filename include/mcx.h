@@ -192,6 +192,11 @@ enum {
   MCX_OPT_BLOCKS_PER_LANE = 14, /* hot-path kernel: consecutive 4-parameter blocks of a chain held by one lane -- 1: one
                               (np/4 lanes per chain), 2 or 4: fewer lanes per chain, the per-chain work (acceptance test,
                               selects, counters) paid once per 2 / 4 blocks (same bits).  0 auto [default] */
+  MCX_OPT_ASYNC_TAIL = 15,   /* sharded runs on the library's RCCL exchange: mcx_run returns while the run's LAST all-gather
+                              (which nothing inside the run reads) is still in flight on its side stream; whatever looks
+                              at the gathered slots next -- mcx_get_musigall, the next run's first gather or publish,
+                              mcx_synchronize, mcx_destroy -- waits for it.  1 [default], 0: mcx_run waits itself, 2: also with a
+                              caller's exchange hook (whose MCX_XCHG_WAIT call then comes after mcx_run has returned) */
   MCX_OPT_DEBUG_MEET = 12    /* test hook: the meetings wait for `value` workgroups more than the grid has, i.e.
                               they can never complete [default 0] */
 };
@@ -220,6 +225,9 @@ int mcx_get_loglike(mcx_engine *e, float *ly);        /* [nc]     MCPar::lylast 
 int mcx_get_mean(mcx_engine *e, float *mu);           /* [nc*np]  MCPar::mu      */
 int mcx_get_var(mcx_engine *e, float *sig);           /* [nc*np]  MCPar::sig (population variance) */
 int mcx_get_musigall(mcx_engine *e, float *musigall); /* [nshards*nc*np*2] MCPar::musigall */
+/* Wait for everything the last mcx_run left in flight on the device (MCX_OPT_ASYNC_TAIL: the last all-gather of a
+ * sharded run and the slot's final publish behind it).  A launcher that times runs calls it before stopping the clock. */
+int mcx_synchronize(mcx_engine *e);
 int mcx_get_chol(mcx_engine *e, float *cov);          /* [np*np]  MCPar::cov after tuning */
 int mcx_get_accept_counts(mcx_engine *e, uint32_t *counts); /* [nc] per chain, burn + main */
 int mcx_get_accept_mask(mcx_engine *e, uint8_t *mask);      /* [(nburn+nsamp)*nc] of the last run */

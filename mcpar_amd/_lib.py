@@ -75,6 +75,7 @@ def load():
         "mcx_get_counters": [vp, C.POINTER(Counters)],
         "mcx_get_state": [vp, fp], "mcx_get_loglike": [vp, fp], "mcx_get_mean": [vp, fp],
         "mcx_get_var": [vp, fp], "mcx_get_musigall": [vp, fp], "mcx_get_chol": [vp, fp],
+        "mcx_synchronize": [vp],
         "mcx_get_accept_counts": [vp, u32p],
         "mcx_get_accept_mask": [vp, C.POINTER(C.c_uint8)],
         "mcx_get_tuner_trace": [vp, fp, C.c_int, C.POINTER(C.c_int)],

@@ -422,10 +422,11 @@ struct mcx_engine {
   int opt_bpl = 0;     // 4-parameter blocks per lane of the hot-path kernel: 0 auto, 1, 2, 4
   int opt_persist = -1;  // small-n mode, one launch per stretch of local steps (k_run_small): -1 auto, 0 off, 1 on
   int ncu = 0;           // compute units of the device (the persistent grid must be resident at once)
-  int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0;
+  int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0, opt_async_tail = 1;
   int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
   bool have_run = false, diag = true, xchg_pending = false;
   int published_steps = 0;  // main-loop steps reflected in this shard's musigall slot
+  int tail_publish = 0;     // > 0: the run's last gather is still in flight; publish that many steps once it is done (finish_tail)
   LikDev lik;
   mcx_exchange_fn xfn = nullptr;
   void *xctx = nullptr;
@@ -640,6 +641,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
 {
   if (!e) return MCX_OK;
   (void)hipSetDevice(e->device);
+  e->tail_publish = 0;  // (nobody will look at the slot; the gather itself is waited for by mcx_exchange_rccl_destroy)
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   prof_collect(e);
   (void)mcx_exchange_rccl_destroy(e);
@@ -666,9 +668,12 @@ extern "C" int mcx_destroy(mcx_engine *e)
   return MCX_OK;
 }
 
+static int finish_tail(mcx_engine *e);
+
 extern "C" int mcx_set_exchange(mcx_engine *e, mcx_exchange_fn fn, void *ctx)
 {
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  MCXCHK(finish_tail(e));  // (a gather of the exchange being replaced may still be in flight)
   e->xfn = fn;
   e->xctx = ctx;
   return MCX_OK;
@@ -699,6 +704,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
     break;
   case MCX_OPT_PROFILE: e->opt_profile = value ? 1 : 0; break;
   case MCX_OPT_EAGER_EXCHANGE: e->opt_eager = value ? 1 : 0; break;
+  case MCX_OPT_ASYNC_TAIL: e->opt_async_tail = value == 2 ? 2 : (value ? 1 : 0); break;
   case MCX_OPT_SPLIT_RNG: e->opt_split = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_PERSIST: e->opt_persist = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_CULL: e->opt_cull = value < 0 ? -1 : (value ? 1 : 0); break;
@@ -1083,6 +1089,23 @@ static int publish(mcx_engine *e, int steps_done)
   return MCX_OK;
 }
 
+// The last all-gather of a sharded run feeds nothing inside that run: it leaves the other shards' slots as of the
+// last sync point for whoever looks at musigall next.  When the library's own RCCL exchange carries it (a side stream,
+// nothing for the host to do), mcx_run does not wait for it: the gather runs on under the caller's next steps -- e.g.
+// the burn-in of the next run, which never touches musigall -- and whatever does touch it (mcx_get_musigall, the next
+// gather or publish, mcx_synchronize, mcx_destroy) waits first.  The slot's final publish (own moments after the last
+// step) cannot precede the gather that still reads the slot, so it waits with it.
+static int finish_tail(mcx_engine *e)
+{
+  if (!e->tail_publish) return MCX_OK;
+  const int steps = e->tail_publish;
+  e->tail_publish = 0;
+  MCXCHK(exchange_wait(e));
+  MCXCHK(publish(e, steps));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MCX_OK;
+}
+
 static int exchange_begin(mcx_engine *e)
 {
   MCXCHK(meet_release(e, false));  // a hook may wait for other engines: never while holding the GPU's meeting lock
@@ -1234,6 +1257,7 @@ extern "C" int mcx_exchange_rccl_destroy(mcx_engine *e)
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
   if (e->xcomm) {
     (void)hipSetDevice(e->device);
+    (void)finish_tail(e);
     if (e->xstream) (void)hipStreamSynchronize(e->xstream);
     if (e->xcomm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->xcomm);
     if (e->xfn == rccl_exchange) { e->xfn = nullptr; e->xctx = nullptr; }
@@ -1262,6 +1286,7 @@ extern "C" int mcx_debug_exchange(mcx_engine *e)
 {
   MCXCHK(enter(e));
   if (!e->xfn) return fail(MCX_ERR_EXCHANGE, "no exchange hook installed");
+  MCXCHK(finish_tail(e));
   MCXCHK(exchange_begin(e));
   MCXCHK(exchange_wait(e));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1277,6 +1302,7 @@ static __global__ void k_fill(float *p, size_t n, float v)
 extern "C" int mcx_debug_fill_slot(mcx_engine *e, float value)
 {
   MCXCHK(enter(e));
+  MCXCHK(finish_tail(e));
   MCXCHK(exchange_wait(e));  // (a gather in flight still reads the slot)
   const size_t slot = 2 * (size_t)e->ntot;
   hipLaunchKernelGGL(k_fill, dim3(nblocks(slot)), dim3(BLOCK), 0, e->stream, e->musigall.p + slot * (size_t)e->rank, slot, value);
@@ -1625,6 +1651,10 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     HIPCHK(hipMemcpyAsync(e->winv_tab.p, e->h_winv.data(), e->h_winv.size() * sizeof(float), hipMemcpyHostToDevice, st));
   }
   e->cnt = mcx_counters{};
+  if (e->tail_publish) {  // the last run's final gather may still be in flight (finish_tail)
+    if (nsamp > 0) e->tail_publish = 0;  // this run rewrites the slot -- after waiting for that gather -- before anything reads it
+    else MCXCHK(finish_tail(e));
+  }
   e->published_steps = 0;
   const bool fused = e->opt_fuse && e->lik.fusable();
   const uint32_t g0 = (uint32_t)(e->rank * n);
@@ -1831,7 +1861,15 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     case MCX_PLAN_SINK: MCXCHK(sink_block_done(e, isamp, steps, sink_seq++)); break;
     case MCX_PLAN_PUBLISH: MCXCHK(publish(e, isamp)); break;
     case MCX_PLAN_GATHER_BEGIN: MCXCHK(exchange_begin(e)); break;  // src/mcpar.cc:127-140
-    case MCX_PLAN_GATHER_WAIT: MCXCHK(exchange_wait(e)); break;
+    case MCX_PLAN_GATHER_WAIT:
+      if (isamp == nsamp && e->xchg_pending && (e->opt_async_tail == 2 || (e->opt_async_tail == 1 && e->xfn == rccl_exchange)) &&
+          pi + 2 == plan.size() && plan[pi + 1].kind == MCX_PLAN_PUBLISH) {
+        e->tail_publish = nsamp;  // finish_tail: the run's last gather stays in flight
+        ++pi;
+        break;
+      }
+      MCXCHK(exchange_wait(e));
+      break;
     case MCX_PLAN_REMOTE_STEP: {  // src/mcpar.cc:152-175 with genRemote
       MCXCHK(meet_release(e, false));  // (genRemote synchronises with the stream after every pass anyway)
       const uint32_t t = e->tbase + (uint32_t)nburn + (uint32_t)isamp;
@@ -2076,7 +2114,20 @@ extern "C" int mcx_get_state(mcx_engine *e, float *v) { return d2h(e, v, e ? e->
 extern "C" int mcx_get_loglike(mcx_engine *e, float *v) { return d2h(e, v, e ? e->lylast.p : nullptr, e ? (size_t)e->nchain : 0); }
 extern "C" int mcx_get_mean(mcx_engine *e, float *v) { return d2h(e, v, e ? e->mu.p : nullptr, e ? (size_t)e->ntot : 0); }
 extern "C" int mcx_get_var(mcx_engine *e, float *v) { return d2h(e, v, e ? e->sig.p : nullptr, e ? (size_t)e->ntot : 0); }
-extern "C" int mcx_get_musigall(mcx_engine *e, float *v) { return d2h(e, v, e ? e->musigall.p : nullptr, e ? 2 * (size_t)e->tchains * e->nparam : 0); }
+extern "C" int mcx_get_musigall(mcx_engine *e, float *v)
+{
+  MCXCHK(enter(e));
+  MCXCHK(finish_tail(e));
+  return d2h(e, v, e->musigall.p, 2 * (size_t)e->tchains * e->nparam);
+}
+
+extern "C" int mcx_synchronize(mcx_engine *e)
+{
+  MCXCHK(enter(e));
+  MCXCHK(finish_tail(e));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MCX_OK;
+}
 extern "C" int mcx_get_chol(mcx_engine *e, float *v) { return d2h(e, v, e ? e->cov.p : nullptr, e ? (size_t)e->ncov : 0); }
 extern "C" int mcx_get_accept_counts(mcx_engine *e, uint32_t *v) { return d2h(e, v, e ? e->acc_cnt.p : nullptr, e ? (size_t)e->nchain : 0); }
 

@@ -16,6 +16,7 @@ OPT_MEET_TIMEOUT_MS = 11
 OPT_DEBUG_MEET = 12
 OPT_CULL = 13
 OPT_BLOCKS_PER_LANE = 14
+OPT_ASYNC_TAIL = 15
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 
@@ -165,6 +166,10 @@ class Engine:
 
     def debug_exchange(self):
         check(load().mcx_debug_exchange(self.h))
+
+    def synchronize(self):
+        """wait for what the last run() left in flight (MCX_OPT_ASYNC_TAIL: a sharded run's last all-gather)"""
+        check(load().mcx_synchronize(self.h))
 
     def exchange_self_check(self):
         """every shard fills its slot with shard + 1, one exchange, then slot r must be full of r + 1 on every

@@ -12,7 +12,7 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, vlspec=None, opts=None):
+def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, vlspec=None, opts=None, runs=1):
     import mcpar_amd as M
     from mcpar_amd import engine as E
     hip = C.CDLL("libamdhip64.so")
@@ -48,7 +48,8 @@ def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, v
             for k, v in (opts or {}).items():
                 engs[s].set_option(k, v)
             engs[s].set_exchange(make_hook(s))
-            engs[s].run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
+            for _ in range(runs):
+                engs[s].run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
         except Exception as ex:  # pragma: no cover
             errs.append(ex)
             bar.abort()
@@ -84,6 +85,32 @@ def test_multishard_equals_oracle(nshards, pl, eager):
         if pl < 1.0:
             assert c["remote_steps"] > 0
         # own slot is current, peers' slots are as of the last exchange (src/mcpar.cc:127-140,205-208)
+        assert np.array_equal(eg.musigall.view(np.uint32), eo.musigall.view(np.uint32))
+
+
+@pytest.mark.parametrize("eager", [0, 1], ids=["lazy", "eager"])
+@pytest.mark.parametrize("pl,runs", [(0.7, 1), (1.0, 1), (0.8, 2), (1.0, 3)])
+def test_last_gather_left_in_flight(pl, runs, eager):
+    """MCX_OPT_ASYNC_TAIL: mcx_run returns without waiting for the run's last gather and without the slot's final publish
+    behind it; the getters (and the next run) finish them.  2 = with any exchange hook -- the default, 1, does it for
+    the library's own RCCL exchange only, which takes several GPUs."""
+    from mcpar_amd import engine as E
+    d, n, nshards, nburn, nsamp = 16, 96, 2, 60, 50
+    vo, keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl) for s in range(nshards)]
+    for _ in range(runs):
+        O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, eager=eager, opts={E.OPT_ASYNC_TAIL: 2}, runs=runs)
+    for s in range(nshards):
+        eo, eg = eos[s], egs[s]
+        assert np.array_equal(eg.accept_mask, eo.accept_mask), "shard %d" % s
+        # (first the peers' slots as of the last exchange and the own slot as of the last step: finish_tail)
+        assert np.array_equal(eg.musigall.view(np.uint32), eo.musigall.view(np.uint32))
+        for name in ("state", "mean", "var"):
+            assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
+        # (the oracle appends a run's rows to its store, the engine keeps the last run's)
+        assert np.array_equal(eg.samples.view(np.uint32), eo.samples[-nsamp * n:].view(np.uint32))
+        eg.synchronize()
         assert np.array_equal(eg.musigall.view(np.uint32), eo.musigall.view(np.uint32))
 
 
