@@ -1718,6 +1718,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         if (plan[pj].kind == MCX_PLAN_BURN_SEGMENT) pb += plan[pj].nsteps;
         ++pj;
       }
+      const size_t pj_burn_end = pj;
       if (pj + 1 < plan.size() && plan[pj].kind == MCX_PLAN_INIT_MOMENTS && plan[pj + 1].kind == MCX_PLAN_MAIN_SEGMENT) {
         init = 1;
         ++pj;
@@ -1729,6 +1730,13 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
           pm += plan[pj].nsteps;
           ++pj;
         }
+      }
+      if (e->xchg_pending && pb > 0 && pm > 0 && snap >= 0) {
+        // The last run's final gather is still in flight (finish_tail) and this stretch will rewrite the slot it
+        // reads: the burn-in, which does not touch the slot, goes first in a launch of its own and runs under the
+        // gather; the main-loop stretch follows in a second launch, behind the wait.
+        pj = pj_burn_end;
+        pm = 0; init = 0; is0 = 0; snap = -1;
       }
       if (pb + pm > 0) {
         RunArgs ra;

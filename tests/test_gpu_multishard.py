@@ -88,9 +88,10 @@ def test_multishard_equals_oracle(nshards, pl, eager):
         assert np.array_equal(eg.musigall.view(np.uint32), eo.musigall.view(np.uint32))
 
 
+@pytest.mark.parametrize("persist", [1, 0], ids=["one-launch", "segments"])
 @pytest.mark.parametrize("eager", [0, 1], ids=["lazy", "eager"])
 @pytest.mark.parametrize("pl,runs", [(0.7, 1), (1.0, 1), (0.8, 2), (1.0, 3)])
-def test_last_gather_left_in_flight(pl, runs, eager):
+def test_last_gather_left_in_flight(pl, runs, eager, persist):
     """MCX_OPT_ASYNC_TAIL: mcx_run returns without waiting for the run's last gather and without the slot's final publish
     behind it; the getters (and the next run) finish them.  2 = with any exchange hook -- the default, 1, does it for
     the library's own RCCL exchange only, which takes several GPUs."""
@@ -100,7 +101,11 @@ def test_last_gather_left_in_flight(pl, runs, eager):
     eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl) for s in range(nshards)]
     for _ in range(runs):
         O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
-    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, eager=eager, opts={E.OPT_ASYNC_TAIL: 2}, runs=runs)
+    # (one-launch mode: a run that starts under the last run's gather launches its burn-in first, on its own)
+    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, eager=eager, opts={E.OPT_ASYNC_TAIL: 2, E.OPT_PERSIST: persist},
+                          runs=runs)
+    if runs > 1 and persist:
+        assert egs[0].counters["kernel_launches"] >= 2
     for s in range(nshards):
         eo, eg = eos[s], egs[s]
         assert np.array_equal(eg.accept_mask, eo.accept_mask), "shard %d" % s
