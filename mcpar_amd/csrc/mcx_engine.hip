@@ -894,8 +894,7 @@ static int cull_prepare(mcx_engine *e, const float *xrows, const int *ain, int n
 {
   const int d = e->nparam, N = e->tchains;
   const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64;
-  HIPCHK(hipMemsetAsync(e->cull_stats.p, 0, 2 * CULL_KD * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(e->cull_hist.p, 0, CULL_BINS * sizeof(unsigned), st));
+  // (the sums and the histogram are zero here: zeroed when allocated, and again by every k_cull_boxes)
   hipLaunchKernelGGL(k_cull_stats, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p);
   hipLaunchKernelGGL(k_cull_keys, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p,
                      e->cull_keys.p, e->cull_hist.p);
@@ -905,10 +904,10 @@ static int cull_prepare(mcx_engine *e, const float *xrows, const int *ain, int n
   const dim3 gb((unsigned)((ng + BLOCK / 64 - 1) / (BLOCK / 64)));
   if (sums)
     hipLaunchKernelGGL((k_cull_boxes<DMAX, true>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
-                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p);
+                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p, e->cull_stats.p, e->cull_hist.p);
   else
     hipLaunchKernelGGL((k_cull_boxes<DMAX, false>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
-                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p);
+                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p, e->cull_stats.p, e->cull_hist.p);
   const int gchunk = 64;  // (every chunk re-reads the Gaussians' key dimensions: 74 us per 65 536 x 65 536 test with 16, 35 with 64)
   hipLaunchKernelGGL((k_cull_test<DMAX>), dim3((unsigned)((nw + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)((ng + gchunk - 1) / gchunk)),
                      dim3(BLOCK), 0, st, (const float *)e->winvall.p, N, (const float *)e->cull_box.p, (const float *)e->cull_lim.p, ng, nact,
@@ -940,8 +939,13 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
   auto cull_now = [&](int na) { return cull_can && (e->opt_cull > 0 || (na >= CULL_MIN_CHAINS && N >= CULL_MIN_GAUSSIANS)); };
   if (cull_can) {
     const size_t ngmax = ((size_t)n + CULL_W - 1) / CULL_W, nw = ((size_t)N + 63) / 64;
+    const bool fresh = !e->cull_hist.p || !e->cull_stats.p;
     MCXCHK(e->cull_keys.alloc((size_t)n)); MCXCHK(e->cull_hist.alloc(CULL_BINS)); MCXCHK(e->cull_sorted.alloc((size_t)n));
-    MCXCHK(e->cull_stats.alloc(2 * CULL_KD)); MCXCHK(e->cull_box.alloc(ngmax * 2 * CULL_KD)); MCXCHK(e->cull_lim.alloc(ngmax));
+    MCXCHK(e->cull_stats.alloc(2 * CULL_KD));
+    if (fresh) {  // (k_cull_boxes leaves them zero for the next sort)
+      HIPCHK(hipMemsetAsync(e->cull_stats.p, 0, 2 * CULL_KD * sizeof(float), st));
+      HIPCHK(hipMemsetAsync(e->cull_hist.p, 0, CULL_BINS * sizeof(unsigned), st));
+    } MCXCHK(e->cull_box.alloc(ngmax * 2 * CULL_KD)); MCXCHK(e->cull_lim.alloc(ngmax));
     MCXCHK(e->cull_excl.alloc(ngmax * nw));
   }
   HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
@@ -994,9 +998,13 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
   unsigned long long kept_min = 0, kept_sums = 0;
   MCXCHK(e->h_nact.alloc(1 + 2 * CULL_NCOUNT));  // pinned: the per-pass read-back queues behind the pass's last kernel
   while (nact > 0) {
-    HIPCHK(hipMemsetAsync(e->nact.p, 0, sizeof(int), st));
+    // two survivor counters in turn: a pass counts in one and zeroes the other for the next pass (the first pass's
+    // draw zeroes its own) -- no fill between the passes
+    int *const cnt_here = e->nact.p + (pass & 1);
+    if (big) HIPCHK(hipMemsetAsync(cnt_here, 0, sizeof(int), st));
     RemoteArgs a;
-    a.active_in = ain; a.nact = nact; a.active_out = aout; a.nact_out = e->nact.p;
+    a.active_in = ain; a.nact = nact; a.active_out = aout; a.nact_out = cnt_here;
+    a.nact_zero = big ? nullptr : e->nact.p + ((pass + 1) & 1);
     a.musigall = musigall; a.winv = e->winvall.p; a.cmax = e->cmax.p;
     a.ptrial = ptrial; a.mutrial = mutrial; a.sigtrial = sigtrial; a.cfac = cfac;
     a.racpt = e->racpt.p; a.psum = e->psum.p; a.pmax = e->pmax.p;
@@ -1006,7 +1014,8 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
       hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
       evaluated_host += (uint64_t)nact * (uint64_t)N;
     } else {
-      DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
+      // (later passes: the k_remote_decide that rejected a chain has drawn its next proposal already)
+      if (pass == 0) DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
       const bool cull = cull_now(nact) && cull_sums;
       const int *list = ain;
       const unsigned long long *excl = nullptr;
@@ -1038,7 +1047,7 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     HIPCHK(hipStreamSynchronize(st));
     const unsigned long long before = kept_sums;
     const uint64_t pairs_now = (uint64_t)nact * (uint64_t)N;
-    nact = (int)(unsigned)back[0];
+    nact = (int)(unsigned)((pass & 1) ? back[0] >> 32 : back[0] & 0xffffffffull);
     if (cull_can) {
       kept_min = kept_sums = 0;
       for (int c = 0; c < CULL_NCOUNT; ++c) { kept_min += back[1 + c]; kept_sums += back[1 + CULL_NCOUNT + c]; }
@@ -1049,8 +1058,8 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     }
     ain = aout;
     aout = (aout == e->active0.p) ? e->active1.p : e->active0.p;
+    e->cnt.kernel_launches += (big || pass > 0) ? 1 : 2;  // (+1: the sweep's own scope)
     ++pass;
-    e->cnt.kernel_launches += big ? 1 : 2;  // (+1: the sweep's own scope)
   }
   e->cnt.remote_pairs_evaluated += evaluated_host + (uint64_t)kept_min + (uint64_t)kept_sums;
   if (e->opt_cull < 0) {

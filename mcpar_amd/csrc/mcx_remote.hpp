@@ -158,7 +158,8 @@ struct RemoteArgs {
   const int *active_in;  // compacted list of still-rejected chains (null = all chains, pass 0)
   int nact;
   int *active_out;
-  int *nact_out;
+  int *nact_out;   // survivors of this pass (zero when the pass's decide starts)
+  int *nact_zero;  // the other one of the two counters: zeroed for the next pass, or null
   const float *musigall, *winv, *cmax;  // winv = qpar: (mu, 1/sig2) pairs
   float *ptrial, *mutrial, *sigtrial, *cfac;
   float *racpt;        // [n] rejection threshold of this pass, by chain
@@ -169,19 +170,15 @@ struct RemoteArgs {
 
 // Murray draw for every still-rejected chain (src/mcpar.cc:337-352): pick a component, draw from
 // its diagonal Gaussian, keep (mutrial, sigtrial); one lane per chain.
-template <int DMAX>
-__global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
+__device__ __forceinline__ void remote_draw_one(const RemoteArgs &a, int j, int pass)
 {
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= a.nact) return;
-  const int j = a.active_in ? a.active_in[i] : i;
   const int d = a.d;
   const uint32_t g = a.g0 + (uint32_t)j;
-  const u32x4 w = philox4x32_10(a.t, g, (uint32_t)a.pass, 0u, a.seed, ST_RSEL);
+  const u32x4 w = philox4x32_10(a.t, g, (uint32_t)pass, 0u, a.seed, ST_RSEL);
   const int sel = (int)(((uint64_t)w.x * (uint64_t)a.N) >> 32);  // src/mcpar.cc:337
   for (int qb = 0; 4 * qb < d; ++qb) {
     float z[4];
-    normal4_from_words(philox4x32_10(a.t, g, (uint32_t)a.pass, (uint32_t)qb, a.seed, ST_RNORM), z);
+    normal4_from_words(philox4x32_10(a.t, g, (uint32_t)pass, (uint32_t)qb, a.seed, ST_RNORM), z);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int k = 4 * qb + c;
@@ -195,6 +192,16 @@ __global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
     }
   }
   a.racpt[j] = u24(w.y);  // src/mcpar.cc:401
+}
+
+// the first pass of a Murray step draws for every chain; later passes are drawn by the k_remote_decide that rejected them
+template <int DMAX>
+__global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i == 0) *a.nact_out = 0;  // (this pass's decide counts its survivors there)
+  if (i >= a.nact) return;
+  remote_draw_one(a, a.active_in ? a.active_in[i] : i, a.pass);
 }
 
 // The all-pairs sweep (src/mcpar.cc:367-395 for ptrial, :421-437 for pvals): lanes = chains (vector
@@ -624,10 +631,12 @@ static __global__ void k_remote_decide(const RemoteArgs a)
     qm = v > qm ? v : qm;
   }
   const float pacpt = qm / qs;
+  if (i == 0 && a.nact_zero) *a.nact_zero = 0;  // the next pass's counter (this pass counts in the other one)
   if (a.racpt[j] < pacpt) {
     a.cfac[j] = a.cmax[j] / qm;
   } else {
     a.active_out[wave_slot(a.nact_out)] = j;
+    remote_draw_one(a, j, a.pass + 1);  // rejected: its next proposal, now (src/mcpar.cc:337-352 of the next pass)
   }
 }
 
@@ -759,8 +768,12 @@ static __global__ __launch_bounds__(BLOCK) void k_cull_scatter(const int *__rest
 template <int DMAX, bool SUMS>
 __global__ __launch_bounds__(BLOCK) void k_cull_boxes(const float *__restrict__ xrows, const int *__restrict__ order, int nact,
                                                       const float *__restrict__ qpar, int own0, float *__restrict__ box,
-                                                      float *__restrict__ lim)
+                                                      float *__restrict__ lim, float *__restrict__ stats_done,
+                                                      unsigned *__restrict__ hist_done)
 {
+  // the sort is over (this kernel runs behind k_cull_scatter): its sums and its histogram are left zero for the next one
+  for (int i = (int)(blockIdx.x * BLOCK + threadIdx.x); i < CULL_BINS; i += (int)(gridDim.x * BLOCK)) hist_done[i] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x < 2 * CULL_KD) stats_done[threadIdx.x] = 0.0f;
   const int g = (int)blockIdx.x * (BLOCK / 64) + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
   if (g * CULL_W >= nact) return;
   float lo[CULL_KD], hi[CULL_KD];
