@@ -1126,15 +1126,19 @@ __global__ __launch_bounds__(BLOCK) void k_accept(const StepArgs a)
 }
 
 // start of a run on the multi-launch paths, one launch instead of three fills and a copy: per-wavefront and
-// per-chain accept counters and the tuner-trace length to zero, the staged initial state into place (src/mcpar.cc:47-50)
+// per-chain accept counters and the tuner-trace length to zero, the staged initial state into place (src/mcpar.cc:47-50),
+// the proposal factor back to the one installed
 static __global__ void k_run_reset(uint32_t *slots, size_t nslots, uint32_t *acc_cnt, size_t n, int *ntrace,
-                                   float *__restrict__ x, const float *__restrict__ x0, size_t ntot)
+                                   float *__restrict__ x, const float *__restrict__ x0, size_t ntot,
+                                   float *__restrict__ cov, const float *__restrict__ cov0, size_t ncov)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nslots) slots[i] = 0u;
   if (i < n) acc_cnt[i] = 0u;
   if (i == 0) *ntrace = 0;
   if (x0 && i < ntot) x[i] = x0[i];
+  if (cov0)  // the factor the tuner is about to rescale, from the factor as installed
+    for (size_t k = i; k < ncov; k += (size_t)gridDim.x * blockDim.x) cov[k] = cov0[k];
 }
 
 // start of the main loop: mu = 0, psum2 = FPEPS (src/mcpar.cc:99-104)

@@ -1689,10 +1689,14 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   if (!lead) {
     hipLaunchKernelGGL(k_run_reset, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->acc_slots.p, (size_t)e->nslots,
                        e->acc_cnt.p, (size_t)n, e->ntrace.p, e->pvals.p, pinit ? (const float *)nullptr : e->pinit_dev.p,
-                       (size_t)e->ntot);
+                       (size_t)e->ntot, e->cov.p, e->cov_pending ? (const float *)e->cov0.p : (const float *)nullptr,
+                       (size_t)e->ncov);
     HIPCHK(hipGetLastError());
+    if (e->cov_pending) {  // (cov_reset's copy went with the reset kernel)
+      e->cov_pending = false;
+      e->cov_offdiag = !e->diag;
+    }
     MCXCHK(eval_trials(e, e->pvals.p, e->lylast.p, 0));  // :53
-    MCXCHK(cov_reset(e));
   }
 
   SegArgs sa;
