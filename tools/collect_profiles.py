@@ -79,3 +79,8 @@ for cfg in ("c3", "c2", "c5", "c3-murray", "c3-rosen2fixed"):
         res["SQ_INSTS_VALU"] = m.get("SQ_INSTS_VALU", {}).get("mean")
     json.dump(res, open(os.path.join(pr, "%s_%s_fused_kernel_counters.json" % (rnd, cfg)), "w"), indent=1)
     print(cfg, {k: v for k, v in res.items() if k in ("traffic_bytes_per_launch", "valu_busy_fraction")})
+
+# the strong-scaling shape's own line (tools/refresh_profiles.sh writes it last)
+_extra = os.path.join(go, "%s_bench_c3_8192chains.json" % rnd)
+if os.path.exists(_extra):
+    shutil.copy(_extra, os.path.join(pr, "%s_bench_c3_8192chains.json" % rnd))
