@@ -237,6 +237,13 @@ int mcx_get_tuner_trace(mcx_engine *e, float *scales, int maxn, int *n); /* cov[
  * (src/mcout.cc:129-145).  rows = steps*nc. */
 int mcx_samples_steps(mcx_engine *e, int *nsteps);
 int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float *rows);
+/* The same rows as the text MCout::output prints for them (src/mcout.cc:41-45: every field as `ostream << float` with
+ * the stream defaults, i.e. printf("%g"), two blanks behind it, a newline behind a row's last column), formatted on the
+ * device -- that conversion is 65-87 % of the reference's wall time.  *nbytes = bytes of the text (no terminating 0);
+ * text == NULL, capacity == 0: the size only.  A C3-sized block of 25 steps is ~270 MB of text: ask step ranges. */
+int mcx_samples_text(mcx_engine *e, int first_step, int nsteps, char *text, size_t capacity, size_t *nbytes);
+/* the same for any rows on the host (ncol columns each, e.g. what a sink was given): uploaded, formatted, copied back */
+int mcx_format_rows(const float *rows, size_t nrows, int ncol, char *text, size_t capacity, size_t *nbytes);
 /* running maximum-likelihood sample of this shard (MCout::add's maxlval, src/mcout.cc:140-144) */
 int mcx_samples_maxlike(mcx_engine *e, float *lmax, float *params);
 

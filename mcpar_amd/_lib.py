@@ -81,6 +81,8 @@ def load():
         "mcx_get_tuner_trace": [vp, fp, C.c_int, C.POINTER(C.c_int)],
         "mcx_samples_steps": [vp, C.POINTER(C.c_int)],
         "mcx_samples_copy": [vp, C.c_int, C.c_int, fp],
+        "mcx_samples_text": [vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)],
+        "mcx_format_rows": [fp, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)],
         "mcx_samples_maxlike": [vp, fp, fp],
         "mcx_get_profile": [vp, C.POINTER(Profile)],
         "mcx_copy_to_host": [vp, vp, C.c_size_t, vp],

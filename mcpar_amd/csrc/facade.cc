@@ -10,14 +10,20 @@
 
 #include <unistd.h>
 
+#include <algorithm>
 #include <cassert>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
 #include <limits>
+#include <locale>
 #include <new>
 #include <sstream>
+#include <thread>
+#include <vector>
+
+#include "fmt_g6.hpp"
 
 const float MCPar::FPEPS = 1.0e-14f;
 
@@ -84,6 +90,52 @@ void MCout::output()
   std::ostream &os = *sink_;
   if (binary_) {
     os.write(reinterpret_cast<const char *>(all), (std::streamsize)(count * sizeof(float)));
+    delete[] all;
+    return;
+  }
+  // The reference prints every number through the stream (src/mcout.cc:41-45): 65-87 % of its wall time, and all of
+  // a driver's time here, where the chain steps are on the GPU.  A stream in its default state (precision 6, no
+  // floatfield / showpoint / showpos / uppercase, no pending width, "C" locale) prints a float as printf("%g"): those
+  // characters come from fmtg6 (exact, tests/cpp/fmt_check.cc), rows cut into pieces for the host's threads.
+  const std::ios_base::fmtflags special =
+      std::ios_base::floatfield | std::ios_base::showpoint | std::ios_base::showpos | std::ios_base::uppercase;
+  if (os.precision() == 6 && !(os.flags() & special) && os.width() == 0 && os.getloc() == std::locale::classic()) {
+    const size_t w = static_cast<size_t>(width_), nrows = count / w;
+    const size_t piece_rows = std::max<size_t>(1, (size_t(1) << 21) / w);  // ~2 M numbers (36 MB of text at most) per piece
+    unsigned nthreads = std::thread::hardware_concurrency();
+    nthreads = std::max(1u, std::min(nthreads, 16u));
+    std::vector<std::vector<char> > text(nthreads);
+    std::vector<size_t> used(nthreads, 0);
+    for (size_t r0 = 0; r0 < nrows; r0 += piece_rows * nthreads) {
+      const size_t batch = std::min(nrows - r0, piece_rows * nthreads);
+      const unsigned nt = batch * w < (size_t(1) << 16) ? 1u : nthreads;  // (small dumps: not worth the threads)
+      const size_t per = (batch + nt - 1) / nt;
+      auto work = [&](unsigned t) {
+        const size_t a = std::min(batch, t * per), b = std::min(batch, a + per);
+        text[t].resize((b - a) * (w * 18 + 1) + 16);
+        char *p = text[t].data();
+        for (size_t r = r0 + a; r < r0 + b; ++r) {
+          const float *row = all + r * w;
+          for (size_t c = 0; c < w; ++c) {
+            p = fmtg6::append(p, row[c]);
+            *p++ = ' ';
+            *p++ = ' ';
+          }
+          *p++ = '\n';
+        }
+        used[t] = static_cast<size_t>(p - text[t].data());
+      };
+      if (nt == 1) {
+        work(0);
+      } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+      }
+      for (unsigned t = 0; t < nt; ++t) os.write(text[t].data(), static_cast<std::streamsize>(used[t]));
+    }
+    for (size_t i = nrows * w; i < count; ++i) os << all[i] << "  ";  // (a ragged tail: never, rows are whole)
     delete[] all;
     return;
   }

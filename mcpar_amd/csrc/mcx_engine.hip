@@ -8,6 +8,7 @@
 #include "mcx_launch.hpp"
 #include "mcx_persist.hpp"
 #include "mcx_remote.hpp"
+#include "mcx_text.hpp"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -392,6 +393,8 @@ struct mcx_engine {
   DevBuf<unsigned> cull_keys, cull_hist;
   DevBuf<int> cull_sorted;
   DevBuf<unsigned long long> tun_cells;  // SegArgs::Tuner::cells
+  DevBuf<unsigned long long> text_wg;    // mcx_samples_text: per-workgroup byte counts / offsets
+  DevBuf<char> text_dev;                 // and the text itself
   DevBuf<float> cull_stats, cull_box, cull_lim;
   DevBuf<unsigned long long> cull_excl;
   int opt_cull = -1;  // -1 auto (many chains, many Gaussians, np = 16 or 32), 0 off, 1 whenever the kernels allow
@@ -651,7 +654,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->cull_keys.release(); e->cull_hist.release(); e->cull_sorted.release(); e->cull_stats.release(); e->cull_box.release();
-  e->cull_lim.release(); e->cull_excl.release(); e->tun_cells.release();
+  e->cull_lim.release(); e->cull_excl.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
   e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release();
   for (int b = 0; b < 2; ++b) {
@@ -2229,6 +2232,60 @@ extern "C" int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float
     if (pin[b]) (void)hipHostFree(pin[b]);
     if (done[b]) (void)hipEventDestroy(done[b]);
   }
+  return rc;
+}
+
+// rows on the device -> their text (mcx_text.hpp); sl == null: sx holds whole rows of d + 1 columns
+static int text_of_rows(const float *sx, const float *sl, size_t count, int d, DevBuf<unsigned long long> &wg, DevBuf<char> &dev,
+                        hipStream_t st, char *text, size_t capacity, size_t *nbytes)
+{
+  *nbytes = 0;
+  if (count == 0) return MCX_OK;
+  const size_t nwg = (count + BLOCK - 1) / BLOCK;
+  if (nwg > 0x7fffffffu) return fail(MCX_ERR_INVALID, "too many rows for one call: ask for fewer at a time");
+  MCXCHK(wg.alloc(nwg + 1));
+  hipLaunchKernelGGL(k_text_sizes, dim3((unsigned)nwg), dim3(BLOCK), 0, st, sx, sl, count, d, wg.p);
+  hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, st, wg.p, nwg);
+  HIPCHK(hipGetLastError());
+  unsigned long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, wg.p + nwg, sizeof total, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *nbytes = (size_t)total;
+  if (!text) return MCX_OK;  // (the size only)
+  if ((size_t)total > capacity) return fail(MCX_ERR_INVALID, "text buffer too small: %llu bytes needed, %zu given", total, capacity);
+  MCXCHK(dev.alloc((size_t)total));
+  hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, st, sx, sl, count, d, (const unsigned long long *)wg.p, dev.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(text, dev.p, (size_t)total, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return MCX_OK;
+}
+
+// The same rows as text: what MCout::output prints for them (src/mcout.cc:41-45), formatted on the device.
+extern "C" int mcx_samples_text(mcx_engine *e, int first_step, int nsteps, char *text, size_t capacity, size_t *nbytes)
+{
+  MCXCHK(enter(e));
+  if (!e || !nbytes || first_step < 0 || nsteps < 0 || (!text && capacity)) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (first_step + nsteps > e->samp_steps) return fail(MCX_ERR_INVALID, "steps [%d,%d) not in the sample store (%d steps)", first_step, first_step + nsteps, e->samp_steps);
+  const size_t n = (size_t)e->nchain, d = (size_t)e->nparam;
+  return text_of_rows(e->samp_x.p + (size_t)first_step * n * d, e->samp_ly.p + (size_t)first_step * n, (size_t)nsteps * n * (d + 1),
+                      (int)d, e->text_wg, e->text_dev, e->stream, text, capacity, nbytes);
+}
+
+// any rows on the host (ncol columns each), e.g. what a sink received: uploaded, formatted, the text copied back
+extern "C" int mcx_format_rows(const float *rows, size_t nrows, int ncol, char *text, size_t capacity, size_t *nbytes)
+{
+  if (!nbytes || ncol < 1 || (nrows && !rows) || (!text && capacity)) return fail(MCX_ERR_INVALID, "bad arguments");
+  MCXCHK(need_device());
+  DevBuf<float> dr;
+  DevBuf<unsigned long long> wg;
+  DevBuf<char> dev;
+  const size_t count = nrows * (size_t)ncol;
+  int rc = dr.alloc(count);
+  if (rc == MCX_OK && count && hipMemcpy(dr.p, rows, count * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(MCX_ERR_HIP, "hipMemcpy failed");
+  if (rc == MCX_OK) rc = text_of_rows(dr.p, nullptr, count, ncol - 1, wg, dev, nullptr, text, capacity, nbytes);
+  dr.release(); wg.release(); dev.release();
   return rc;
 }
 

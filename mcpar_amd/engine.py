@@ -24,6 +24,17 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def format_rows(rows):
+    """rows [nrows, ncol] float32 -> the bytes MCout::output prints for them (src/mcout.cc:41-45), formatted on the GPU"""
+    rows = np.ascontiguousarray(rows, np.float32)
+    nrows, ncol = rows.shape
+    nb = C.c_size_t(0)
+    check(load().mcx_format_rows(_fp(rows), nrows, ncol, None, 0, C.byref(nb)))
+    buf = C.create_string_buffer(max(nb.value, 1))
+    check(load().mcx_format_rows(_fp(rows), nrows, ncol, buf, nb.value, C.byref(nb)))
+    return buf.raw[:nb.value]
+
+
 def make_vlfunc(kind, d, params=None, ncomp=0, host_fn=None, device_fn=None):
     """Build an mcx_vlfunc.  host_fn(x[npset, d]) -> y[npset] wraps a user VLFunc (src/vlfunc.hh:9-12);
     device_fn is a hipFunction_t (int) of a user kernel f(int npset, const float *x, float *y).
@@ -325,6 +336,15 @@ class Engine:
         if nsteps:
             check(load().mcx_samples_copy(self.h, first_step, nsteps, _fp(out)))
         return out
+
+    def samples_text(self, first_step, nsteps):
+        """the rows of samples_range(first_step, nsteps) as the bytes MCout::output prints for them (src/mcout.cc:41-45),
+        formatted on the device"""
+        nb = C.c_size_t(0)
+        check(load().mcx_samples_text(self.h, first_step, nsteps, None, 0, C.byref(nb)))
+        buf = C.create_string_buffer(max(nb.value, 1))
+        check(load().mcx_samples_text(self.h, first_step, nsteps, buf, nb.value, C.byref(nb)))
+        return buf.raw[:nb.value]
 
     def maxlike(self):
         lm = C.c_float(0)
