@@ -655,13 +655,33 @@ def main():
                 eng.samples_into(rows)
             dc = (time.perf_counter() - t0) / ke
             del rows
+            # the reference's product is TEXT (src/mcout.cc:41-45, 65-87 % of its wall time): the last steps of the run as
+            # the bytes MCout::output prints for them, formatted on the GPU (mcx_samples_text) and copied to the host
+            text = None
+            try:
+                ts = min(25, nsamp)
+                need = eng.samples_text_into(nsamp - ts, ts, None)
+                tbuf = np.empty(need, np.uint8)
+                eng.samples_text_into(nsamp - ts, ts, tbuf)  # warm (page-faults the destination once)
+                t0 = time.perf_counter()
+                got = eng.samples_text_into(nsamp - ts, ts, tbuf)
+                dtx = time.perf_counter() - t0
+                text = dict(steps=ts, numbers=ts * n * (d + 1), bytes=int(got), ms=dtx * 1e3, GBps=got / dtx / 1e9,
+                            numbers_per_s=ts * n * (d + 1) / dtx, first_row=bytes(tbuf[:min(got, 60)]).decode("ascii", "replace"),
+                            what="mcx_samples_text: %d steps of the run's rows as the text the reference prints (printf %%g, two blanks "
+                                 "per field), two formatting passes on the GPU + one copy into pageable host memory; glibc's "
+                                 "snprintf does ~7e6 such numbers per second and core" % ts)
+                del tbuf
+            except Exception as ex:  # noqa: BLE001
+                text = dict(error=repr(ex))
             end_to_end = dict(value=n * (nburn + nsamp) / de, unit="chain-steps/s", ms_per_step=de * 1e3, steps=ke,
                               host_bytes_per_job=int(nbytes), host_GBps=nbytes / de / 1e9, sink_block_steps=blk,
                               what="the same job with every sample row (MCout layout, np+1 columns) delivered to a consumer in "
                                    "pinned host memory through mcx_set_sink, copy-out overlapped with the steps; `value` keeps "
                                    "the rows in HBM",
                               copy_after_the_run=dict(value=n * (nburn + nsamp) / dc, ms_per_step=dc * 1e3,
-                                                      what="whole run kept in HBM, then mcx_samples_copy into pageable host memory"))
+                                                      what="whole run kept in HBM, then mcx_samples_copy into pageable host memory"),
+                              text=text)
         job.close()
         job = None
         if not args.no_extras:

@@ -346,6 +346,15 @@ class Engine:
         check(load().mcx_samples_text(self.h, first_step, nsteps, buf, nb.value, C.byref(nb)))
         return buf.raw[:nb.value]
 
+    def samples_text_into(self, first_step, nsteps, buf):
+        """the same into a caller's uint8 array (None: the size only); returns the number of bytes"""
+        nb = C.c_size_t(0)
+        if buf is None:
+            check(load().mcx_samples_text(self.h, first_step, nsteps, None, 0, C.byref(nb)))
+        else:
+            check(load().mcx_samples_text(self.h, first_step, nsteps, buf.ctypes.data_as(C.c_char_p), buf.size, C.byref(nb)))
+        return nb.value
+
     def maxlike(self):
         lm = C.c_float(0)
         p = np.empty(self.np, np.float32)

@@ -43,7 +43,7 @@ def test_every_kind_of_float_prints_like_the_c_library():
     assert E.format_rows(np.zeros((0, 4), np.float32)) == b""
 
 
-@pytest.mark.parametrize("d,n,nsamp,stride", [(16, 300, 12, 1), (2, 7, 5, 1), (8, 1000, 9, 2)])
+@pytest.mark.parametrize("d,n,nsamp,stride", [(16, 300, 12, 1), (2, 7, 5, 1), (8, 1000, 9, 2), (16, 20000, 3, 1)])
 def test_samples_text_is_the_text_of_the_rows(d, n, nsamp, stride):
     import mcpar_amd as M
     from mcpar_amd import engine as E
