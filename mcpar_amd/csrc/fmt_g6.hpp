@@ -105,6 +105,15 @@ FMTG6_HD bool big_low_bits_nonzero(const Big &a, int nbits)  // any of the bits 
 // round(m 2^e 10^p) to an integer, ties to even -- exact.  The result is known to be small (callers choose p so).
 FMTG6_HD uint32_t scaled_round(uint32_t m, int e, int p)
 {
+  if (p >= 0 && p <= 11 && e < 0 && e >= -63) {  // 1e-6 <= value < 1e6, i.e. nearly every sample: m 10^p < 2^61
+    uint64_t num = m;
+    for (int i = 0; i < p; ++i) num *= 10u;
+    const int s = -e;
+    uint64_t n = num >> s;
+    const uint64_t half = (num >> (s - 1)) & 1u, sticky = num & ((1ull << (s - 1)) - 1ull);
+    if (half && (sticky || (n & 1u))) ++n;
+    return n > 0xffffffffull ? 0xffffffffu : (uint32_t)n;
+  }
   if (p >= 0) {
     Big num;
     big_set(num, m);
