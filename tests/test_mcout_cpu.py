@@ -78,6 +78,19 @@ def test_facade_mcout_equals_reference_mcout_on_one_rank(tmp_path):
     assert seen >= 3
 
 
+def test_bulk_output_prints_what_the_stream_prints(tmp_path):
+    """the threaded fmtg6 path of MCout::output (1.5 M numbers of every kind) against `ostream << float`, and a stream with
+    its own precision, which the facade must honour"""
+    subprocess.check_call(["make", "-C", DRV, "../libmcpar.so"], stdout=subprocess.DEVNULL)
+    exe = str(tmp_path / "mcout_bulk")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include", "mcpar"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mcout_bulk.cc"),
+                           "-o", exe, "-L", os.path.join(ROOT, "mcpar_amd"), "-lmcpar", "-lmcx",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mcpar_amd")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
 @pytest.mark.skipif(not os.path.exists(MPIEXEC), reason="no MPI launcher in this image")
 def test_facade_mcout_equals_reference_mcout_on_two_ranks(tmp_path):
     r = subprocess.run(["make", "-C", DRV, "../libmcpar_mpi.so", "MPI=" + MPI], capture_output=True, text=True)
