@@ -99,7 +99,9 @@ void MCout::output()
   // characters come from fmtg6 (exact, tests/cpp/fmt_check.cc), rows cut into pieces for the host's threads.
   const std::ios_base::fmtflags special =
       std::ios_base::floatfield | std::ios_base::showpoint | std::ios_base::showpos | std::ios_base::uppercase;
-  if (os.precision() == 6 && !(os.flags() & special) && os.width() == 0 && os.getloc() == std::locale::classic()) {
+  static const bool through_the_stream = getenv("MCPAR_TEXT") && !strcmp(getenv("MCPAR_TEXT"), "stream");  // (escape hatch)
+  if (!through_the_stream && os.precision() == 6 && !(os.flags() & special) && os.width() == 0 &&
+      os.getloc() == std::locale::classic()) {
     const size_t w = static_cast<size_t>(width_), nrows = count / w;
     const size_t piece_rows = std::max<size_t>(1, (size_t(1) << 21) / w);  // ~2 M numbers (36 MB of text at most) per piece
     unsigned nthreads = std::thread::hardware_concurrency();
