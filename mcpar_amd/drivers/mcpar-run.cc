@@ -6,6 +6,7 @@
 // that src/anly/mcpar-analysis.R:80-120 reconstructs; --quiet prints only the summary (stderr).
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -16,6 +17,8 @@
 #include "mcpar/mcout.hh"
 #include "mcpar/mcpar.hh"
 #include "mcpar/rosenbrock.hh"
+
+#include "../csrc/fmt_g6.hpp"
 
 int main(int argc, char *argv[])
 {
@@ -77,13 +80,20 @@ int main(int argc, char *argv[])
     auto t0 = std::chrono::steady_clock::now();
     mcpar.run(nsamp, nburn, pinit.data(), *L, rslts);
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (iter && !quiet)
+    if (iter && !quiet) {  // (the numbers through fmtg6 like MCout::output: the same characters as `cout << float`)
+      std::vector<char> line((size_t)(np + 1) * 18 + 32);
       for (int r = 0; r < rslts.size(); ++r) {
-        std::cout << r / nc << "  ";
+        char *q = line.data() + snprintf(line.data(), 16, "%d  ", r / nc);
         const float *p = rslts.getpset(r);
-        for (int j = 0; j < np + 1; ++j) std::cout << p[j] << "  ";
-        std::cout << "\n";
+        for (int j = 0; j < np + 1; ++j) {
+          q = fmtg6::append(q, p[j]);
+          *q++ = ' ';
+          *q++ = ' ';
+        }
+        *q++ = '\n';
+        std::cout.write(line.data(), q - line.data());
       }
+    }
     if (rank == 0)
       std::cerr << "chains " << nc << " x np " << np << "  burn " << nburn << " + samples " << nsamp
                 << ": accept rate (main) " << (double)mcpar.naccept_main() / ((double)nc * nsamp)
