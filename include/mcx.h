@@ -158,6 +158,11 @@ int mcx_set_output_hook(mcx_engine *e, mcx_output_fn fn, void *ctx);
  * fn == NULL removes the sink.  block_steps is rounded up to a multiple of the sample stride. */
 typedef int (*mcx_sink_fn)(void *ctx, int first_step, int nsteps, const float *rows);
 int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_steps);
+/* The same sink, but every block arrives as the TEXT MCout::output prints for its rows (src/mcout.cc:41-45; see
+ * mcx_samples_text), formatted on the device: nbytes characters, no terminating 0, valid during the call.  One of the
+ * two sinks at a time: setting one removes the other. */
+typedef int (*mcx_text_sink_fn)(void *ctx, int first_step, int nsteps, const char *text, size_t nbytes);
+int mcx_set_text_sink(mcx_engine *e, mcx_text_sink_fn fn, void *ctx, int block_steps);
 
 /* ---- options ------------------------------------------------------------------------------ */
 enum {

@@ -15,6 +15,7 @@ HOSTFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINT
 XCHGFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 OUTFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 SINKFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
+TEXTSINKFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t)
 
 
 class VLFunc(C.Structure):
@@ -71,6 +72,7 @@ def load():
         "mcx_set_exchange": [vp, XCHGFN, vp],
         "mcx_set_output_hook": [vp, OUTFN, vp],
         "mcx_set_sink": [vp, SINKFN, vp, C.c_int],
+        "mcx_set_text_sink": [vp, TEXTSINKFN, vp, C.c_int],
         "mcx_set_option": [vp, C.c_int, C.c_int64],
         "mcx_get_counters": [vp, C.POINTER(Counters)],
         "mcx_get_state": [vp, fp], "mcx_get_loglike": [vp, fp], "mcx_get_mean": [vp, fp],

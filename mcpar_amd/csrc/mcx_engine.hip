@@ -442,6 +442,10 @@ struct mcx_engine {
   void *octx = nullptr;
   // streaming sample sink (mcx_set_sink): ring of SINK_RING blocks in samp_x / samp_ly, staged out on cstream
   mcx_sink_fn sfn = nullptr;
+  mcx_text_sink_fn tfn = nullptr;  // mcx_set_text_sink: the blocks as text instead of rows (one of the two at most)
+  DevBuf<unsigned long long> sink_text_wg[2];  // per staging buffer: the text kernels' byte counts / offsets
+  PinBuf<unsigned long long> sink_text_total[2];
+  PinBuf<char> sink_text_pin;
   void *sctx = nullptr;
   int sink_block = 0;  // main-loop steps per block (0 = no sink: the whole run stays in HBM)
   bool run_sink = false;           // the current / last run streamed its samples
@@ -660,10 +664,12 @@ extern "C" int mcx_destroy(mcx_engine *e)
   for (int b = 0; b < 2; ++b) {
     e->sink_stage[b].release();
     e->sink_pin[b].release();
+    e->sink_text_wg[b].release();
+    e->sink_text_total[b].release();
     if (e->ev_steps[b]) (void)hipEventDestroy(e->ev_steps[b]);
     if (e->ev_copy[b]) (void)hipEventDestroy(e->ev_copy[b]);
   }
-  e->best_row.release(); e->best_key.release(); e->cov0.release();
+  e->best_row.release(); e->best_key.release(); e->cov0.release(); e->sink_text_pin.release();
   if (e->meet_fd >= 0) (void)close(e->meet_fd);
   if (e->cstream) (void)hipStreamDestroy(e->cstream);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1536,6 +1542,22 @@ static int sink_deliver(mcx_engine *e, int seq)
   HIPCHK(hipEventSynchronize(e->ev_copy[b]));
   const int first = seq * e->run_kb;  // kept steps before this block
   const int kept = std::min(e->run_kb, (e->last_sink_total - first));
+  if (e->tfn) {
+    // text sink: the block's byte count has arrived with the event; now that its size is known, the fields are
+    // formatted once more into place (mcx_text.hpp) and copied out -- the staging buffer still holds the rows (the block
+    // that reuses it is queued only after this call)
+    const size_t total = (size_t)e->sink_text_total[b].p[0];
+    const size_t count = (size_t)kept * e->nchain * (size_t)(e->nparam + 1), nwg = (count + BLOCK - 1) / BLOCK;
+    MCXCHK(e->text_dev.alloc(total));
+    if (total > e->sink_text_pin.n) MCXCHK(e->sink_text_pin.alloc(total + total / 8));
+    hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
+                       (const float *)nullptr, count, e->nparam, (const unsigned long long *)e->sink_text_wg[b].p, e->text_dev.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->sink_text_pin.p, e->text_dev.p, total, hipMemcpyDeviceToHost, e->cstream));
+    HIPCHK(hipStreamSynchronize(e->cstream));
+    if (e->tfn(e->sctx, first, kept, e->sink_text_pin.p, total) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
+    return MCX_OK;
+  }
   if (e->sfn(e->sctx, first, kept, e->sink_pin[b].p) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
   return MCX_OK;
 }
@@ -1560,7 +1582,16 @@ static int sink_block_done(mcx_engine *e, int done, int nsteps, int seq)
   hipLaunchKernelGGL(k_rows_interleave, dim3(nblocks(kept * n * (d + 1))), dim3(BLOCK), 0, e->cstream, sx, sl,
                      e->sink_stage[b].p, kept * n, d);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(e->sink_pin[b].p, e->sink_stage[b].p, kept * n * (d + 1) * sizeof(float), hipMemcpyDeviceToHost, e->cstream));
+  if (e->tfn) {  // the size of the block's text (its two counting passes); sink_deliver places and copies it
+    const size_t count = kept * n * (size_t)(d + 1), nwg = (count + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(k_text_sizes, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
+                       (const float *)nullptr, count, d, e->sink_text_wg[b].p);
+    hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, e->cstream, e->sink_text_wg[b].p, nwg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->sink_text_total[b].p, e->sink_text_wg[b].p + nwg, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->cstream));
+  } else {
+    HIPCHK(hipMemcpyAsync(e->sink_pin[b].p, e->sink_stage[b].p, kept * n * (d + 1) * sizeof(float), hipMemcpyDeviceToHost, e->cstream));
+  }
   HIPCHK(hipEventRecord(e->ev_copy[b], e->cstream));
   // the ring: block seq + SINK_RING - 1 will overwrite the slot of block seq - 1, whose copy is already waited for
   // two blocks from now at the latest; with SINK_RING = 4 the host-side wait above is the only synchronisation
@@ -1577,6 +1608,17 @@ extern "C" int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_
 {
   if (!e || (fn && block_steps < 1)) return fail(MCX_ERR_INVALID, "bad arguments");
   e->sfn = fn;
+  e->tfn = nullptr;
+  e->sctx = ctx;
+  e->sink_block = fn ? block_steps : 0;
+  return MCX_OK;
+}
+
+extern "C" int mcx_set_text_sink(mcx_engine *e, mcx_text_sink_fn fn, void *ctx, int block_steps)
+{
+  if (!e || (fn && block_steps < 1)) return fail(MCX_ERR_INVALID, "bad arguments");
+  e->tfn = fn;
+  e->sfn = nullptr;
   e->sctx = ctx;
   e->sink_block = fn ? block_steps : 0;
   return MCX_OK;
@@ -1625,7 +1667,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   e->samp_steps = 0;
   const int nkeep = (nsamp + e->opt_stride - 1) / e->opt_stride;  // kept steps: isamp % stride == 0
   // sink mode: a ring of SINK_RING blocks instead of the whole run (block length a multiple of the stride)
-  const bool sink = e->sfn != nullptr && e->opt_samples && nsamp > 0;
+  const bool sink = (e->sfn != nullptr || e->tfn != nullptr) && e->opt_samples && nsamp > 0;
   const int sblock = sink ? ((std::max(e->sink_block, 1) + e->opt_stride - 1) / e->opt_stride) * e->opt_stride : 0;
   const int kb = sink ? sblock / e->opt_stride : 0;
   e->run_sink = sink; e->run_sblock = sblock; e->run_kb = kb;
@@ -1639,7 +1681,12 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   if (sink) {
     for (int b = 0; b < 2; ++b) {
       MCXCHK(e->sink_stage[b].alloc((size_t)kb * n * (d + 1)));
-      MCXCHK(e->sink_pin[b].alloc((size_t)kb * n * (d + 1)));
+      if (e->tfn) {
+        MCXCHK(e->sink_text_wg[b].alloc(((size_t)kb * n * (d + 1) + BLOCK - 1) / BLOCK + 1));
+        MCXCHK(e->sink_text_total[b].alloc(1));
+      } else {
+        MCXCHK(e->sink_pin[b].alloc((size_t)kb * n * (d + 1)));
+      }
       if (!e->ev_steps[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_steps[b], hipEventDisableTiming));
       if (!e->ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_copy[b], hipEventDisableTiming));
     }

@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (HOSTFN, K_NAMES, OUTFN, SINKFN, XCHGFN, Counters, PlanItem, Profile, VLFunc, check, load)
+from ._lib import (HOSTFN, K_NAMES, OUTFN, SINKFN, TEXTSINKFN, XCHGFN, Counters, PlanItem, Profile, VLFunc, check, load)
 
 VL_ROSENBROCK1, VL_ROSENBROCK2, VL_GAUSSIAN, VL_DUALGAUSS, VL_GAUSSMIX, VL_HOST = 1, 2, 3, 4, 5, 100
 VL_DEVICE = 101
@@ -224,6 +224,25 @@ class Engine:
         cb = SINKFN(tramp)
         self._keep.append(cb)
         check(load().mcx_set_sink(self.h, cb, None, int(block_steps)))
+
+    def set_text_sink(self, pyfn, block_steps):
+        """pyfn(first_step, nsteps, text: bytes-like memoryview) -> 0: every block as the text MCout::output prints for it
+        (src/mcout.cc:41-45), formatted on the device.  pyfn = None removes the sink."""
+        if pyfn is None:
+            check(load().mcx_set_text_sink(self.h, TEXTSINKFN(), None, 0))
+            return
+
+        def tramp(ctx, first, nsteps, text, nbytes):
+            try:
+                view = (C.c_char * nbytes).from_address(text) if nbytes else b""
+                return int(pyfn(first, nsteps, memoryview(view)) or 0)
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = TEXTSINKFN(tramp)
+        self._keep.append(cb)
+        check(load().mcx_set_text_sink(self.h, cb, None, int(block_steps)))
 
     def stage_pinit(self, pinit):
         """put the initial chain state in HBM ahead of time; run(..., pinit=None, ...) starts from it"""

@@ -59,3 +59,46 @@ def test_samples_text_is_the_text_of_the_rows(d, n, nsamp, stride):
     assert eng.samples_text(kept, 0) == b""
     with pytest.raises(M.McxError):
         eng.samples_text(0, kept + 1)
+
+
+@pytest.mark.parametrize("d,n,nburn,nsamp,pl,block,stride", [
+    (16, 512, 120, 103, 0.85, 10, 1),    # one-launch kernel with Murray steps between its launches, ragged last block
+    (16, 20000, 55, 45, 0.9, 6, 3),      # hot-path fused kernel, thinned, more blocks than ring slots
+    (6, 100, 30, 25, 0.8, 1, 1),         # generic kernel, one step per block
+    (2, 5, 0, 7, 1.0, 100, 1),           # block longer than the run
+])
+def test_text_sink_streams_the_text_of_the_rows(d, n, nburn, nsamp, pl, block, stride):
+    """mcx_set_text_sink: the blocks of mcx_set_sink, each as the text of its rows; against the oracle's own sample store
+    printed by the C library"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    p = O.default_pinit(d, n)
+    vo, keep_o = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=pl, threads=8)
+    eo.set_record(samples=True, mask=False, stride=stride)
+    eo.run(nsamp, nburn, p, vo)
+    vg, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eng = M.Engine(d, n, pl=pl)
+    eng.set_option(E.OPT_SAMPLE_STRIDE, stride)
+    got, calls = [], []
+
+    def sink(first, nsteps, text):
+        calls.append((first, nsteps))
+        got.append(bytes(text))
+        return 0
+    eng.set_text_sink(sink, block)
+    eng.run(nsamp, nburn, p, vg)
+    kb = (block + stride - 1) // stride
+    nkeep = (nsamp + stride - 1) // stride
+    assert calls == [(f, min(kb, nkeep - f)) for f in range(0, nkeep, kb)]
+    assert b"".join(got) == libc_text(eo.samples)
+    gl, gp = eng.maxlike()  # the running maximum is kept on the device as with the row sink
+    ll = eo.samples[:, d]
+    i = int(np.argmax(np.where(ll > -np.inf, ll, -np.inf)))
+    assert gl == ll[i] and np.array_equal(gp.view(np.uint32), eo.samples[i, :d].view(np.uint32))
+    # a row sink afterwards replaces the text sink
+    rows = []
+    eng.set_sink(lambda f, ns, r: rows.append(r.copy()) and 0, block)
+    eng.run(nsamp, nburn, p, vg)
+    assert np.concatenate(rows).shape == eo.samples.shape
+    eo.close()
