@@ -674,6 +674,29 @@ def main():
                 del tbuf
             except Exception as ex:  # noqa: BLE001
                 text = dict(error=repr(ex))
+            # and the whole job with every row delivered AS TEXT (mcx_set_text_sink): what a driver that prints its samples
+            # would hand to write(2)
+            try:
+                tbytes = [0]
+
+                def tsink(first, nsteps, view):
+                    tbytes[0] += len(view)
+                    return 0
+                eng.set_text_sink(tsink, blk)
+                job.run()
+                tbytes[0] = 0
+                t0 = time.perf_counter()
+                job.run()
+                dts = time.perf_counter() - t0
+                eng.set_text_sink(None, 0)
+                if isinstance(text, dict):
+                    text["whole_job_through_the_text_sink"] = dict(
+                        ms_per_step=dts * 1e3, bytes=int(tbytes[0]), GBps=tbytes[0] / dts / 1e9, value=n * (nburn + nsamp) / dts,
+                        unit="chain-steps/s", what="the job of `value` with all %d x %d rows delivered as text in pinned host memory, "
+                        "blocks of %d steps" % (nsamp, n, blk))
+            except Exception as ex:  # noqa: BLE001
+                if isinstance(text, dict):
+                    text["whole_job_through_the_text_sink"] = dict(error=repr(ex))
             end_to_end = dict(value=n * (nburn + nsamp) / de, unit="chain-steps/s", ms_per_step=de * 1e3, steps=ke,
                               host_bytes_per_job=int(nbytes), host_GBps=nbytes / de / 1e9, sink_block_steps=blk,
                               what="the same job with every sample row (MCout layout, np+1 columns) delivered to a consumer in "
