@@ -42,6 +42,14 @@ public:
   // addition: output() writes the rows as raw little-endian float32 (np+1 per row, same order) instead of text --
   // the text formatting of src/mcout.cc:41-45 is 65-87 % of the reference's wall time
   void binary(bool on) { binary_ = on; }
+  // addition: nothing is stored -- MCPar::run hands every block of rows to the stream as text formatted on the GPU
+  // (mcx_set_text_sink: the same characters, at the speed of the copy).  size(), getpset(), collect() then see no rows;
+  // maxlike() still answers (the engine keeps the running maximum).  One rank only: with several ranks the rows are
+  // gathered as usual.
+  void text_only(bool on) { text_only_ = on; }
+  bool text_only(void) const { return text_only_; }
+  void write_text(const char *text, std::size_t nbytes);              // (MCPar::run's text sink)
+  void note_best(float lval, const float *params);                    // (the engine's running maximum)
   // COLLECTIVE: every rank of the communicator must call it.  Best sample over all ranks.
   const std::vector<float> &maxlike(float *lmax);
 
@@ -55,7 +63,7 @@ private:
   std::ostream *sink_;            // rank 0 only
   MPI_Comm comm_;
   int rank_, nranks_;
-  bool binary_;
+  bool binary_, text_only_;
   void note_row(const float *row);
 };
 

@@ -38,7 +38,7 @@ static void die(const char *where)
 // ---------------------------------------------------------------------------------------------
 MCout::MCout(int np, std::ostream *aoutstream, MPI_Comm acomm)
     : nparam_(np), width_(np + 1), fill_(0), flushed_(0), stored_rows_(0), capacity_rows_(0),
-      best_l_(-std::numeric_limits<float>::infinity()), best_p_(static_cast<size_t>(np), 0.0f), sink_(0), binary_(false)
+      best_l_(-std::numeric_limits<float>::infinity()), best_p_(static_cast<size_t>(np), 0.0f), sink_(0), binary_(false), text_only_(false)
 {
 #ifdef MCX_WITH_MPI
   if (MPI_Comm_dup(acomm, &comm_) != MPI_SUCCESS) {
@@ -58,6 +58,19 @@ void MCout::note_row(const float *row)
   if (row[nparam_] > best_l_) {  // first strict maximum wins (src/mcout.cc:140-144)
     best_l_ = row[nparam_];
     best_p_.assign(row, row + nparam_);
+  }
+}
+
+void MCout::write_text(const char *text, size_t nbytes)
+{
+  if (rank_ == 0 && sink_ && nbytes) sink_->write(text, static_cast<std::streamsize>(nbytes));
+}
+
+void MCout::note_best(float lval, const float *params)
+{
+  if (lval > best_l_) {
+    best_l_ = lval;
+    best_p_.assign(params, params + nparam_);
   }
 }
 
@@ -432,6 +445,19 @@ int sample_sink(void *vctx, int first_step, int nsteps, const float *rows)
   return 0;
 }
 
+// MCout::text_only: the same blocks, as text from the device, straight to the stream (mcx_set_text_sink)
+int text_sink(void *vctx, int first_step, int nsteps, const char *text, size_t nbytes)
+{
+  RunCtx *c = static_cast<RunCtx *>(vctx);
+  const int steps_done = first_step + nsteps;
+  c->copied_steps = steps_done;
+  write_step_diagnostics(c, steps_done);
+  if (steps_done < c->nsamp) (*c->log) << "Beginning output at step " << steps_done << std::endl;
+  c->out->write_text(text, nbytes);
+  if (steps_done < c->nsamp) (*c->log) << "Output finished\n" << std::endl;
+  return 0;
+}
+
 #ifdef MCX_WITH_MPI
 struct XchgCtx {
   MPI_Comm comm;
@@ -467,8 +493,9 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   else logname << "/dev/null";
   std::ofstream logfile(logname.str().c_str());
 
+  const bool as_text = outsamples.text_only() && !mpi;  // (several ranks: rows, gathered in rank order as usual)
   try {
-    outsamples.newsamps(nsamp * nchain);  // src/mcpar.cc:31
+    if (!as_text) outsamples.newsamps(nsamp * nchain);  // src/mcpar.cc:31
   } catch (std::bad_alloc &) {
     logfile << "Unable to allocate space for output samples.  Exiting.\n";
     exit(2);
@@ -481,7 +508,8 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   RunCtx ctx = {eng,   &outsamples, &logfile, nchain,   nparam + 1, 0, nsamp, std::vector<float>(),
                 logging, mpi,        logstep,  SYNCSTEP, 0,          outsamples.size()};
   const int outstep = nsamp > 50 ? nsamp / 10 : 5;  // src/mcpar.cc:110
-  mcx_set_sink(eng, sample_sink, &ctx, outstep);
+  if (as_text) mcx_set_text_sink(eng, text_sink, &ctx, outstep);
+  else mcx_set_sink(eng, sample_sink, &ctx, outstep);
 #ifdef MCX_WITH_MPI
   std::vector<float> nohost;
   XchgCtx xc = {comm ? comm->comm : MPI_COMM_WORLD, comm ? comm->host : nohost};
@@ -504,6 +532,11 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   }
   if (st != MCX_OK) die("MCPar::run");
   mcx_get_counters(eng, &counters);
+  if (as_text && nsamp > 0) {  // MCout saw no rows: its maxlike() answers from the engine's running maximum
+    float lbest = 0.0f;
+    std::vector<float> pbest(static_cast<size_t>(nparam));
+    if (mcx_samples_maxlike(eng, &lbest, pbest.data()) == MCX_OK) outsamples.note_best(lbest, pbest.data());
+  }
   outsamples.output();  // output remaining samples (src/mcpar.cc:212)
   return 0;
 }

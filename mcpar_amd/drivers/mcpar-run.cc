@@ -1,7 +1,7 @@
 // mcpar-run -- the BASELINE configurations as a first-class driver (the reference reaches them
 // only through its library API: SURVEY fact 3).
 //   mcpar-run [--func rosen1|rosen2|rosen2fixed|gauss|dgauss|mix] [--np D] [--nc CHAINS] [--nsamp N]
-//             [--nburn B] [--pl P] [--sync S] [--ncomp K] [--quiet] [--iter]
+//             [--nburn B] [--pl P] [--sync S] [--ncomp K] [--quiet] [--iter] [--binary] [--stream-text]
 // Output: the reference's row format (src/mcout.cc:41-45); --iter prepends the iteration index
 // that src/anly/mcpar-analysis.R:80-120 reconstructs; --quiet prints only the summary (stderr).
 #include <chrono>
@@ -25,7 +25,7 @@ int main(int argc, char *argv[])
   std::string func = "rosen1";
   int np = 16, nc = 4096, nsamp = 100, nburn = 500, sync = 10, ncomp = 8;
   float pl = 1.0f;
-  bool quiet = false, iter = false, binary = false;
+  bool quiet = false, iter = false, binary = false, stream_text = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : "0"; };
@@ -40,6 +40,7 @@ int main(int argc, char *argv[])
     else if (a == "--quiet") quiet = true;
     else if (a == "--iter") iter = true;
     else if (a == "--binary") binary = true;  // rows as raw float32 (np+1 per row) instead of text
+    else if (a == "--stream-text") stream_text = true;  // the same text, formatted on the GPU, nothing kept on the host
     else { std::cerr << "unknown option " << a << "\n"; return 2; }
   }
   MPI_Init(&argc, &argv);
@@ -71,6 +72,7 @@ int main(int argc, char *argv[])
   std::ostringstream sink;
   MCout rslts(np, (quiet || iter) ? static_cast<std::ostream *>(&sink) : &std::cout, MPI_COMM_WORLD);
   rslts.binary(binary);
+  rslts.text_only(stream_text && !binary && !iter);
   std::vector<float> pinit((size_t)nc * np);
   for (int j = 0; j < nc; ++j)
     for (int i = 0; i < np; ++i)

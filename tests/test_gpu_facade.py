@@ -120,6 +120,11 @@ def test_mcpar_run_binary_rows_equal_text_rows(tmp_path):
     eo.run(73, 60, O.default_pinit(8, 96), vl)
     assert np.array_equal(rows.view(np.uint32), eo.samples.view(np.uint32))
     assert t.stdout.decode() == fmt_rows(eo.samples)
+    # --stream-text (MCout::text_only): the same bytes, formatted on the GPU and never stored on the host; same maximum
+    st = subprocess.run([os.path.join(DRV, "mcpar-run")] + args + ["--stream-text"], cwd=tmp_path, capture_output=True, timeout=300)
+    assert st.returncode == 0, st.stderr
+    assert st.stdout == t.stdout
+    assert st.stderr.decode().split("max likelihood value:")[1] == t.stderr.decode().split("max likelihood value:")[1]
     # --iter: the iteration index the R analysis script reconstructs (src/anly/mcpar-analysis.R:80-120) in front of every row
     it = subprocess.run([os.path.join(DRV, "mcpar-run")] + args + ["--iter"], cwd=tmp_path, capture_output=True, timeout=300)
     assert it.returncode == 0, it.stderr
