@@ -98,12 +98,21 @@ void MCout::add_rows(const float *rows, size_t nrows)
 void MCout::output()
 {
   size_t count = 0;
-  float *all = collect(&count);
+  float *owned = 0;
+  const float *all = 0;
+  if (nranks_ == 1) {  // nothing to gather: print from the store itself (collect() would copy the rows first)
+    count = fill_ > flushed_ ? fill_ - flushed_ : 0;
+    if (count) all = &rows_[flushed_];
+    flushed_ = fill_;
+  } else {
+    owned = collect(&count);
+    all = owned;
+  }
   if (rank_ != 0 || count == 0) return;
   std::ostream &os = *sink_;
   if (binary_) {
     os.write(reinterpret_cast<const char *>(all), (std::streamsize)(count * sizeof(float)));
-    delete[] all;
+    delete[] owned;
     return;
   }
   // The reference prints every number through the stream (src/mcout.cc:41-45): 65-87 % of its wall time, and all of
@@ -151,14 +160,14 @@ void MCout::output()
       for (unsigned t = 0; t < nt; ++t) os.write(text[t].data(), static_cast<std::streamsize>(used[t]));
     }
     for (size_t i = nrows * w; i < count; ++i) os << all[i] << "  ";  // (a ragged tail: never, rows are whole)
-    delete[] all;
+    delete[] owned;
     return;
   }
   for (size_t i = 0; i < count; ++i) {
     os << all[i] << "  ";
     if ((i + 1) % width_ == 0) os << "\n";
   }
-  delete[] all;
+  delete[] owned;
 }
 
 // rows added since the last flush, all ranks', rank-major; buffer exists on rank 0 only
