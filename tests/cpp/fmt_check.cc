@@ -21,7 +21,9 @@ static bool same(uint32_t bits, long *bad)
   snprintf(want, sizeof want, "%g", (double)f);
   char *end = fmtg6::append(got, f);
   *end = 0;
-  if (strcmp(want, got) != 0) {
+  char got2[32];
+  *fmtg6::append_words(got2, f) = 0;  // (the form the GPU's lanes assemble)
+  if (strcmp(want, got) != 0 || strcmp(want, got2) != 0) {
     if (++*bad <= 10) fprintf(stderr, "bits %08x: libc '%s' fmtg6 '%s'\n", bits, want, got);
     return false;
   }
