@@ -28,12 +28,13 @@ def job_ms(kind, d, n, persist, params=None, K=0, reps=20):
     e.close()
     return dt * 1e3, launches
 
-for d in (8, 16, 32):
-    for n in (8192, 16384, 20480, 24576, 28672, 32768, 49152, 65536, 131072):
-        lpc = 1
-        while lpc * 4 < d: lpc *= 2
-        if n * lpc // 64 > 8 * 256:
-            continue
-        a, la = job_ms(M.VL_ROSENBROCK1, d, n, 1)
-        b, lb = job_ms(M.VL_ROSENBROCK1, d, n, 0)
-        print("d=%2d n=%6d owners/WG=%d  one launch %.3f ms (%d launches)   fused %.3f ms (%d launches)   ratio %.2f" % (d, n, -(-(n * lpc // 64) // 256), a, la, b, lb, b / a), flush=True)
+if __name__ == "__main__":
+  for d in (8, 16, 32):
+      for n in (8192, 16384, 20480, 24576, 28672, 32768, 49152, 65536, 131072):
+          lpc = 1
+          while lpc * 4 < d: lpc *= 2
+          if n * lpc // 64 > 8 * 256:
+              continue
+          a, la = job_ms(M.VL_ROSENBROCK1, d, n, 1)
+          b, lb = job_ms(M.VL_ROSENBROCK1, d, n, 0)
+          print("d=%2d n=%6d owners/WG=%d  one launch %.3f ms (%d launches)   fused %.3f ms (%d launches)   ratio %.2f" % (d, n, -(-(n * lpc // 64) // 256), a, la, b, lb, b / a), flush=True)
