@@ -44,11 +44,11 @@ public:
   void binary(bool on) { binary_ = on; }
   // addition: nothing is stored -- MCPar::run hands every block of rows to the stream as text formatted on the GPU
   // (mcx_set_text_sink: the same characters, at the speed of the copy).  size(), getpset(), collect() then see no rows;
-  // maxlike() still answers (the engine keeps the running maximum).  One rank only: with several ranks the rows are
-  // gathered as usual.
+  // maxlike() still answers (the engine keeps the running maximum).  With several ranks the ranks' texts of a block
+  // are written in rank order, the row order of a dump.
   void text_only(bool on) { text_only_ = on; }
   bool text_only(void) const { return text_only_; }
-  void write_text(const char *text, std::size_t nbytes);              // (MCPar::run's text sink)
+  void write_text(const char *text, std::size_t nbytes);              // (MCPar::run's text sink; collective)
   void note_best(float lval, const float *params);                    // (the engine's running maximum)
   // COLLECTIVE: every rank of the communicator must call it.  Best sample over all ranks.
   const std::vector<float> &maxlike(float *lmax);

@@ -61,8 +61,38 @@ void MCout::note_row(const float *row)
   }
 }
 
+// COLLECTIVE with several ranks: the ranks' texts of one block reach the stream in rank order -- the row order of a dump
+// (src/mcout.cc:62-69: rank-major, then step, then chain)
 void MCout::write_text(const char *text, size_t nbytes)
 {
+#ifdef MCX_WITH_MPI
+  if (nranks_ > 1) {
+    if (nbytes > 0x7fffffffu) {
+      std::cerr << "MCout::write_text: a block of " << nbytes << " bytes does not fit an MPI message.  Aborting.\n";
+      MPI_Abort(MPI_COMM_WORLD, 1);
+    }
+    if (rank_ != 0) {
+      long long mine = static_cast<long long>(nbytes);
+      if (MPI_Send(&mine, 1, MPI_LONG_LONG, 0, 7101, comm_) != MPI_SUCCESS ||
+          MPI_Send(const_cast<char *>(text), static_cast<int>(nbytes), MPI_CHAR, 0, 7102, comm_) != MPI_SUCCESS) {
+        std::cerr << "Unable to send output text.  Aborting.\n";
+        MPI_Abort(MPI_COMM_WORLD, 1);
+      }
+      return;
+    }
+    if (sink_ && nbytes) sink_->write(text, static_cast<std::streamsize>(nbytes));
+    std::vector<char> theirs;
+    for (int r = 1; r < nranks_; ++r) {
+      long long n = 0;
+      if (MPI_Recv(&n, 1, MPI_LONG_LONG, r, 7101, comm_, MPI_STATUS_IGNORE) != MPI_SUCCESS) MPI_Abort(MPI_COMM_WORLD, 1);
+      theirs.resize(static_cast<size_t>(n) + 1);
+      if (MPI_Recv(theirs.data(), static_cast<int>(n), MPI_CHAR, r, 7102, comm_, MPI_STATUS_IGNORE) != MPI_SUCCESS)
+        MPI_Abort(MPI_COMM_WORLD, 1);
+      if (sink_ && n) sink_->write(theirs.data(), static_cast<std::streamsize>(n));
+    }
+    return;
+  }
+#endif
   if (rank_ == 0 && sink_ && nbytes) sink_->write(text, static_cast<std::streamsize>(nbytes));
 }
 
@@ -502,7 +532,7 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   else logname << "/dev/null";
   std::ofstream logfile(logname.str().c_str());
 
-  const bool as_text = outsamples.text_only() && !mpi;  // (several ranks: rows, gathered in rank order as usual)
+  const bool as_text = outsamples.text_only();  // (several ranks: MCout::write_text gathers the texts in rank order)
   try {
     if (!as_text) outsamples.newsamps(nsamp * nchain);  // src/mcpar.cc:31
   } catch (std::bad_alloc &) {

@@ -165,3 +165,10 @@ def test_two_mpi_ranks_through_the_facade(tmp_path):
             expect += fmt_rows(e.samples[lo * nc:hi * nc])
         lo = hi
     assert r.stdout == expect
+    # --stream-text on two ranks: every rank's blocks as text from its GPU, written by rank 0 in rank order: the same bytes
+    st = subprocess.run([MPIEXEC, "-n", "2", os.path.join(DRV, "mcpar-run-mpi"), "--func", "rosen1", "--np", str(np_),
+                         "--nc", str(nc), "--nsamp", str(nsamp), "--nburn", str(nburn), "--pl", str(pl), "--stream-text"],
+                        cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert st.returncode == 0, st.stderr[-2000:]
+    assert st.stdout == expect
+    assert st.stderr.split("max likelihood value:")[1] == r.stderr.split("max likelihood value:")[1]
