@@ -49,6 +49,11 @@ public:
   void text_only(bool on) { text_only_ = on; }
   bool text_only(void) const { return text_only_; }
   void write_text(const char *text, std::size_t nbytes);              // (MCPar::run's text sink; collective)
+  // (MCPar::run) would output() print the rows exactly as printf("%g") does -- a stream in its default state, no
+  // binary mode, nothing waiting to be printed?  Then the text of a block may come from the GPU next to its rows ...
+  bool prints_plain_text(void) const;
+  // ... and the rows stored so far count as printed
+  void mark_flushed(void) { flushed_ = fill_; }
   void note_best(float lval, const float *params);                    // (the engine's running maximum)
   // COLLECTIVE: every rank of the communicator must call it.  Best sample over all ranks.
   const std::vector<float> &maxlike(float *lmax);

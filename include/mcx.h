@@ -163,6 +163,8 @@ int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_steps);
  * two sinks at a time: setting one removes the other. */
 typedef int (*mcx_text_sink_fn)(void *ctx, int first_step, int nsteps, const char *text, size_t nbytes);
 int mcx_set_text_sink(mcx_engine *e, mcx_text_sink_fn fn, void *ctx, int block_steps);
+/* inside a row sink's callback of a run with MCX_OPT_SINK_TEXT: the same block as text (valid during the callback) */
+int mcx_sink_text(mcx_engine *e, const char **text, size_t *nbytes);
 
 /* ---- options ------------------------------------------------------------------------------ */
 enum {
@@ -202,6 +204,8 @@ enum {
                               at the gathered slots next -- mcx_get_musigall, the next run's first gather or publish,
                               mcx_synchronize, mcx_destroy -- waits for it.  1 [default], 0: mcx_run waits itself, 2: also with a
                               caller's exchange hook (whose MCX_XCHG_WAIT call then comes after mcx_run has returned) */
+  MCX_OPT_SINK_TEXT = 16,    /* a row sink (mcx_set_sink) also gets every block as text: inside the callback, mcx_sink_text
+                              returns the characters MCout::output would print for the block's rows [default 0] */
   MCX_OPT_DEBUG_MEET = 12    /* test hook: the meetings wait for `value` workgroups more than the grid has, i.e.
                               they can never complete [default 0] */
 };

@@ -73,6 +73,7 @@ def load():
         "mcx_set_output_hook": [vp, OUTFN, vp],
         "mcx_set_sink": [vp, SINKFN, vp, C.c_int],
         "mcx_set_text_sink": [vp, TEXTSINKFN, vp, C.c_int],
+        "mcx_sink_text": [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
         "mcx_set_option": [vp, C.c_int, C.c_int64],
         "mcx_get_counters": [vp, C.POINTER(Counters)],
         "mcx_get_state": [vp, fp], "mcx_get_loglike": [vp, fp], "mcx_get_mean": [vp, fp],

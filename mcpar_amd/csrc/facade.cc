@@ -96,6 +96,22 @@ void MCout::write_text(const char *text, size_t nbytes)
   if (rank_ == 0 && sink_ && nbytes) sink_->write(text, static_cast<std::streamsize>(nbytes));
 }
 
+static bool stream_prints_like_printf(const std::ostream &os)
+{
+  const std::ios_base::fmtflags special =
+      std::ios_base::floatfield | std::ios_base::showpoint | std::ios_base::showpos | std::ios_base::uppercase;
+  static const bool through_the_stream = getenv("MCPAR_TEXT") && !strcmp(getenv("MCPAR_TEXT"), "stream");  // (escape hatch)
+  return !through_the_stream && os.precision() == 6 && !(os.flags() & special) && os.width() == 0 &&
+         os.getloc() == std::locale::classic();
+}
+
+bool MCout::prints_plain_text(void) const
+{
+  if (binary_ || text_only_ || fill_ != flushed_) return false;
+  // (the stream lives on rank 0; the others follow its answer in MCPar::run)
+  return rank_ != 0 || (sink_ && stream_prints_like_printf(*sink_));
+}
+
 void MCout::note_best(float lval, const float *params)
 {
   if (lval > best_l_) {
@@ -149,11 +165,7 @@ void MCout::output()
   // a driver's time here, where the chain steps are on the GPU.  A stream in its default state (precision 6, no
   // floatfield / showpoint / showpos / uppercase, no pending width, "C" locale) prints a float as printf("%g"): those
   // characters come from fmtg6 (exact, tests/cpp/fmt_check.cc), rows cut into pieces for the host's threads.
-  const std::ios_base::fmtflags special =
-      std::ios_base::floatfield | std::ios_base::showpoint | std::ios_base::showpos | std::ios_base::uppercase;
-  static const bool through_the_stream = getenv("MCPAR_TEXT") && !strcmp(getenv("MCPAR_TEXT"), "stream");  // (escape hatch)
-  if (!through_the_stream && os.precision() == 6 && !(os.flags() & special) && os.width() == 0 &&
-      os.getloc() == std::locale::classic()) {
+  if (stream_prints_like_printf(os)) {
     const size_t w = static_cast<size_t>(width_), nrows = count / w;
     const size_t piece_rows = std::max<size_t>(1, (size_t(1) << 21) / w);  // ~2 M numbers (36 MB of text at most) per piece
     unsigned nthreads = std::thread::hardware_concurrency();
@@ -440,6 +452,7 @@ struct RunCtx {
   // optional per-step diagnostics of the reference (src/mcpar.cc:121-126, 129-139)
   bool logging, mpi;
   int logstep, syncstep, logged_upto, size0;
+  bool gpu_text;  // every block's text comes with its rows (MCX_OPT_SINK_TEXT): printed from it, the rows only stored
 };
 
 // The reference writes its `logging` diagnostics inside the step loop.  The steps run on the GPU in
@@ -476,11 +489,17 @@ int sample_sink(void *vctx, int first_step, int nsteps, const float *rows)
   c->out->add_rows(rows, (size_t)nsteps * c->nchain);
   c->copied_steps = steps_done;
   write_step_diagnostics(c, steps_done);  // iterations before this dump point
-  if (steps_done < c->nsamp) {
-    (*c->log) << "Beginning output at step " << steps_done << std::endl;
+  const char *text = 0;
+  size_t nbytes = 0;
+  const bool have_text = c->gpu_text && mcx_sink_text(c->eng, &text, &nbytes) == MCX_OK;
+  if (steps_done < c->nsamp) (*c->log) << "Beginning output at step " << steps_done << std::endl;
+  if (have_text) {  // the characters output() would produce for these rows, made on the GPU (the last block's too:
+    c->out->write_text(text, nbytes);  // its text exists only now; the run's final output() then finds nothing new)
+    c->out->mark_flushed();
+  } else if (steps_done < c->nsamp) {
     c->out->output();
-    (*c->log) << "Output finished\n" << std::endl;
   }
+  if (steps_done < c->nsamp) (*c->log) << "Output finished\n" << std::endl;
   return 0;
 }
 
@@ -544,8 +563,15 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   HostL hl = {&L};
   if (!L.device_descriptor(nparam, &f)) f = mcx_vlfunc{MCX_VL_HOST, nparam, 0, 0, host_tramp, &hl};
 
+  // the text of every block from the GPU next to its rows, when MCout::output would print plain printf("%g") text anyway
+  // (rank 0 knows its stream; with several ranks every rank follows its answer)
+  int gpu_text = (!as_text && outsamples.prints_plain_text()) ? 1 : 0;
+#ifdef MCX_WITH_MPI
+  if (mpi && comm) MPI_Bcast(&gpu_text, 1, MPI_INT, 0, comm->comm);
+#endif
+  mcx_set_option(eng, MCX_OPT_SINK_TEXT, gpu_text);
   RunCtx ctx = {eng,   &outsamples, &logfile, nchain,   nparam + 1, 0, nsamp, std::vector<float>(),
-                logging, mpi,        logstep,  SYNCSTEP, 0,          outsamples.size()};
+                logging, mpi,        logstep,  SYNCSTEP, 0,          outsamples.size(), gpu_text != 0};
   const int outstep = nsamp > 50 ? nsamp / 10 : 5;  // src/mcpar.cc:110
   if (as_text) mcx_set_text_sink(eng, text_sink, &ctx, outstep);
   else mcx_set_sink(eng, sample_sink, &ctx, outstep);
@@ -561,6 +587,7 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
 
   const int st = mcx_run(eng, nsamp, nburn, pinit, &f, incov);
   mcx_set_sink(eng, 0, 0, 0);
+  mcx_set_option(eng, MCX_OPT_SINK_TEXT, 0);
   if (st == MCX_OK) write_step_diagnostics(&ctx, nsamp);
 #ifdef MCX_WITH_MPI
   if (staged) mcx_set_exchange(eng, 0, 0);  // its context lives on this stack frame

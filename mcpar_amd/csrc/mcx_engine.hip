@@ -425,7 +425,7 @@ struct mcx_engine {
   int opt_bpl = 0;     // 4-parameter blocks per lane of the hot-path kernel: 0 auto, 1, 2, 4
   int opt_persist = -1;  // small-n mode, one launch per stretch of local steps (k_run_small): -1 auto, 0 off, 1 on
   int ncu = 0;           // compute units of the device (the persistent grid must be resident at once)
-  int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0, opt_async_tail = 1;
+  int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0, opt_async_tail = 1, opt_sink_text = 0;
   int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
   bool have_run = false, diag = true, xchg_pending = false;
   int published_steps = 0;  // main-loop steps reflected in this shard's musigall slot
@@ -446,6 +446,9 @@ struct mcx_engine {
   DevBuf<unsigned long long> sink_text_wg[2];  // per staging buffer: the text kernels' byte counts / offsets
   PinBuf<unsigned long long> sink_text_total[2];
   PinBuf<char> sink_text_pin;
+  bool run_sink_text = false;        // this run's row sink also gets every block's text (MCX_OPT_SINK_TEXT)
+  const char *cb_text = nullptr;     // valid while a sink callback runs: mcx_sink_text
+  size_t cb_text_bytes = 0;
   void *sctx = nullptr;
   int sink_block = 0;  // main-loop steps per block (0 = no sink: the whole run stays in HBM)
   bool run_sink = false;           // the current / last run streamed its samples
@@ -713,6 +716,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
     break;
   case MCX_OPT_PROFILE: e->opt_profile = value ? 1 : 0; break;
   case MCX_OPT_EAGER_EXCHANGE: e->opt_eager = value ? 1 : 0; break;
+  case MCX_OPT_SINK_TEXT: e->opt_sink_text = value ? 1 : 0; break;
   case MCX_OPT_ASYNC_TAIL: e->opt_async_tail = value == 2 ? 2 : (value ? 1 : 0); break;
   case MCX_OPT_SPLIT_RNG: e->opt_split = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_PERSIST: e->opt_persist = value < 0 ? -1 : (value ? 1 : 0); break;
@@ -1542,7 +1546,7 @@ static int sink_deliver(mcx_engine *e, int seq)
   HIPCHK(hipEventSynchronize(e->ev_copy[b]));
   const int first = seq * e->run_kb;  // kept steps before this block
   const int kept = std::min(e->run_kb, (e->last_sink_total - first));
-  if (e->tfn) {
+  if (e->tfn || e->run_sink_text) {
     // text sink: the block's byte count has arrived with the event; now that its size is known, the fields are
     // formatted once more into place (mcx_text.hpp) and copied out -- the staging buffer still holds the rows (the block
     // that reuses it is queued only after this call)
@@ -1555,10 +1559,17 @@ static int sink_deliver(mcx_engine *e, int seq)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(e->sink_text_pin.p, e->text_dev.p, total, hipMemcpyDeviceToHost, e->cstream));
     HIPCHK(hipStreamSynchronize(e->cstream));
-    if (e->tfn(e->sctx, first, kept, e->sink_text_pin.p, total) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
-    return MCX_OK;
+    if (e->tfn) {
+      if (e->tfn(e->sctx, first, kept, e->sink_text_pin.p, total) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
+      return MCX_OK;
+    }
+    e->cb_text = e->sink_text_pin.p;  // (row sink with MCX_OPT_SINK_TEXT: the callback asks mcx_sink_text for it)
+    e->cb_text_bytes = total;
   }
-  if (e->sfn(e->sctx, first, kept, e->sink_pin[b].p) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
+  const int rc = e->sfn(e->sctx, first, kept, e->sink_pin[b].p);
+  e->cb_text = nullptr;
+  e->cb_text_bytes = 0;
+  if (rc != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
   return MCX_OK;
 }
 
@@ -1582,16 +1593,16 @@ static int sink_block_done(mcx_engine *e, int done, int nsteps, int seq)
   hipLaunchKernelGGL(k_rows_interleave, dim3(nblocks(kept * n * (d + 1))), dim3(BLOCK), 0, e->cstream, sx, sl,
                      e->sink_stage[b].p, kept * n, d);
   HIPCHK(hipGetLastError());
-  if (e->tfn) {  // the size of the block's text (its two counting passes); sink_deliver places and copies it
+  if (e->tfn || e->run_sink_text) {  // the size of the block's text (its two counting passes); sink_deliver places and copies it
     const size_t count = kept * n * (size_t)(d + 1), nwg = (count + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(k_text_sizes, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
                        (const float *)nullptr, count, d, e->sink_text_wg[b].p);
     hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, e->cstream, e->sink_text_wg[b].p, nwg);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(e->sink_text_total[b].p, e->sink_text_wg[b].p + nwg, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->cstream));
-  } else {
-    HIPCHK(hipMemcpyAsync(e->sink_pin[b].p, e->sink_stage[b].p, kept * n * (d + 1) * sizeof(float), hipMemcpyDeviceToHost, e->cstream));
   }
+  if (!e->tfn)
+    HIPCHK(hipMemcpyAsync(e->sink_pin[b].p, e->sink_stage[b].p, kept * n * (d + 1) * sizeof(float), hipMemcpyDeviceToHost, e->cstream));
   HIPCHK(hipEventRecord(e->ev_copy[b], e->cstream));
   // the ring: block seq + SINK_RING - 1 will overwrite the slot of block seq - 1, whose copy is already waited for
   // two blocks from now at the latest; with SINK_RING = 4 the host-side wait above is the only synchronisation
@@ -1611,6 +1622,15 @@ extern "C" int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_
   e->tfn = nullptr;
   e->sctx = ctx;
   e->sink_block = fn ? block_steps : 0;
+  return MCX_OK;
+}
+
+extern "C" int mcx_sink_text(mcx_engine *e, const char **text, size_t *nbytes)
+{
+  if (!e || !text || !nbytes) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (!e->cb_text) return fail(MCX_ERR_INVALID, "no block text: call it from a sink callback of a run with MCX_OPT_SINK_TEXT");
+  *text = e->cb_text;
+  *nbytes = e->cb_text_bytes;
   return MCX_OK;
 }
 
@@ -1671,6 +1691,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   const int sblock = sink ? ((std::max(e->sink_block, 1) + e->opt_stride - 1) / e->opt_stride) * e->opt_stride : 0;
   const int kb = sink ? sblock / e->opt_stride : 0;
   e->run_sink = sink; e->run_sblock = sblock; e->run_kb = kb;
+  e->run_sink_text = sink && e->sfn != nullptr && e->opt_sink_text != 0;
   if (e->opt_samples && nsamp > 0) {
     const size_t rows = sink ? (size_t)std::min<long long>((long long)SINK_RING * kb, nkeep + kb) : (size_t)nkeep;
     int s1 = e->samp_x.alloc(rows * e->ntot), s2 = e->samp_ly.alloc(rows * n);
@@ -1681,12 +1702,11 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   if (sink) {
     for (int b = 0; b < 2; ++b) {
       MCXCHK(e->sink_stage[b].alloc((size_t)kb * n * (d + 1)));
-      if (e->tfn) {
+      if (e->tfn || e->opt_sink_text) {
         MCXCHK(e->sink_text_wg[b].alloc(((size_t)kb * n * (d + 1) + BLOCK - 1) / BLOCK + 1));
         MCXCHK(e->sink_text_total[b].alloc(1));
-      } else {
-        MCXCHK(e->sink_pin[b].alloc((size_t)kb * n * (d + 1)));
       }
+      if (!e->tfn) MCXCHK(e->sink_pin[b].alloc((size_t)kb * n * (d + 1)));
       if (!e->ev_steps[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_steps[b], hipEventDisableTiming));
       if (!e->ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_copy[b], hipEventDisableTiming));
     }

@@ -17,6 +17,7 @@ OPT_DEBUG_MEET = 12
 OPT_CULL = 13
 OPT_BLOCKS_PER_LANE = 14
 OPT_ASYNC_TAIL = 15
+OPT_SINK_TEXT = 16
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 
@@ -224,6 +225,12 @@ class Engine:
         cb = SINKFN(tramp)
         self._keep.append(cb)
         check(load().mcx_set_sink(self.h, cb, None, int(block_steps)))
+
+    def sink_text(self):
+        """inside a row sink's callback of a run with OPT_SINK_TEXT: the block's rows as text (bytes)"""
+        ptr, nb = C.c_void_p(0), C.c_size_t(0)
+        check(load().mcx_sink_text(self.h, C.byref(ptr), C.byref(nb)))
+        return C.string_at(ptr.value, nb.value) if nb.value else b""
 
     def set_text_sink(self, pyfn, block_steps):
         """pyfn(first_step, nsteps, text: bytes-like memoryview) -> 0: every block as the text MCout::output prints for it
