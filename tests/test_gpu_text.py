@@ -102,3 +102,38 @@ def test_text_sink_streams_the_text_of_the_rows(d, n, nburn, nsamp, pl, block, s
     eng.run(nsamp, nburn, p, vg)
     assert np.concatenate(rows).shape == eo.samples.shape
     eo.close()
+
+
+def test_row_sink_can_ask_for_its_blocks_text():
+    """MCX_OPT_SINK_TEXT: inside a row sink's callback mcx_sink_text gives the characters of exactly those rows; outside a
+    callback (or without the option) it is an error"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    d, n, nburn, nsamp, block = 16, 777, 60, 23, 5
+    vl, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eng = M.Engine(d, n, pl=0.9)
+    eng.set_option(E.OPT_SINK_TEXT, 1)
+    seen = []
+
+    def sink(first, nsteps, rows):
+        seen.append((rows.copy(), eng.sink_text()))
+        return 0
+    eng.set_sink(sink, block)
+    eng.run(nsamp, nburn, O.default_pinit(d, n), vl)
+    assert len(seen) == 5
+    for rows, text in seen:
+        assert text == libc_text(rows)
+    with pytest.raises(M.McxError):
+        eng.sink_text()
+    eng.set_option(E.OPT_SINK_TEXT, 0)
+    errors = []
+
+    def sink2(first, nsteps, rows):
+        try:
+            eng.sink_text()
+        except M.McxError:
+            errors.append(first)
+        return 0
+    eng.set_sink(sink2, block)
+    eng.run(nsamp, nburn, O.default_pinit(d, n), vl)
+    assert len(errors) == 5
