@@ -1552,19 +1552,23 @@ static int sink_deliver(mcx_engine *e, int seq)
     // that reuses it is queued only after this call)
     const size_t total = (size_t)e->sink_text_total[b].p[0];
     const size_t count = (size_t)kept * e->nchain * (size_t)(e->nparam + 1), nwg = (count + BLOCK - 1) / BLOCK;
-    MCXCHK(e->text_dev.alloc(total));
-    if (total > e->sink_text_pin.n) MCXCHK(e->sink_text_pin.alloc(total + total / 8));
-    hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
-                       (const float *)nullptr, count, e->nparam, (const unsigned long long *)e->sink_text_wg[b].p, e->text_dev.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(e->sink_text_pin.p, e->text_dev.p, total, hipMemcpyDeviceToHost, e->cstream));
-    HIPCHK(hipStreamSynchronize(e->cstream));
-    if (e->tfn) {
-      if (e->tfn(e->sctx, first, kept, e->sink_text_pin.p, total) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
-      return MCX_OK;
+    int arc = e->text_dev.alloc(total);
+    if (arc == MCX_OK && total > e->sink_text_pin.n) arc = e->sink_text_pin.alloc(total + total / 8);
+    if (arc != MCX_OK && e->tfn) return arc;
+    if (arc == MCX_OK) {
+      hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
+                         (const float *)nullptr, count, e->nparam, (const unsigned long long *)e->sink_text_wg[b].p, e->text_dev.p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(e->sink_text_pin.p, e->text_dev.p, total, hipMemcpyDeviceToHost, e->cstream));
+      HIPCHK(hipStreamSynchronize(e->cstream));
+      if (e->tfn) {
+        if (e->tfn(e->sctx, first, kept, e->sink_text_pin.p, total) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
+        return MCX_OK;
+      }
+      e->cb_text = e->sink_text_pin.p;  // (row sink with MCX_OPT_SINK_TEXT: the callback asks mcx_sink_text for it)
+      e->cb_text_bytes = total;
     }
-    e->cb_text = e->sink_text_pin.p;  // (row sink with MCX_OPT_SINK_TEXT: the callback asks mcx_sink_text for it)
-    e->cb_text_bytes = total;
+    // (a row sink whose block's text found no memory gets its rows all the same: mcx_sink_text then says so)
   }
   const int rc = e->sfn(e->sctx, first, kept, e->sink_pin[b].p);
   e->cb_text = nullptr;
