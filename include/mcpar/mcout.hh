@@ -38,7 +38,8 @@ public:
     rows_.resize(rows_.size() + static_cast<std::size_t>(nsamp) * width_);
   }
   void add(const float *pv, float lval);                   // one row
-  void add_rows(const float *rows, std::size_t nrows);     // nrows rows already in (np+1)-column layout
+  // nrows rows already in (np+1)-column layout; track_best = false: the caller reports the maximum itself (note_best)
+  void add_rows(const float *rows, std::size_t nrows, bool track_best = true);
 
   // ---- inspection ----------------------------------------------------------------------------
   int size(void) const { return stored_rows_; }            // rows stored

@@ -131,11 +131,27 @@ void MCout::add(const float *pv, float lval)
   ++stored_rows_;
 }
 
-void MCout::add_rows(const float *rows, size_t nrows)
+void MCout::add_rows(const float *rows, size_t nrows, bool track_best)
 {
   assert(fill_ + nrows * width_ <= rows_.size());
-  std::memcpy(&rows_[fill_], rows, nrows * width_ * sizeof(float));
-  for (size_t r = 0; r < nrows; ++r) note_row(rows + r * width_);
+  const size_t bytes = nrows * width_ * sizeof(float);
+  char *dst = reinterpret_cast<char *>(&rows_[fill_]);
+  const char *src = reinterpret_cast<const char *>(rows);
+  if (bytes < (size_t(64) << 20)) {
+    std::memcpy(dst, src, bytes);
+  } else {  // hundreds of megabytes into pages that are touched for the first time: one thread faults them in at ~3 GB/s
+    const unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 8u));
+    const size_t per = ((bytes / nt) + 4095) & ~size_t(4095);
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) {
+      const size_t a = std::min(bytes, t * per), b = std::min(bytes, a + per);
+      if (b > a) th.emplace_back([=] { std::memcpy(dst + a, src + a, b - a); });
+    }
+    std::memcpy(dst, src, std::min(bytes, per));
+    for (auto &x : th) x.join();
+  }
+  if (track_best)
+    for (size_t r = 0; r < nrows; ++r) note_row(rows + r * width_);
   fill_ += nrows * width_;
   stored_rows_ += static_cast<int>(nrows);
 }
@@ -486,7 +502,7 @@ int sample_sink(void *vctx, int first_step, int nsteps, const float *rows)
 {
   RunCtx *c = static_cast<RunCtx *>(vctx);
   const int steps_done = first_step + nsteps;
-  c->out->add_rows(rows, (size_t)nsteps * c->nchain);
+  c->out->add_rows(rows, (size_t)nsteps * c->nchain, false);  // (the running maximum comes from the engine: MCPar::run)
   c->copied_steps = steps_done;
   write_step_diagnostics(c, steps_done);  // iterations before this dump point
   const char *text = 0;
@@ -598,7 +614,7 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   }
   if (st != MCX_OK) die("MCPar::run");
   mcx_get_counters(eng, &counters);
-  if (as_text && nsamp > 0) {  // MCout saw no rows: its maxlike() answers from the engine's running maximum
+  if (nsamp > 0) {  // MCout's maxlike() answers from the engine's running maximum (first strict maximum, like MCout::add)
     float lbest = 0.0f;
     std::vector<float> pbest(static_cast<size_t>(nparam));
     if (mcx_samples_maxlike(eng, &lbest, pbest.data()) == MCX_OK) outsamples.note_best(lbest, pbest.data());
