@@ -66,8 +66,11 @@ def one_case(rng, idx):
     eg.set_option(E.OPT_SPLIT_RNG, split)
     eg.set_option(E.OPT_CULL, cull)
     eg.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
-    streamed = []
-    if sink:
+    streamed, texts = [], []
+    as_text = bool(sink) and rng.random() < 0.2 and n * nsamp * (d + 1) < 200000  # the blocks as text (mcx_set_text_sink)
+    if as_text:
+        eg.set_text_sink(lambda first, nsteps, text: texts.append((first, bytes(text))) and 0, sink)
+    elif sink:
         eg.set_sink(lambda first, nsteps, rows: streamed.append((first, rows.copy())) and 0, sink)
     eg.run(nsamp, nburn, p, vg, incov)
     c = eg.counters
@@ -82,6 +85,11 @@ def one_case(rng, idx):
         a, b = getattr(eg, name), getattr(eo, name)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, desc)
     want = eo.samples.reshape(nsamp, n, d + 1)[::stride].reshape(-1, d + 1) if nsamp else np.zeros((0, d + 1), np.float32)
+    if as_text:
+        from test_gpu_text import libc_text
+        assert [f for f, t in texts] == sorted(f for f, t in texts), desc
+        assert b"".join(t for f, t in texts) == libc_text(want), ("text", desc)
+        return
     if sink:
         assert [f for f, r in streamed] == sorted(f for f, r in streamed), desc
         got = np.concatenate([r for f, r in streamed]) if streamed else np.zeros((0, d + 1), np.float32)
