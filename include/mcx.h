@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 3
+#define MCX_ABI_VERSION 4
 
 typedef enum mcx_status {
   MCX_OK = 0,
@@ -192,7 +192,9 @@ enum {
   MCX_OPT_MEET_TIMEOUT_MS = 11, /* small-n mode: how long a tuner meeting of the one-launch kernel may wait for a
                               workgroup that is not resident (CU mask, partitioned device, foreign kernel) before
                               the launch is abandoned and the run repeated on the per-segment kernels (same bits;
-                              mcx_counters.meet_timeouts counts it) [default 2000] */
+                              mcx_counters.meet_timeouts counts it, MCX_VERBOSE=1 in the environment prints it; the engine
+                              keeps to the per-segment kernels for 16 runs, then tries again) [default 50: a healthy
+                              launch is 0.3-1.3 ms long and its meetings wait microseconds] */
   MCX_OPT_CULL = 13,       /* Murray sweeps: exclude, exactly, the Gaussians that are too far from all 128 chains of a
                               wavefront to matter (the chains are sorted spatially first; same bits).  -1 auto [default:
                               np = 16 or 32, >= 4096 chains still rejected, >= 4096 Gaussians], 0 off, 1 whenever np allows */
@@ -206,8 +208,13 @@ enum {
                               caller's exchange hook (whose MCX_XCHG_WAIT call then comes after mcx_run has returned) */
   MCX_OPT_SINK_TEXT = 16,    /* a row sink (mcx_set_sink) also gets every block as text: inside the callback, mcx_sink_text
                               returns the characters MCout::output would print for the block's rows [default 0] */
-  MCX_OPT_DEBUG_MEET = 12    /* test hook: the meetings wait for `value` workgroups more than the grid has, i.e.
-                              they can never complete [default 0] */
+  MCX_OPT_MEET_UNDER_GATHER = 17 /* small-n mode, sharded runs: may a launch with tuner meetings -- whose workgroups must all
+                              be resident at once -- start while this engine's own last gather is still in flight
+                              (MCX_OPT_ASYNC_TAIL)?  0: no, the step stream waits for the gather first: no cycle of a
+                              half-resident launch, its GPU's gather kernel and a peer's can form.  1: yes, the next
+                              run's burn-in runs under the gather; MCX_OPT_MEET_TIMEOUT_MS is then the net.  -1 auto
+                              [default] = 0 */
+  /* (12 is taken by a test hook that is not part of this header) */
 };
 int mcx_set_option(mcx_engine *e, int opt, int64_t value);
 
@@ -226,6 +233,13 @@ typedef struct mcx_counters {
                             cannot lower the running minimum) before any per-pair work */
   uint64_t meet_timeouts; /* runs repeated on the per-segment kernels because a tuner meeting of the one-launch
                             small-n kernel was abandoned (MCX_OPT_MEET_TIMEOUT_MS) */
+  /* ABI 4 */
+  uint64_t meet_timeouts_total; /* the same, over the engine's life (meet_timeouts is the last run's) */
+  uint64_t small_n_launches;    /* launches of the one-launch small-n kernel in the last run (0: per-segment kernels) */
+  uint64_t small_n_blocks_per_lane; /* 4-parameter blocks per lane those launches ran with (0 when there were none) */
+  uint64_t exchange_waits;      /* times the step stream was made to wait for a gather (src/mcpar.cc:127-140) that had
+                                   been begun earlier: the last run's waits, including a wait for the run before's tail */
+  uint64_t exchange_wait_ns;    /* device time the step stream spent in those waits (HIP events around each wait) */
 } mcx_counters;
 int mcx_get_counters(mcx_engine *e, mcx_counters *c);
 

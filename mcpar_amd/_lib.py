@@ -26,7 +26,9 @@ class VLFunc(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("naccept_burn", "naccept_main", "nsteps_burn", "nsteps_main",
                                           "remote_steps", "remote_passes", "exchanges", "kernel_launches",
-                                          "remote_pairs", "remote_pairs_evaluated", "meet_timeouts")]
+                                          "remote_pairs", "remote_pairs_evaluated", "meet_timeouts", "meet_timeouts_total",
+                                          "small_n_launches", "small_n_blocks_per_lane", "exchange_waits",
+                                          "exchange_wait_ns")]
 
 
 K_NAMES = ("fused_burn", "fused_main", "propose", "eval", "accept", "remote", "tuner", "misc", "remote_sweep",
@@ -42,7 +44,8 @@ class Profile(C.Structure):
 
 
 def lib_path():
-    return os.path.join(HERE, "libmcx.so")
+    # MCX_LIBMCX: another build of the same library (tools/persist_ab.py times variants of one kernel on one box)
+    return os.environ.get("MCX_LIBMCX") or os.path.join(HERE, "libmcx.so")
 
 
 _lib = None

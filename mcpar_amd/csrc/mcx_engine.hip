@@ -71,6 +71,10 @@ static int fail(int code, const char *fmt, ...)
 extern "C" const char *mcx_last_error(void) { return g_err.c_str(); }
 extern "C" int mcx_abi_version(void) { return MCX_ABI_VERSION; }
 
+// Test hook, not part of the public header: mcx_set_option(e, 12, k) makes the tuner meetings of the one-launch small-n
+// kernel wait for k workgroups more than the grid has, i.e. they can never complete (tests/test_gpu_small_n_safety.py).
+enum { MCX_OPT_DEBUG_MEET = 12 };
+
 static int need_device()
 {
   int n = 0;
@@ -416,7 +420,8 @@ struct mcx_engine {
   bool meet_check = false;   // a launch with meetings is in flight: its "abandoned" word has not been looked at yet
   unsigned long long *meet_word = nullptr;  // that word (ctr[5] of the run's counter block)
   bool persist_broken = false;  // a meeting was abandoned once on this engine: the one-launch kernel is not used again
-  int opt_meet_timeout_ms = 2000, opt_debug_meet = 0;
+  int opt_meet_timeout_ms = 50, opt_debug_meet = 0;
+  int opt_meet_under_gather = -1;  // may a launch with tuner meetings start under this engine's in-flight gather: -1 auto (= no), 0 no, 1 yes
   // run bookkeeping
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -461,6 +466,11 @@ struct mcx_engine {
   DevBuf<float> best_row;            // running maximum-likelihood sample: [0] = log-likelihood, [1..np] = parameters
   DevBuf<unsigned long long> best_key;  // scratch of the arg-max reduction
   mcx_counters cnt{};
+  uint64_t meet_total = 0;           // runs repeated because a meeting was abandoned, over the engine's life
+  int runs_since_broken = 0;         // runs on the per-segment kernels since then (the one-launch kernel is tried again)
+  // time the step stream waits for gathers begun earlier (mcx_counters.exchange_wait_ns): event pairs around each wait
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> xw_pool;
+  size_t xw_used = 0;
   std::vector<EvPair> evs;
   mcx_profile prof{};
 };
@@ -673,6 +683,10 @@ extern "C" int mcx_destroy(mcx_engine *e)
     if (e->ev_copy[b]) (void)hipEventDestroy(e->ev_copy[b]);
   }
   e->best_row.release(); e->best_key.release(); e->cov0.release(); e->sink_text_pin.release();
+  for (auto &pr : e->xw_pool) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
   if (e->meet_fd >= 0) (void)close(e->meet_fd);
   if (e->cstream) (void)hipStreamDestroy(e->cstream);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -729,6 +743,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
     if (value < 1) return fail(MCX_ERR_INVALID, "MEET_TIMEOUT_MS must be >= 1");
     e->opt_meet_timeout_ms = (int)std::min<int64_t>(value, 600000);
     break;
+  case MCX_OPT_MEET_UNDER_GATHER: e->opt_meet_under_gather = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_DEBUG_MEET:
     e->opt_debug_meet = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
     e->persist_broken = false;  // (a test switching the hook off again gets the one-launch kernel back)
@@ -1087,14 +1102,38 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
 
 static int meet_release(mcx_engine *e, bool stream_is_idle);
 
+constexpr size_t XW_MAX = 256;  // waits of one run that are timed (a job has one per Murray step at most)
+
 static int exchange_wait(mcx_engine *e)
 {
   if (!e->xchg_pending) return MCX_OK;
   MCXCHK(meet_release(e, false));
   e->xchg_pending = false;
+  // the wait as the step stream sees it: an event on either side (collected by xwait_collect once the stream is idle)
+  const bool timed = e->xw_used < XW_MAX;
+  if (timed && e->xw_used == e->xw_pool.size()) {
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    e->xw_pool.emplace_back(a, b);
+  }
+  if (timed) HIPCHK(hipEventRecord(e->xw_pool[e->xw_used].first, e->stream));
   if (e->xfn(e->xctx, MCX_XCHG_WAIT, e->musigall.p, 2 * (size_t)e->ntot, e->rank, e->size, e->stream) != 0)
     return fail(MCX_ERR_EXCHANGE, "exchange hook failed in WAIT");
+  if (timed) HIPCHK(hipEventRecord(e->xw_pool[e->xw_used++].second, e->stream));
+  e->cnt.exchange_waits++;
   return MCX_OK;
+}
+
+// the step stream is idle: add up what the timed waits took
+static void xwait_collect(mcx_engine *e)
+{
+  for (size_t i = 0; i < e->xw_used; ++i) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, e->xw_pool[i].first, e->xw_pool[i].second) == hipSuccess && ms > 0.0f)
+      e->cnt.exchange_wait_ns += (uint64_t)((double)ms * 1e6);
+  }
+  e->xw_used = 0;
 }
 
 // write this shard's slot from the resident moments after `steps_done` main-loop steps
@@ -1125,6 +1164,7 @@ static int finish_tail(mcx_engine *e)
   MCXCHK(exchange_wait(e));
   MCXCHK(publish(e, steps));
   HIPCHK(hipStreamSynchronize(e->stream));
+  xwait_collect(e);
   return MCX_OK;
 }
 
@@ -1649,6 +1689,7 @@ extern "C" int mcx_set_text_sink(mcx_engine *e, mcx_text_sink_fn fn, void *ctx, 
 }
 
 static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L, const float *incov);
+constexpr int PERSIST_RETRY_RUNS = 16;
 
 extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L,
                        const float *incov)
@@ -1662,11 +1703,18 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     // the step counter has not moved: repeat the run on the per-segment kernels (same bits), and keep to them.
     (void)hipStreamSynchronize(e->stream);
     e->persist_broken = true;
+    e->runs_since_broken = 0;
+    e->meet_total++;
     repeated = 1;
+    if (getenv("MCX_VERBOSE"))
+      fprintf(stderr, "mcx: a tuner meeting of the one-launch small-n kernel was abandoned after %d ms (a workgroup of its grid "
+                      "was not resident); the run is repeated on the per-segment kernels\n", e->opt_meet_timeout_ms);
     rc = run_once(e, nsamp, nburn, pinit, L, incov);
     if (rc == MCX_INTERNAL_MEET_ABANDONED) rc = fail(MCX_ERR_HIP, "internal: meeting abandoned without the one-launch kernel");
   }
   e->cnt.meet_timeouts = repeated;
+  // whatever kept a workgroup out may be gone: the one-launch kernel is tried again after PERSIST_RETRY_RUNS runs
+  if (e->persist_broken && !repeated && rc == MCX_OK && ++e->runs_since_broken >= PERSIST_RETRY_RUNS) e->persist_broken = false;
   if (rc != MCX_OK) {  // never leave the GPU's meeting lock behind a failed run
     if (e->meet_held) {
       (void)hipStreamSynchronize(e->stream);
@@ -1744,11 +1792,13 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   // Small-n mode, one launch per stretch of local steps (mcx_persist.hpp): the whole burn-in with its tuner
   // events, the start of the main loop and every run of consecutive local main-loop segments go to k_run_small
   // when the chains fill at most POWN_MAX wavefronts per CU and the hot-path kernel applies.
-  const int nown = (int)(((size_t)n * e->lpc + 63) / 64);
+  // (with two 4-parameter blocks per lane where that takes a workgroup from two or more owner wavefronts towards one)
+  const int pbpl = mcxk_persist_bpl(e->lpc, d, n, e->ncu, e->opt_bpl), plpc2 = e->lpc / pbpl;
+  const int nown = (int)(((size_t)n * plpc2 + 63) / 64);
   const bool fast_lik = e->lik.kind == LIK_ROSEN1 || e->lik.kind == LIK_GAUSS || (e->lik.kind == LIK_MIX && e->lik.ncomp <= 8);
   const bool persist = fused && e->lpc <= 8 && fast_lik && e->diag && e->vec4 && !e->opt_mask && e->ncu > 0 &&
                        nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
-                       mcxk_persist_lds_bytes(e->lpc, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
+                       mcxk_persist_lds_bytes(plpc2, pbpl, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
                        (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0)) && !e->persist_broken &&
                        (nburn == 0 || meet_lock_open(e));
   // When the run opens with such a launch, the launch itself takes the initial state (and its likelihood,
@@ -1818,6 +1868,15 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
           ++pj;
         }
       }
+      if (e->xchg_pending && pb > 0 && e->opt_meet_under_gather <= 0) {
+        // The last run's final gather is still in flight (finish_tail) and this launch has tuner meetings: every one
+        // of its workgroups must become resident while the gather's kernel holds whatever it holds -- and that kernel
+        // may itself be waiting for a peer GPU whose gather kernel cannot start beside the peer's small-n launch.  No
+        // such cycle can form if the launch with meetings starts behind the gather: the step stream waits for it here
+        // (MCX_OPT_MEET_UNDER_GATHER = 1 lets the burn-in run under the gather instead; the meetings' timeout is then
+        // the net).  Launches without meetings have no workgroup waiting for another and need no such care.
+        MCXCHK(exchange_wait(e));
+      }
       if (e->xchg_pending && pb > 0 && pm > 0 && snap >= 0) {
         // The last run's final gather is still in flight (finish_tail) and this stretch will rewrite the slot it
         // reads: the burn-in, which does not touch the slot, goes first in a launch of its own and runs under the
@@ -1832,7 +1891,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         ra.samp_x = ra.samp_ly = nullptr;
         if (e->opt_samples && pm > 0) samp_vbase(e, is0, &ra.samp_x, &ra.samp_ly);
         ra.samp_stride = e->opt_stride;
-        MCXCHK(e->trash.alloc(4 * (size_t)PBLOCK * (size_t)std::max(e->ncu, 1)));
+        MCXCHK(e->trash.alloc((size_t)PTRASH * (size_t)PBLOCK * (size_t)std::max(e->ncu, 1)));
         ra.trash = e->trash.p;
         ra.lik = e->lik.params.p; ra.ncomp = e->lik.ncomp; ra.n = n; ra.d = d; ra.g0 = g0; ra.seed = e->seed;
         ra.t0 = pb > 0 ? e->tbase : e->tbase + (uint32_t)nburn + (uint32_t)is0;
@@ -1856,7 +1915,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         ra.nown = nown;
         const int nwg = std::min(nown, e->ncu);
         ra.own = (nown + nwg - 1) / nwg;
-        ra.ksteps = mcxk_persist_ksteps(e->lpc, ra.own);
+        ra.ksteps = mcxk_persist_ksteps(plpc2, pbpl, ra.own);
         ra.meet_timeout = (unsigned long long)e->opt_meet_timeout_ms * 100000ull;  // s_memrealtime: 100 MHz
         ra.meet_expect_extra = e->opt_debug_meet;
         if (snap >= 0) {  // the kernel rewrites this shard's slot: no gather may still be reading it
@@ -1874,7 +1933,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         if (pb > 0) MCXCHK(meet_lock_take(e));
         {
           ProfScope ps(e, MCX_K_RUN_SMALL, (uint64_t)(pb + pm) * n);
-          const hipError_t le = mcxk_launch_persist(e->lpc, e->lik.kind, ra, st);
+          const hipError_t le = mcxk_launch_persist(e->lpc, pbpl, e->lik.kind, ra, st);
           if (le != hipSuccess) (void)meet_release(e, true);
           if (le == hipErrorCooperativeLaunchTooLarge) {  // the grid cannot be resident at once on this device
             (void)hipGetLastError();
@@ -1885,6 +1944,8 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
             e->meet_check = true;
             e->meet_word = ctrp + 5;
           }
+          e->cnt.small_n_launches++;
+          e->cnt.small_n_blocks_per_lane = (uint64_t)pbpl;
         }
         pi = pj - 1;
         continue;
@@ -2056,6 +2117,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   }
   e->cnt.naccept_burn = hctr[3];
   e->cnt.naccept_main = hctr[4];
+  xwait_collect(e);
   if (sink) MCXCHK(sink_drain(e, sink_seq));
   e->samp_steps = (e->opt_samples && !sink) ? nkeep : 0;
   e->last_nsamp = nsamp;
@@ -2203,6 +2265,7 @@ extern "C" int mcx_get_counters(mcx_engine *e, mcx_counters *c)
 {
   if (!e || !c) return fail(MCX_ERR_INVALID, "bad arguments");
   *c = e->cnt;
+  c->meet_timeouts_total = e->meet_total;
   return MCX_OK;
 }
 extern "C" int mcx_get_state(mcx_engine *e, float *v) { return d2h(e, v, e ? e->pvals.p : nullptr, e ? (size_t)e->ntot : 0); }

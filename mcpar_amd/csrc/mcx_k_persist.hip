@@ -9,11 +9,33 @@ using namespace mcx;
 
 // recorders (one per owner) where the owner's latency is the bound, not the generators' throughput: measured
 // faster with one or two owner wavefronts per workgroup, equal with three, slower with four
-bool mcxk_persist_recorders(int own) { return own <= 2; }
-
-static size_t lds_for(int lpc, int own, int rec, int K)
+bool mcxk_persist_recorders(int own)
 {
-  return (size_t)2 * (1 + rec) * K * own * 64 * sizeof(float4) + (size_t)2 * (1 + rec) * K * own * (64 / lpc) * sizeof(float);
+  static const char *env = getenv("MCX_PERSIST_REC");  // tuning only (tools/persist_sweep.py)
+  if (env && *env) return atoi(env) != 0;
+  return own <= 2;
+}
+
+static size_t lds_for(int lpc2, int bpl, int own, int rec, int K)
+{
+  return (size_t)2 * (1 + rec) * K * own * bpl * 64 * sizeof(float4) + (size_t)2 * (1 + rec) * K * own * (64 / lpc2) * sizeof(float);
+}
+
+// Blocks per lane (mcx_persist.hpp): two where that halves the owner wavefronts of a workgroup that would hold two or
+// more -- one owner wavefront per workgroup is the regime in which a step costs one wavefront's dependent chain and
+// nothing else -- and the chain's parameters split into 8-parameter lanes.  `opt` = MCX_OPT_BLOCKS_PER_LANE.
+int mcxk_persist_bpl(int lpc, int d, int n, int ncu, int opt)
+{
+  auto legal = [&](int bpl) { return bpl >= 1 && bpl <= lpc && d % (4 * bpl) == 0; };
+  if (opt > 0) return legal(opt) && (opt == 1 || opt == 2 || opt == 4) ? opt : 1;
+  int bpl = 1;
+  while (bpl < 2 && legal(2 * bpl)) {
+    const int nown = (int)(((size_t)n * (size_t)(lpc / bpl) + 63) / 64);
+    const int nwg = std::max(std::min(nown, ncu), 1);
+    if ((nown + nwg - 1) / nwg < 2) break;
+    bpl *= 2;
+  }
+  return bpl;
 }
 
 // Steps per phase.  The default is the generators' count (16 - owners - recorders); with 1-3 owners per workgroup
@@ -23,78 +45,83 @@ static size_t lds_for(int lpc, int own, int rec, int K)
 // 14 -> 0.395, 16 -> 0.382; 16-D x 12 288 (3 owners) 13 -> 0.548, 16 -> 0.547, 18 -> 0.508, 20 -> 0.501, 22 -> 0.522;
 // 16-D x 16 384 (4 owners) 8 -> 0.750, 10 -> 0.725, 12 -> 0.661, 14 -> 0.663, 16 -> 0.655.  The pattern is not monotonic: how the
 // phase's items (a two-step item per owner and step pair, one acceptance item per owner) deal out over the filling
-// wavefronts matters as much as the phase count.
-int mcxk_persist_ksteps(int lpc, int own)
+// wavefronts matters as much as the phase count.  With bpl blocks per lane an owner stands for bpl owners' worth of
+// items and LDS.
+int mcxk_persist_ksteps(int lpc2, int bpl, int own)
 {
   const int rec = mcxk_persist_recorders(own) ? 1 : 0;
-  int k = own == 1 ? 32 : (own == 2 ? 16 : (own == 3 ? 20 : (own == 4 ? 16 : PWAVES - own - rec * own)));
-  while (k > 2 && (k > PKMAX || lds_for(lpc, own, rec, k) > MCXK_PERSIST_LDS_LIMIT)) k -= 2;
+  const int eff = own * bpl;  // the table goes by the generators' load
+  int k = eff == 1 ? 32 : (eff == 2 ? 16 : (eff == 3 ? 20 : (eff == 4 ? 16 : std::max(PWAVES - own - rec * own, 2))));
+  static const char *env = getenv("MCX_PERSIST_KSTEPS");  // tuning only (tools/persist_sweep.py)
+  if (env && *env) k = std::max(atoi(env), 2);
+  while (k > 2 && (k > PKMAX || lds_for(lpc2, bpl, own, rec, k) > MCXK_PERSIST_LDS_LIMIT)) k -= 2;
   return k;
 }
 
-size_t mcxk_persist_lds_bytes(int lpc, int own)
+size_t mcxk_persist_lds_bytes(int lpc2, int bpl, int own)
 {
-  return lds_for(lpc, own, mcxk_persist_recorders(own) ? 1 : 0, mcxk_persist_ksteps(lpc, own));
+  return lds_for(lpc2, bpl, own, mcxk_persist_recorders(own) ? 1 : 0, mcxk_persist_ksteps(lpc2, bpl, own));
 }
 
-template <int LPC, int LIK, bool REC>
+template <int LPC2, int BPL, int LIK, bool REC>
 static hipError_t go2(const RunArgs &a, hipStream_t st)
 {
   static bool attr_set = false;  // per instantiation; the value is the largest the kernel can be launched with
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run_small<LPC, LIK, REC>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run_small<LPC2, BPL, LIK, REC>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)MCXK_PERSIST_LDS_LIMIT);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const unsigned nwg = (unsigned)((a.nown + a.own - 1) / a.own);
-  const size_t lds = mcxk_persist_lds_bytes(LPC, a.own);
+  const size_t lds = mcxk_persist_lds_bytes(LPC2, BPL, a.own);
   if (a.nburn > 0) {
     // tuner meetings inside: every workgroup of the grid must be resident at once.  What the occupancy
-    // calculator and the device's CU count promise is checked here; what they cannot see (a CU mask, a foreign
-    // kernel holding LDS) is caught by the meetings' own timeout.
-    static size_t asked_lds = ~(size_t)0;  // (per instantiation: the answer depends on the LDS request only)
-    static int asked_per_cu = 0;
-    int per_cu = asked_per_cu, ncu = 0, dev = 0;
-    hipError_t e = hipSuccess;
-    if (asked_lds != lds) {
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_run_small<LPC, LIK, REC>), PBLOCK, lds);
-      if (e == hipSuccess) { asked_per_cu = per_cu; asked_lds = lds; }
-    }
+    // calculator and the device's CU count promise is checked here (asked again per launch: it is a table lookup in
+    // the runtime, and engines on several devices and threads share this code); what they cannot see (a CU mask, a
+    // foreign kernel holding LDS) is caught by the meetings' own timeout.
+    int per_cu = 0, ncu = 0, dev = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_run_small<LPC2, BPL, LIK, REC>), PBLOCK, lds);
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
     if ((long long)per_cu * ncu < (long long)nwg) return hipErrorCooperativeLaunchTooLarge;
   }
-  hipLaunchKernelGGL((k_run_small<LPC, LIK, REC>), dim3(nwg), dim3(PBLOCK), lds, st, a);
+  hipLaunchKernelGGL((k_run_small<LPC2, BPL, LIK, REC>), dim3(nwg), dim3(PBLOCK), lds, st, a);
   return hipGetLastError();
 }
 
-template <int LPC, int LIK>
+template <int LPC2, int BPL, int LIK>
 static hipError_t go(const RunArgs &a, hipStream_t st)
 {
-  return mcxk_persist_recorders(a.own) ? go2<LPC, LIK, true>(a, st) : go2<LPC, LIK, false>(a, st);
+  return mcxk_persist_recorders(a.own) ? go2<LPC2, BPL, LIK, true>(a, st) : go2<LPC2, BPL, LIK, false>(a, st);
 }
 
-template <int LPC>
+template <int LPC2, int BPL>
 static hipError_t by_lik(int lik, const RunArgs &a, hipStream_t st)
 {
   switch (lik) {
-  case LIK_ROSEN1: return go<LPC, LIK_ROSEN1>(a, st);
-  case LIK_GAUSS: return go<LPC, LIK_GAUSS>(a, st);
-  case LIK_MIX: return go<LPC, LIK_MIX>(a, st);
+  case LIK_ROSEN1: return go<LPC2, BPL, LIK_ROSEN1>(a, st);
+  case LIK_GAUSS: return go<LPC2, BPL, LIK_GAUSS>(a, st);
+  case LIK_MIX: return go<LPC2, BPL, LIK_MIX>(a, st);
   default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t mcxk_launch_persist(int lpc, int lik, const RunArgs &a, hipStream_t st)
+// lpc = 4-parameter blocks per chain (a power of two), bpl of them per lane
+hipError_t mcxk_launch_persist(int lpc, int bpl, int lik, const RunArgs &a, hipStream_t st)
 {
-  switch (lpc) {
-  case 1: return by_lik<1>(lik, a, st);
-  case 2: return by_lik<2>(lik, a, st);
-  case 4: return by_lik<4>(lik, a, st);
-  case 8: return by_lik<8>(lik, a, st);
+  switch (bpl * 16 + lpc / bpl) {
+  case 16 + 1: return by_lik<1, 1>(lik, a, st);
+  case 16 + 2: return by_lik<2, 1>(lik, a, st);
+  case 16 + 4: return by_lik<4, 1>(lik, a, st);
+  case 16 + 8: return by_lik<8, 1>(lik, a, st);
+  case 32 + 1: return by_lik<1, 2>(lik, a, st);
+  case 32 + 2: return by_lik<2, 2>(lik, a, st);
+  case 32 + 4: return by_lik<4, 2>(lik, a, st);
+  case 64 + 1: return by_lik<1, 4>(lik, a, st);
+  case 64 + 2: return by_lik<2, 4>(lik, a, st);
   default: return hipErrorInvalidValue;
   }
 }

@@ -18,7 +18,9 @@ hipError_t mcxk_launch_generic_main(int lpc, int lik, const mcx::SegArgs &a, hip
 // small-n mode, one launch per stretch of local steps (mcx_persist.hpp); every workgroup must be resident:
 // ceil(a.nown / a.own) <= number of CUs, 1 <= a.own <= POWN_MAX
 namespace mcx { struct RunArgs; }
-hipError_t mcxk_launch_persist(int lpc, int lik, const mcx::RunArgs &a, hipStream_t st);                // mcx_k_persist.hip
-size_t mcxk_persist_lds_bytes(int lpc, int own);
-int mcxk_persist_ksteps(int lpc, int own);
+// lpc = 4-parameter blocks per chain, bpl of them per lane (mcxk_persist_bpl's choice: 1, 2 or 4), lpc2 = lpc / bpl
+hipError_t mcxk_launch_persist(int lpc, int bpl, int lik, const mcx::RunArgs &a, hipStream_t st);        // mcx_k_persist.hip
+int mcxk_persist_bpl(int lpc, int d, int n, int ncu, int opt);
+size_t mcxk_persist_lds_bytes(int lpc2, int bpl, int own);
+int mcxk_persist_ksteps(int lpc2, int bpl, int own);
 constexpr size_t MCXK_PERSIST_LDS_LIMIT = (size_t)152 << 10;  // dynamic LDS a launch may ask for (160 KB per CU less the static part)

@@ -1,4 +1,4 @@
-// mcx_persist.hpp -- small-n mode, one launch per run: k_run_small<LPC, LIK>.
+// mcx_persist.hpp -- small-n mode, one launch per run: k_run_small<LPC2, BPL, LIK, REC>.
 //
 // With few chains (fewer wavefronts than SIMDs) a Metropolis step is bound by the latency of ONE wave's
 // instruction stream, and every kernel boundary (tuner checks, chunk changes) costs more than the steps it
@@ -37,12 +37,21 @@
 #pragma once
 #include "mcx_device.hpp"
 
+// How an abandoned tuner meeting is handled inside the step loop (an A/B switch for tools/meet_ab.sh; 2 ships):
+//   0  meetings wait without a bound (round 2; not safe -- measurement only)
+//   1  bounded wait, the owner leaves its step loop on the spot (round 3)
+//   2  bounded wait, the owner goes on to the end of its phase with a zero count (no extra loop exit)
+#ifndef MCX_MEET_VARIANT
+#define MCX_MEET_VARIANT 2
+#endif
+
 namespace mcx {
 
 constexpr int PBLOCK = 1024;          // 16 wavefronts: 4 per SIMD of one CU
 constexpr int PWAVES = PBLOCK / 64;
 constexpr int POWN_MAX = 8;           // owner wavefronts per workgroup: measured 1.2-3x faster than the fused kernels up to 6, equal at 7-8 (tools/persist_sweep.py)
 constexpr int PKMAX = 32;             // most steps per phase (LDS double buffers hold 2 phases)
+constexpr int PTRASH = 16;           // floats of RunArgs::trash per thread of the grid (a float4 per block of the lane)
 constexpr int PEVENTS = 64;           // tuner events (steps 51, 101, ... and the end of the burn-in) one launch can hold
 
 struct RunArgs {
@@ -54,7 +63,7 @@ struct RunArgs {
   uint32_t *acc_cnt;
   float *T;                 // [d][d] Cholesky factor, diagonal here; rescaled in place when the launch ends
   float *samp_x, *samp_ly;  // sample store of the run (row 0 = main step 0 / kept step 0), or null
-  float *trash;             // 16 B per thread of the grid: where lanes that own no parameters dump their stores
+  float *trash;             // PTRASH floats per thread of the grid: where lanes that own no parameters dump their stores
   int samp_stride;
   const float *lik;
   int ncomp;
@@ -103,6 +112,12 @@ __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *wo
       // compiler's s_waitcnt bookkeeping and put vmcnt waits -- on the previous step's stores -- into the step loop)
       const unsigned long long add = (1ull << 40) | (unsigned long long)s;
       unsigned long long v = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+#if MCX_MEET_VARIANT == 0
+      while ((int)(v >> 40) < nwg) {
+        __builtin_amdgcn_s_sleep(4);
+        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#else
       if ((int)((v & ~MEET_ABORT_BIT) >> 40) < nwg && !(v & MEET_ABORT_BIT)) {
         // bounded wait: the constant-rate wall clock, looked at once per 64 polls (reading it is a scalar memory
         // operation of its own: once per poll it stretched every meeting of a healthy run)
@@ -120,6 +135,7 @@ __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *wo
           }
         } while (!(v & MEET_ABORT_BIT));
       }
+#endif
       total = (v & MEET_ABORT_BIT) ? MEET_ABORTED : (v & ((1ull << 40) - 1ull));
       __hip_atomic_store(lds_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
@@ -135,10 +151,15 @@ __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *wo
   return ((unsigned long long)hi << 32) | lo;
 }
 
-template <int LPC, int LIK, bool REC>
+// LPC2 lanes per chain, each holding BPL consecutive 4-parameter blocks (LPC = LPC2 * BPL blocks per chain).  BPL = 2
+// (d % 8 == 0) halves the owner wavefronts: the per-chain part of a step (acceptance test, selects, counters, ballot) is
+// paid once per two blocks, the first stage of the butterfly over the block index is an in-lane add --
+// the same pair, the same sum -- and Philox counters go by block index whichever lane holds the block: same bits.
+template <int LPC2, int BPL, int LIK, bool REC>
 __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
 {
   static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX, "hot-path likelihoods only");
+  static_assert(BPL == 1 || BPL == 2 || BPL == 4, "one, two or four blocks per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ __attribute__((aligned(16))) float lds_means[LIK == LIK_MIX ? 8 * MAXD_LDS : 4];
   __shared__ float lds_logw[8];
@@ -157,9 +178,10 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   const int nphase = (T + K - 1) / K;
   const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
   const bool owner = wv < OWN, recorder = REC && !owner && wv < 2 * OWN;
-  // LDS double buffers, by phase parity: zbuf / xbuf [2][K][OWN][64] float4, ubuf / lbuf [2][K][OWN][64/LPC] float
-  constexpr int CPW = 64 / LPC;  // chains per owner wavefront
-  const size_t nz = (size_t)2 * K * OWN * 64, nu = (size_t)2 * K * OWN * CPW;
+  // LDS double buffers, by phase parity: zbuf / xbuf [2][K][OWN][BPL][64] float4, ubuf / lbuf [2][K][OWN][64/LPC2] float
+  constexpr int CPW = 64 / LPC2;  // chains per owner wavefront
+  const int OB = OWN * BPL;       // (owner, block of the lane) pairs of the workgroup
+  const size_t nz = (size_t)2 * K * OB * 64, nu = (size_t)2 * K * OWN * CPW;
   float4 *zbuf = reinterpret_cast<float4 *>(lds_raw);
   float4 *xbuf = zbuf + nz;  // (REC only)
   float *ubuf = reinterpret_cast<float *>(zbuf + (REC ? 2 : 1) * nz);
@@ -169,30 +191,32 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   // ---- generator side -------------------------------------------------------------------------------------
   // The work of one phase is a list of items dealt round-robin to the `nfill` waves that fill in this
   // iteration (a counter in LDS was measured slower: ~40 same-address atomics per phase serialise).
-  const int fq = lane % LPC, fcl = lane / LPC;  // this lane's parameter block and chain within an owner wavefront
+  const int fq = lane % LPC2, fcl = lane / LPC2;  // this lane's place in its chain and its chain within an owner wavefront
   auto fill = [&](int phase, int me_fill, int nfill) {
     const int buf = phase & 1, tau0 = phase * K;
     const int ns = T - tau0 < K ? T - tau0 : K;  // steps [tau0, tau0 + ns)
-    // normals: one item = TWO consecutive steps of one owner (two independent Philox / Box-Muller chains per
-    // lane: the lone instruction streams of 3-4 waves do not fill a SIMD otherwise)
-    const int npair = (ns + 1) >> 1, nz_items = npair * OWN;
-    const int dq = nfill / OWN, dr = nfill - dq * OWN;
-    int gp = me_fill / OWN, o = me_fill - gp * OWN;  // item i = (step pair gp, owner o), i = gp * OWN + o
+    // normals: one item = TWO consecutive steps of one block-per-lane set of one owner (two independent Philox /
+    // Box-Muller chains per lane: the lone instruction streams of 3-4 waves do not fill a SIMD otherwise)
+    const int npair = (ns + 1) >> 1, nz_items = npair * OB;
+    const int dq = nfill / OB, dr = nfill - dq * OB;
+    int gp = me_fill / OB, ob = me_fill - gp * OB;  // item i = (step pair gp, owner o, block b), i = (gp * OWN + o) * BPL + b
     for (int i = me_fill; i < nz_items; i += nfill) {
+      const int o = ob / BPL, b = ob % BPL;
       const int chain = ((int)blockIdx.x * OWN + o) * CPW + fcl;
-      if (chain < a.n && 4 * fq < d) {
+      const int qb = fq * BPL + b;  // the block's index within the chain
+      if (chain < a.n && 4 * qb < d) {
         const int g0s = 2 * gp;
         const uint32_t t = a.t0 + (uint32_t)(tau0 + g0s), gch = a.g0 + (uint32_t)chain;
         f32x2 ze, zo, ye, yo;
-        normal4_packed(philox4x32_10(t, gch, (uint32_t)fq, 0u, a.seed, ST_LOCAL), ze, zo);
-        normal4_packed(philox4x32_10(t + 1u, gch, (uint32_t)fq, 0u, a.seed, ST_LOCAL), ye, yo);
-        float4 *dst = zbuf + ((size_t)(buf * K + g0s) * OWN + o) * 64 + lane;
+        normal4_packed(philox4x32_10(t, gch, (uint32_t)qb, 0u, a.seed, ST_LOCAL), ze, zo);
+        normal4_packed(philox4x32_10(t + 1u, gch, (uint32_t)qb, 0u, a.seed, ST_LOCAL), ye, yo);
+        float4 *dst = zbuf + ((size_t)(buf * K + g0s) * OB + ob) * 64 + lane;
         dst[0] = make_float4(ze.x, ze.y, zo.x, zo.y);  // (even pair, odd pair)
-        if (g0s + 1 < ns) dst[(size_t)OWN * 64] = make_float4(ye.x, ye.y, yo.x, yo.y);
+        if (g0s + 1 < ns) dst[(size_t)OB * 64] = make_float4(ye.x, ye.y, yo.x, yo.y);
       }
       gp += dq;
-      o += dr;
-      if (o >= OWN) { o -= OWN; ++gp; }
+      ob += dr;
+      if (ob >= OB) { ob -= OB; ++gp; }
     }
     // then, dealt on from where the normals ended: OWN items = the logs of the phase's acceptance draws of one
     // owner (one Philox block of the ACCEPT stream serves 4 steps), and one item = the 1/pwgt values
@@ -205,7 +229,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
         const int c = lane % CPW;
         const int chain = ((int)blockIdx.x * OWN + oo) * CPW + c;
         if (chain < a.n)
-          for (uint32_t b = bf + (uint32_t)(lane / CPW); b <= bl; b += (uint32_t)LPC) {
+          for (uint32_t b = bf + (uint32_t)(lane / CPW); b <= bl; b += (uint32_t)LPC2) {
             const u32x4 aw = philox4x32_10(b, a.g0 + (uint32_t)chain, 0u, 0u, a.seed, ST_ACCEPT);
             const f32x2 l01 = accept_lu_x2(aw.x, aw.y), l23 = accept_lu_x2(aw.z, aw.w);
             const float l[4] = {l01.x, l01.y, l23.x, l23.y};
@@ -222,66 +246,66 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
     }
   };
 
-  // ---- this wave's chains (the lane layout of k_fused_fast); recorder o + OWN mirrors owner o ---------------
+  // ---- this wave's chains (the lane layout of k_fused_fast / k_fused_fastb); recorder o + OWN mirrors owner o ---
   const int slot_o = owner ? wv : (recorder ? wv - OWN : 0);
   const size_t gid = ((size_t)blockIdx.x * OWN + slot_o) * 64 + lane;
-  const size_t chain = gid / LPC;
-  const int q = (int)(gid % LPC);
-  const int k0 = 4 * q;
+  const size_t chain = gid / LPC2;
+  const int q = (int)(gid % LPC2);
+  const int k0 = 4 * BPL * q;  // first parameter of this lane; block b holds k0 + 4 b .. k0 + 4 b + 3 (d % (4 BPL) == 0)
   const bool mine = (owner || recorder) && chain < (size_t)a.n;
   const bool live = mine && k0 < d;
   const bool working = (owner || recorder) && (int)blockIdx.x * OWN + slot_o < a.nown;
   const size_t off = chain * (size_t)d + k0;
-  f32x2 xe = {0, 0}, xo = {0, 0}, me = {0, 0}, mo = {0, 0}, se = {0, 0}, so = {0, 0}, te = {0, 0}, to = {0, 0};
-  f32x2 gme = {0, 0}, gmo = {0, 0};
-  float gs0 = 0, gs1 = 0, gs2 = 0, gs3 = 0, ly = __builtin_inff();
-  if (live && owner) {
-    const float4 f = *reinterpret_cast<const float4 *>((a.x0 ? a.x0 : a.x) + off);
-    xe = f32x2{f.x, f.z}; xo = f32x2{f.y, f.w};
-    const float *Tsrc = a.T0 ? a.T0 : a.T;
-    te = f32x2{Tsrc[(k0 + 0) * d + k0 + 0], Tsrc[(k0 + 2) * d + k0 + 2]};
-    to = f32x2{Tsrc[(k0 + 1) * d + k0 + 1], Tsrc[(k0 + 3) * d + k0 + 3]};
-    if (LIK == LIK_GAUSS) {
-      gme = f32x2{a.lik[k0 + 0], a.lik[k0 + 2]}; gmo = f32x2{a.lik[k0 + 1], a.lik[k0 + 3]};
-      gs0 = a.lik[d + k0 + 0]; gs1 = a.lik[d + k0 + 1]; gs2 = a.lik[d + k0 + 2]; gs3 = a.lik[d + k0 + 3];
+  f32x2 xe[BPL], xo[BPL], me[BPL], mo[BPL], se[BPL], so[BPL], te[BPL], to[BPL], gme[BPL], gmo[BPL];
+  float gs[BPL][4];
+  float ly = __builtin_inff();
+#pragma unroll
+  for (int b = 0; b < BPL; ++b) {
+    xe[b] = xo[b] = me[b] = mo[b] = se[b] = so[b] = te[b] = to[b] = gme[b] = gmo[b] = f32x2{0, 0};
+    gs[b][0] = gs[b][1] = gs[b][2] = gs[b][3] = 0.0f;
+    const int kb = k0 + 4 * b;
+    if (live && owner) {
+      const float4 f = *reinterpret_cast<const float4 *>((a.x0 ? a.x0 : a.x) + off + 4 * b);
+      xe[b] = f32x2{f.x, f.z}; xo[b] = f32x2{f.y, f.w};
+      const float *Tsrc = a.T0 ? a.T0 : a.T;
+      te[b] = f32x2{Tsrc[(kb + 0) * d + kb + 0], Tsrc[(kb + 2) * d + kb + 2]};
+      to[b] = f32x2{Tsrc[(kb + 1) * d + kb + 1], Tsrc[(kb + 3) * d + kb + 3]};
+      if (LIK == LIK_GAUSS) {
+        gme[b] = f32x2{a.lik[kb + 0], a.lik[kb + 2]}; gmo[b] = f32x2{a.lik[kb + 1], a.lik[kb + 3]};
+        gs[b][0] = a.lik[d + kb + 0]; gs[b][1] = a.lik[d + kb + 1]; gs[b][2] = a.lik[d + kb + 2]; gs[b][3] = a.lik[d + kb + 3];
+      }
     }
-  }
-  if (live && (REC ? recorder : owner) && a.nmain > 0 && !a.init_moments) {
-    const float4 m = *reinterpret_cast<const float4 *>(a.mu + off);
-    const float4 p = *reinterpret_cast<const float4 *>(a.psum2 + off);
-    me = f32x2{m.x, m.z}; mo = f32x2{m.y, m.w};
-    se = f32x2{p.x, p.z}; so = f32x2{p.y, p.w};
+    if (live && (REC ? recorder : owner) && a.nmain > 0 && !a.init_moments) {
+      const float4 m = *reinterpret_cast<const float4 *>(a.mu + off + 4 * b);
+      const float4 p = *reinterpret_cast<const float4 *>(a.psum2 + off + 4 * b);
+      me[b] = f32x2{m.x, m.z}; mo[b] = f32x2{m.y, m.w};
+      se[b] = f32x2{p.x, p.z}; so[b] = f32x2{p.y, p.w};
+    }
   }
   // owner lanes that hold no chain never accept: log u < ly' - (+inf) is false for every ly'
   if (mine && owner && !a.x0) ly = a.ly[chain];
   // Every load of the chain state is awaited here, once, on every path (the compiler's s_waitcnt bookkeeping
   // is path-insensitive): inside the step loops the only vector-memory operations are stores, and no
   // s_waitcnt vmcnt may end up there -- it would wait for the previous step's stores.
-  asm volatile("" ::"v"(xe), "v"(xo), "v"(te), "v"(to), "v"(me), "v"(mo), "v"(se), "v"(so), "v"(gme), "v"(gmo), "v"(gs0),
-               "v"(gs1), "v"(gs2), "v"(gs3), "v"(ly));
+#pragma unroll
+  for (int b = 0; b < BPL; ++b)
+    asm volatile("" ::"v"(xe[b]), "v"(xo[b]), "v"(te[b]), "v"(to[b]), "v"(me[b]), "v"(mo[b]), "v"(se[b]), "v"(so[b]), "v"(gme[b]),
+                 "v"(gmo[b]), "v"(gs[b][0]), "v"(gs[b][1]), "v"(gs[b][2]), "v"(gs[b][3]));
+  asm volatile("" ::"v"(ly));
   if (owner) __builtin_amdgcn_s_setprio(3);  // the owners' dependent instruction stream goes first on its SIMD
   else if (recorder) __builtin_amdgcn_s_setprio(1);
   uint32_t cnt = 0, wacc = 0;
   unsigned long long macc = 0;  // accepted main-loop proposals of this wave
 
+  // the first log2(BPL) stages of the butterfly over the block index, inside the lane; the lane group does the rest
+  auto blocks_sum = [&](const float p[BPL]) -> float {
+    if (BPL == 1) return group_sum<LPC2>(p[0]);
+    if (BPL == 2) return group_sum<LPC2>(p[0] + p[BPL > 1 ? 1 : 0]);
+    return group_sum<LPC2>((p[0] + p[BPL > 1 ? 1 : 0]) + (p[BPL == 4 ? 2 : 0] + p[BPL == 4 ? 3 : 0]));
+  };
+
   // likelihood of the proposal (pe, po), same arithmetic as k_fused_fast
-  auto loglike = [&](f32x2 pe, f32x2 po) -> float {
-    float acc = 0.0f;
-    if (LIK == LIK_ROSEN1) {
-      const f32x2 t1 = splat2(1.0f) - pe;
-      const f32x2 t2 = fma2(-pe, pe, po);
-      const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
-      if (live) acc = term.x + term.y;
-    } else if (LIK == LIK_GAUSS) {
-      const f32x2 ae = pe - gme, ao = po - gmo;
-      const f32x2 he = (splat2(0.5f) * ae) * ae, ho = (splat2(0.5f) * ao) * ao;
-      if (live) {
-        acc = __builtin_fmaf(he.x, gs0, 0.0f);
-        acc = __builtin_fmaf(ho.x, gs1, acc);
-        acc = __builtin_fmaf(he.y, gs2, acc);
-        acc = __builtin_fmaf(ho.y, gs3, acc);
-      }
-    }
+  auto loglike = [&](const f32x2 pe[BPL], const f32x2 po[BPL]) -> float {
     if (LIK == LIK_MIX) {
       const int Kc = a.ncomp;
       float e[8];
@@ -289,16 +313,20 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
       for (int c = 0; c < 8; ++c) {
         e[c] = 0.0f;
         if (c < Kc) {
-          float s2 = 0.0f;
-          if (live) {
-            const float4 m = *reinterpret_cast<const float4 *>(&lds_means[c * d + k0]);
-            const f32x2 ae = pe - f32x2{m.x, m.z}, ao = po - f32x2{m.y, m.w};
-            s2 = __builtin_fmaf(ae.x, ae.x, 0.0f);
-            s2 = __builtin_fmaf(ao.x, ao.x, s2);
-            s2 = __builtin_fmaf(ae.y, ae.y, s2);
-            s2 = __builtin_fmaf(ao.y, ao.y, s2);
+          float s2[BPL];
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) {
+            s2[b] = 0.0f;
+            if (live) {
+              const float4 m = *reinterpret_cast<const float4 *>(&lds_means[c * d + k0 + 4 * b]);
+              const f32x2 ae = pe[b] - f32x2{m.x, m.z}, ao = po[b] - f32x2{m.y, m.w};
+              s2[b] = __builtin_fmaf(ae.x, ae.x, 0.0f);
+              s2[b] = __builtin_fmaf(ao.x, ao.x, s2[b]);
+              s2[b] = __builtin_fmaf(ae.y, ae.y, s2[b]);
+              s2[b] = __builtin_fmaf(ao.y, ao.y, s2[b]);
+            }
           }
-          e[c] = __builtin_fmaf(-0.5f, group_sum<LPC>(s2), lds_logw[c]);
+          e[c] = __builtin_fmaf(-0.5f, blocks_sum(s2), lds_logw[c]);
         }
       }
       float emax = e[0];
@@ -316,7 +344,27 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
       }
       return emax + logf_v1(ssum);
     }
-    return 0.0f - group_sum<LPC>(acc);
+    float acc[BPL];
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+      acc[b] = 0.0f;
+      if (LIK == LIK_ROSEN1) {
+        const f32x2 t1 = splat2(1.0f) - pe[b];
+        const f32x2 t2 = fma2(-pe[b], pe[b], po[b]);
+        const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
+        if (live) acc[b] = term.x + term.y;
+      } else if (LIK == LIK_GAUSS) {
+        const f32x2 ae = pe[b] - gme[b], ao = po[b] - gmo[b];
+        const f32x2 he = (splat2(0.5f) * ae) * ae, ho = (splat2(0.5f) * ao) * ao;
+        if (live) {
+          acc[b] = __builtin_fmaf(he.x, gs[b][0], 0.0f);
+          acc[b] = __builtin_fmaf(ho.x, gs[b][1], acc[b]);
+          acc[b] = __builtin_fmaf(he.y, gs[b][2], acc[b]);
+          acc[b] = __builtin_fmaf(ho.y, gs[b][3], acc[b]);
+        }
+      }
+    }
+    return 0.0f - blocks_sum(acc);
   };
 
   __syncthreads();  // the mixture's means and log-weights are staged
@@ -343,13 +391,45 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   if (emit) {
     kmod = a.isamp0 % sstride;
     const size_t row0 = (size_t)((a.isamp0 + sstride - 1) / sstride);  // row of the first kept step >= isamp0
-    float *dump = a.trash + 4 * ((size_t)blockIdx.x * PBLOCK + threadIdx.x);
+    float *dump = a.trash + PTRASH * ((size_t)blockIdx.x * PBLOCK + threadIdx.x);
     const bool rec = REC ? recorder : owner;
     sxv = (live && rec) ? a.samp_x + row0 * rowx + off : dump;
     slv = (mine && rec) ? a.samp_ly + row0 * rowl + chain : dump;
     sxs = (live && rec) ? rowx : 0;
     sls = (mine && rec) ? rowl : 0;
   }
+  // Welford (src/mcpar.cc:184-209), the exchange snapshot (:202-208) and the sample emission (:177-182) of one main-loop
+  // step, from the post-step state (ce, co, lyv): the recorder's work, or the owner's when there are no recorders
+  auto record = [&](const f32x2 ce[BPL], const f32x2 co[BPL], float lyv, float w, bool snap) {
+    const f32x2 w2 = splat2(w);  // 1/pwgt, src/mcpar.cc:186-187
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+      const f32x2 de = ce[b] - me[b], dO = co[b] - mo[b];  // src/mcpar.cc:199-202
+      me[b] = fma2(de, w2, me[b]);
+      mo[b] = fma2(dO, w2, mo[b]);
+      se[b] = fma2(de, ce[b] - me[b], se[b]);
+      so[b] = fma2(dO, co[b] - mo[b], so[b]);
+    }
+    if (snap && live) {  // snapshot for the next exchange (src/mcpar.cc:202-208)
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) {
+        const f32x2 ve = se[b] * w2, vo = so[b] * w2;
+        float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * (off + 4 * b));
+        slot[0] = make_float4(me[b].x, ve.x, mo[b].x, vo.x);
+        slot[1] = make_float4(me[b].y, ve.y, mo[b].y, vo.y);
+      }
+    }
+    if (emit) {  // src/mcpar.cc:177-182
+      if (kmod == 0) {
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) *reinterpret_cast<float4 *>(sxv + 4 * b) = make_float4(ce[b].x, co[b].x, ce[b].y, co[b].y);
+        *slv = lyv;  // every lane of the chain stores the same value
+        sxv += sxs;
+        slv += sls;
+      }
+      kmod = kmod + 1 == sstride ? 0 : kmod + 1;
+    }
+  };
 
   const int NG = PWAVES - OWN - NREC;  // pure generator waves
   __syncthreads();
@@ -358,6 +438,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   // iteration p: owners run phase p, recorders digest phase p - 1, everybody else fills phase p + 1
   for (int p = 0; p < nphase + (REC ? 1 : 0); ++p) {
     const int buf = p & 1;
+#if MCX_MEET_VARIANT != 0
     // a tuner meeting was abandoned during the last phase: every wavefront of the workgroup reads the same flag
     // (written before the barrier that ended that phase) and leaves here.  Meetings happen in burn-in steps only:
     // phases that follow a phase without any need no look.
@@ -365,33 +446,47 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
       aborted = true;
       break;
     }
+#endif
     if (owner) {
       if (working && p < nphase) {
         const int tau0 = p * K;
         const int ns = T - tau0 < K ? T - tau0 : K;
         const int nb = a.nburn - tau0 < 0 ? 0 : (a.nburn - tau0 < ns ? a.nburn - tau0 : ns);  // burn-in steps of this phase
-        const float4 *zp = zbuf + ((size_t)(buf * K) * OWN + wv) * 64 + lane;
-        const float *up = ubuf + ((size_t)(buf * K) * OWN + wv) * CPW + lane / LPC;
-        float4 *xq = xbuf + ((size_t)(buf * K) * OWN + wv) * 64 + lane;
-        float *lq = lbuf + ((size_t)(buf * K) * OWN + wv) * CPW + lane / LPC;
-        float4 zn = *zp;
+        const float4 *zp = zbuf + ((size_t)(buf * K) * OB + wv * BPL) * 64 + lane;
+        const float *up = ubuf + ((size_t)(buf * K) * OWN + wv) * CPW + lane / LPC2;
+        float4 *xq = xbuf + ((size_t)(buf * K) * OB + wv * BPL) * 64 + lane;
+        float *lq = lbuf + ((size_t)(buf * K) * OWN + wv) * CPW + lane / LPC2;
+        float4 zn[BPL];
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) zn[b] = zp[b * 64];
         float lun = *up;
         // proposal, likelihood, acceptance (src/mcpar.cc:302-312, 62-75); returns the chains of the wave that accepted.
         // The next step's numbers are fetched first: they are on their way while this step computes.
         auto metropolis = [&](int s) -> uint32_t {
-          const float4 z = zn;
+          float4 z[BPL];
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) z[b] = zn[b];
           const float lu = lun;
           if (s + 1 < ns) {
-            zp += (size_t)OWN * 64;
+            zp += (size_t)OB * 64;
             up += (size_t)OWN * CPW;
-            zn = *zp;
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) zn[b] = zp[b * 64];
             lun = *up;
           }
-          const f32x2 pe = fma2(te, f32x2{z.x, z.y}, xe), po = fma2(to, f32x2{z.z, z.w}, xo);
+          f32x2 pe[BPL], po[BPL];
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) {
+            pe[b] = fma2(te[b], f32x2{z[b].x, z[b].y}, xe[b]);
+            po[b] = fma2(to[b], f32x2{z[b].z, z[b].w}, xo[b]);
+          }
           const float lyt = loglike(pe, po);
           const bool take = accept_local(lyt, ly, lu);
-          xe = take ? pe : xe;
-          xo = take ? po : xo;
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) {
+            xe[b] = take ? pe[b] : xe[b];
+            xo[b] = take ? po[b] : xo[b];
+          }
           ly = take ? lyt : ly;
           cnt += take ? 1u : 0u;
           return (uint32_t)__popcll(__ballot(take && q == 0));
@@ -404,8 +499,26 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
           if (tau0 + s == next_event) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
             const int last = next_event;
             const int steps = last - seg_start + 1, check = last > irate ? 1 : 0;
+#if MCX_MEET_VARIANT == 2
+            // An abandoned meeting (wave-uniform) does not leave the step loop -- an extra exit would cost the healthy
+            // run its loop shape: the wave goes on with a count of zero, skips later meetings, and the flag ends the
+            // launch at the next phase boundary; nothing an abandoned launch computes is ever written back.
+            unsigned long long seg = 0;
+            if (!aborted) {
+              seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent], a.meet_timeout);
+              if (seg == MEET_ABORTED) {
+                if (lane == 0) {
+                  __hip_atomic_store(&lds_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __hip_atomic_store(a.ctr + 5, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                aborted = true;
+                seg = 0;
+              }
+            }
+#else
             const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent],
                                                        a.meet_timeout);
+#if MCX_MEET_VARIANT == 1
             if (seg == MEET_ABORTED) {  // (wave-uniform) the rest of this phase is not run; the flag ends the launch
               if (lane == 0) {
                 __hip_atomic_store(&lds_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -414,6 +527,8 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
               s = ns;
               break;
             }
+#endif
+#endif
             ++nevent;
             wacc = 0;
             tun_na += seg;
@@ -424,10 +539,13 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
               float f = 1.0f;
               if (arate < a.armin) { tun_na = tun_nt = 0; f = a.dfac; }
               else if (arate > a.armax) { tun_na = tun_nt = 0; f = a.ifac; }
-              if (f != 1.0f) { te = te * splat2(f); to = to * splat2(f); }
+              if (f != 1.0f) {
+#pragma unroll
+                for (int b = 0; b < BPL; ++b) { te[b] = te[b] * splat2(f); to[b] = to[b] * splat2(f); }
+              }
               if (blockIdx.x == 0 && wv == 0 && lane == 0) {  // lane 0 of the grid holds T[0][0]
                 const int kk = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
-                if (kk < 256) a.trace[kk] = te.x;
+                if (kk < 256) a.trace[kk] = te[0].x;
               }
               ++ntrace_local;
               irate += 50;
@@ -436,41 +554,25 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
             next_event = irate + 1 < a.nburn ? irate + 1 : a.nburn - 1;
           }
         }
-        xq += (size_t)nb * OWN * 64;
+        xq += (size_t)nb * OB * 64;
         lq += (size_t)nb * OWN * CPW;
         for (; s < ns; ++s) {  // ---- main-loop steps (src/mcpar.cc:152-209)
           macc += metropolis(s);
           if (REC) {  // hand the state to the recorder (every lane of a chain writes the same ly)
-            *xq = make_float4(xe.x, xe.y, xo.x, xo.y);
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) xq[b * 64] = make_float4(xe[b].x, xe[b].y, xo[b].x, xo[b].y);
             *lq = ly;
-            xq += (size_t)OWN * 64;
+            xq += (size_t)OB * 64;
             lq += (size_t)OWN * CPW;
           } else {  // no recorders (the run is bound by the generators' throughput, not by this wave's latency)
             if (s == nb && tau0 + s == a.nburn && a.init_moments) {  // src/mcpar.cc:99-104
-              me = mo = splat2(0.0f);
-              se = so = splat2(FPEPS);
-            }
-            const f32x2 w2 = splat2(wbuf[(p & 3) * PKMAX + s]);  // 1/pwgt, src/mcpar.cc:186-187
-            const f32x2 de = xe - me, dO = xo - mo;               // src/mcpar.cc:199-202
-            me = fma2(de, w2, me);
-            mo = fma2(dO, w2, mo);
-            se = fma2(de, xe - me, se);
-            so = fma2(dO, xo - mo, so);
-            if (tau0 + s - a.nburn == a.snap_after && live) {  // snapshot for the next exchange (src/mcpar.cc:202-208)
-              const f32x2 ve = se * w2, vo = so * w2;
-              float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
-              slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
-              slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
-            }
-            if (emit) {  // src/mcpar.cc:177-182
-              if (kmod == 0) {
-                *reinterpret_cast<float4 *>(sxv) = make_float4(xe.x, xo.x, xe.y, xo.y);
-                *slv = ly;  // every lane of the chain stores the same value
-                sxv += sxs;
-                slv += sls;
+#pragma unroll
+              for (int b = 0; b < BPL; ++b) {
+                me[b] = mo[b] = splat2(0.0f);
+                se[b] = so[b] = splat2(FPEPS);
               }
-              kmod = kmod + 1 == sstride ? 0 : kmod + 1;
             }
+            record(xe, xo, ly, wbuf[(p & 3) * PKMAX + s], tau0 + s - a.nburn == a.snap_after);
           }
         }
       }
@@ -481,39 +583,28 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
         const int nb = a.nburn - tau0 < 0 ? 0 : (a.nburn - tau0 < ns ? a.nburn - tau0 : ns);
         if (nb < ns) {
           if (tau0 + nb == a.nburn && a.init_moments) {  // src/mcpar.cc:99-104
-            me = mo = splat2(0.0f);
-            se = so = splat2(FPEPS);
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) {
+              me[b] = mo[b] = splat2(0.0f);
+              se[b] = so[b] = splat2(FPEPS);
+            }
           }
-          const float4 *xq = xbuf + ((size_t)(pb * K + nb) * OWN + slot_o) * 64 + lane;
-          const float *lq = lbuf + ((size_t)(pb * K + nb) * OWN + slot_o) * CPW + lane / LPC;
+          const float4 *xq = xbuf + ((size_t)(pb * K + nb) * OB + slot_o * BPL) * 64 + lane;
+          const float *lq = lbuf + ((size_t)(pb * K + nb) * OWN + slot_o) * CPW + lane / LPC2;
           const float *wq = wbuf + ((p - 1) & 3) * PKMAX;
           for (int s = nb; s < ns; ++s) {
-            const float4 xv = *xq;
+            f32x2 ce[BPL], co[BPL];
+#pragma unroll
+            for (int b = 0; b < BPL; ++b) {
+              const float4 xv = xq[b * 64];
+              ce[b] = f32x2{xv.x, xv.y};
+              co[b] = f32x2{xv.z, xv.w};
+            }
             const float lyv = *lq;
-            const f32x2 w2 = splat2(wq[s]);  // 1/pwgt, src/mcpar.cc:186-187
-            xq += (size_t)OWN * 64;
+            const float w = wq[s];
+            xq += (size_t)OB * 64;
             lq += (size_t)OWN * CPW;
-            const f32x2 ce = {xv.x, xv.y}, co = {xv.z, xv.w};
-            const f32x2 de = ce - me, dO = co - mo;  // src/mcpar.cc:199-202
-            me = fma2(de, w2, me);
-            mo = fma2(dO, w2, mo);
-            se = fma2(de, ce - me, se);
-            so = fma2(dO, co - mo, so);
-            if (tau0 + s - a.nburn == a.snap_after && live) {  // snapshot for the next exchange (src/mcpar.cc:202-208)
-              const f32x2 ve = se * w2, vo = so * w2;
-              float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
-              slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
-              slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
-            }
-            if (emit) {  // src/mcpar.cc:177-182
-              if (kmod == 0) {
-                *reinterpret_cast<float4 *>(sxv) = make_float4(ce.x, co.x, ce.y, co.y);
-                *slv = lyv;  // every lane of the chain stores the same value
-                sxv += sxs;
-                slv += sls;
-              }
-              kmod = kmod + 1 == sstride ? 0 : kmod + 1;
-            }
+            record(ce, co, lyv, w, tau0 + s - a.nburn == a.snap_after);
           }
         }
       }
@@ -530,10 +621,14 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   if (aborted) return;  // abandoned launch: nothing is written back, the host repeats the run (ctr[5] is set)
   if (owner) {
     if (live) {
-      *reinterpret_cast<float4 *>(a.x + off) = make_float4(xe.x, xo.x, xe.y, xo.y);
-      if ((a.nburn > 0 || a.T0) && chain == 0) {  // the (rescaled) diagonal; off-diagonal entries are zero on this path
-        a.T[(k0 + 0) * d + k0 + 0] = te.x; a.T[(k0 + 2) * d + k0 + 2] = te.y;
-        a.T[(k0 + 1) * d + k0 + 1] = to.x; a.T[(k0 + 3) * d + k0 + 3] = to.y;
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) {
+        const int kb = k0 + 4 * b;
+        *reinterpret_cast<float4 *>(a.x + off + 4 * b) = make_float4(xe[b].x, xo[b].x, xe[b].y, xo[b].y);
+        if ((a.nburn > 0 || a.T0) && chain == 0) {  // the (rescaled) diagonal; off-diagonal entries are zero on this path
+          a.T[(kb + 0) * d + kb + 0] = te[b].x; a.T[(kb + 2) * d + kb + 2] = te[b].y;
+          a.T[(kb + 1) * d + kb + 1] = to[b].x; a.T[(kb + 3) * d + kb + 3] = to[b].y;
+        }
       }
     }
     if (mine && q == 0) {
@@ -543,15 +638,18 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
     if (lane == 0 && macc) atomicAdd(a.ctr + 4, macc);
   }
   if ((REC ? recorder : owner) && live && a.nmain > 0) {
-    *reinterpret_cast<float4 *>(a.mu + off) = make_float4(me.x, mo.x, me.y, mo.y);
-    *reinterpret_cast<float4 *>(a.psum2 + off) = make_float4(se.x, so.x, se.y, so.y);
-    if (a.final_publish) {  // src/mcpar.cc:202-208 after the last step
-      const f32x2 w2 = splat2(a.winv[a.isamp0 + a.nmain - 1]);
-      const f32x2 ve = se * w2, vo = so * w2;
-      *reinterpret_cast<float4 *>(a.sig + off) = make_float4(ve.x, vo.x, ve.y, vo.y);
-      float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * off);
-      slot[0] = make_float4(me.x, ve.x, mo.x, vo.x);
-      slot[1] = make_float4(me.y, ve.y, mo.y, vo.y);
+    const f32x2 w2 = splat2(a.winv[a.isamp0 + a.nmain - 1]);
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+      *reinterpret_cast<float4 *>(a.mu + off + 4 * b) = make_float4(me[b].x, mo[b].x, me[b].y, mo[b].y);
+      *reinterpret_cast<float4 *>(a.psum2 + off + 4 * b) = make_float4(se[b].x, so[b].x, se[b].y, so[b].y);
+      if (a.final_publish) {  // src/mcpar.cc:202-208 after the last step
+        const f32x2 ve = se[b] * w2, vo = so[b] * w2;
+        *reinterpret_cast<float4 *>(a.sig + off + 4 * b) = make_float4(ve.x, vo.x, ve.y, vo.y);
+        float4 *slot = reinterpret_cast<float4 *>(a.musig_own + 2 * (off + 4 * b));
+        slot[0] = make_float4(me[b].x, ve.x, mo[b].x, vo.x);
+        slot[1] = make_float4(me[b].y, ve.y, mo[b].y, vo.y);
+      }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {

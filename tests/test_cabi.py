@@ -22,7 +22,7 @@ def test_header_symbols_are_exported():
     assert len(syms) >= 30
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.mcx_abi_version() == 3
+    assert lib.mcx_abi_version() == 4
 
 
 def test_product_never_touches_the_oracle():

@@ -91,3 +91,82 @@ def test_blocks_per_lane_multishard_snapshot(bpl):
         assert egs[s].counters["remote_passes"] == eos[s].remote_passes
         for name in ("state", "mean", "var", "samples", "musigall"):
             assert same_bits(getattr(egs[s], name), getattr(eos[s], name)), (s, name)
+
+
+# ---- the one-launch small-n kernel (k_run_small<LPC2, BPL, ...>, mcx_persist.hpp) with two / four blocks per lane -------
+@pytest.mark.parametrize("bpl", [2, 4])
+@pytest.mark.parametrize("kind,d,n", [("rosen", 16, 3000), ("rosen", 8, 1111), ("rosen", 12, 700), ("rosen", 32, 640),
+                                      ("rosen", 24, 300), ("gauss", 16, 900), ("gauss", 24, 300), ("mix", 32, 512),
+                                      ("mix", 8, 777), ("mix", 16, 2100)])
+def test_small_n_blocks_per_lane_same_bits_as_oracle(kind, d, n, bpl):
+    """forced blocks per lane (illegal combinations -- d = 12 with two, d = 8 with four -- fall back to one)"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    so, sg = specs(kind, d)
+    nburn, nsamp = 130, 70
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(*so)
+    eo = O.Engine(d, n, pl=1.0, threads=8)
+    vg, k2 = M.make_vlfunc(*sg)
+    eg = M.Engine(d, n, pl=1.0)
+    eg.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
+    eg.set_option(E.OPT_PERSIST, 1)
+    for rep in range(2):  # the second run continues the step counter and starts from staged moments
+        eo.run(nsamp, nburn, p, vo)
+        eg.run(nsamp, nburn, p, vg)
+        c = eg.counters
+        assert c["kernel_launches"] <= 3 and c["meet_timeouts"] == 0, c
+        assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+        assert np.array_equal(eg.accept_counts, eo.accept_counts)
+        assert np.array_equal(eg.tuner_trace, eo.tuner_trace)
+        for name in ("state", "loglike", "mean", "var", "musigall", "samples", "chol"):
+            assert same_bits(getattr(eg, name), getattr(eo, name)), (rep, name)
+    eg.close()
+
+
+@pytest.mark.parametrize("d,n,want_bpl", [(16, 8192, 2), (16, 16384, 2), (8, 4096, 1), (8, 16384, 2)])
+def test_small_n_automatic_blocks_per_lane_full_job(d, n, want_bpl):
+    """the automatic choice on the shapes it is made for: 8192 x 16-D -- the per-GPU shape of a strong-scaled C3 job -- runs
+    with one owner wavefront per workgroup; the whole R-local job (nburn 500 + nsamp 1000, thinned store) against the oracle"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    nburn, nsamp, stride = 500, 1000, 50
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=1.0, threads=8)
+    eo.set_record(samples=True, mask=False, stride=stride)
+    eo.run(nsamp, nburn, p, vo)
+    vg, k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eg = M.Engine(d, n, pl=1.0)
+    eg.set_option(E.OPT_SAMPLE_STRIDE, stride)
+    eg.run(nsamp, nburn, p, vg)
+    c = eg.counters
+    assert c["kernel_launches"] <= 3 and c["meet_timeouts"] == 0, c
+    assert c["small_n_blocks_per_lane"] == want_bpl, c
+    assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+    assert np.array_equal(eg.tuner_trace, eo.tuner_trace)
+    kept = (nsamp + stride - 1) // stride
+    assert same_bits(eg.samples, eo.samples[-kept * n:])
+    for name in ("state", "loglike", "mean", "var", "musigall"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
+    eg.close()
+
+
+@pytest.mark.parametrize("bpl", [2, 4])
+def test_small_n_blocks_per_lane_multishard_snapshot(bpl):
+    """two shards on one GPU, lazy schedule, one launch per stretch: the recorder wavefronts snapshot the slot of both blocks"""
+    from mcpar_amd import engine as E
+    from test_gpu_configs import run_sharded_async
+    d, n, nshards, nburn, nsamp, pl = 16, 2048, 2, 100, 55, 0.93
+    vo, keep = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl, threads=8) for s in range(nshards)]
+    O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
+
+    def setup(s, e):
+        e.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
+        e.set_option(E.OPT_PERSIST, 1)
+    egs, nbegin = run_sharded_async(d, n, nshards, nburn, nsamp, pl, 0, setup=setup)
+    for s in range(nshards):
+        assert egs[s].counters["remote_passes"] == eos[s].remote_passes
+        for name in ("state", "mean", "var", "samples", "musigall"):
+            assert same_bits(getattr(egs[s], name), getattr(eos[s], name)), (s, name)

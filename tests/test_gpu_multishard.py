@@ -12,7 +12,9 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, vlspec=None, opts=None, runs=1):
+def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, vlspec=None, opts=None, runs=1, deferred=False):
+    """deferred: the hook does nothing but note the request in BEGIN and moves the data in WAIT -- a gather that is truly
+    in flight between the two: an engine that rewrites its slot, or reads the peers', before its WAIT gets wrong bits"""
     import mcpar_amd as M
     from mcpar_amd import engine as E
     hip = C.CDLL("libamdhip64.so")
@@ -26,7 +28,9 @@ def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, v
 
     def make_hook(s):
         def hook(phase, ptr, slot, shard, ns, stream):
-            if phase != E.XCHG_BEGIN:
+            if deferred and phase == E.XCHG_BEGIN:
+                return 0
+            if not deferred and phase != E.XCHG_BEGIN:
                 return 0
             ptrs[s] = ptr
             hip.hipDeviceSynchronize()   # every shard's slot is published
@@ -88,10 +92,11 @@ def test_multishard_equals_oracle(nshards, pl, eager):
         assert np.array_equal(eg.musigall.view(np.uint32), eo.musigall.view(np.uint32))
 
 
-@pytest.mark.parametrize("persist", [1, 0], ids=["one-launch", "segments"])
+@pytest.mark.parametrize("deferred", [False, True], ids=["copy-in-begin", "copy-in-wait"])
+@pytest.mark.parametrize("persist", [1, 2, 0], ids=["one-launch", "one-launch-under-gather", "segments"])
 @pytest.mark.parametrize("eager", [0, 1], ids=["lazy", "eager"])
 @pytest.mark.parametrize("pl,runs", [(0.7, 1), (1.0, 1), (0.8, 2), (1.0, 3)])
-def test_last_gather_left_in_flight(pl, runs, eager, persist):
+def test_last_gather_left_in_flight(pl, runs, eager, persist, deferred):
     """MCX_OPT_ASYNC_TAIL: mcx_run returns without waiting for the run's last gather and without the slot's final publish
     behind it; the getters (and the next run) finish them.  2 = with any exchange hook -- the default, 1, does it for
     the library's own RCCL exchange only, which takes several GPUs."""
@@ -101,11 +106,14 @@ def test_last_gather_left_in_flight(pl, runs, eager, persist):
     eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl) for s in range(nshards)]
     for _ in range(runs):
         O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
-    # (one-launch mode: a run that starts under the last run's gather launches its burn-in first, on its own)
-    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, eager=eager, opts={E.OPT_ASYNC_TAIL: 2, E.OPT_PERSIST: persist},
-                          runs=runs)
-    if runs > 1 and persist:
+    # (one-launch mode: a run that starts under the last run's gather waits for it before a launch with tuner meetings --
+    # or, MCX_OPT_MEET_UNDER_GATHER = 1, launches its burn-in first, on its own, under the gather)
+    egs = run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, eager=eager, runs=runs, deferred=deferred,
+                          opts={E.OPT_ASYNC_TAIL: 2, E.OPT_PERSIST: 1 if persist else 0, E.OPT_MEET_UNDER_GATHER: 1 if persist == 2 else 0})
+    if runs > 1 and persist == 2:
         assert egs[0].counters["kernel_launches"] >= 2
+    if runs > 1:
+        assert egs[0].counters["exchange_waits"] >= 1
     for s in range(nshards):
         eo, eg = eos[s], egs[s]
         assert np.array_equal(eg.accept_mask, eo.accept_mask), "shard %d" % s
