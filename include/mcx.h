@@ -330,6 +330,10 @@ int mcx_device_pci_bus_id(char *buf, size_t len);
  * HIP events; *gbps = (bytes read + bytes written) / time in GB/s.  What bench.py reports the HBM figures against
  * next to the nominal 8 TB/s. */
 int mcx_debug_copy_bandwidth(size_t bytes, int reps, double *gbps);
+/* host logic of the one-launch small-n kernel, for tests (no device): recorders yes/no and steps per phase for `own` owner
+ * wavefronts per workgroup of lpc2 lanes per chain x bpl blocks per lane, and who generates what: tab[3][16][12] item
+ * codes (0xffffffff ends a wavefront's list; kind << 14 | step pair << 4 | (owner, block)) */
+int mcx_debug_persist_deal(int lpc2, int bpl, int own, int *rec, int *ksteps, uint32_t *tab, int max_words);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:
  * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
  * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf,

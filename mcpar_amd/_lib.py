@@ -108,6 +108,7 @@ def load():
         "mcx_exchange_rccl_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "mcx_debug_exchange": [vp],
         "mcx_debug_fill_slot": [vp, C.c_float],
+        "mcx_debug_persist_deal": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), u32p, C.c_int],
         "mcx_debug_copy_bandwidth": [C.c_size_t, C.c_int, C.POINTER(C.c_double)],
         "mcx_debug_numerics": [C.c_int, C.c_int, u32p, u32p],
         "mcx_debug_normals": [C.c_uint32] * 6 + [C.c_int, fp],

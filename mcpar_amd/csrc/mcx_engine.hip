@@ -466,6 +466,9 @@ struct mcx_engine {
   DevBuf<float> best_row;            // running maximum-likelihood sample: [0] = log-likelihood, [1..np] = parameters
   DevBuf<unsigned long long> best_key;  // scratch of the arg-max reduction
   mcx_counters cnt{};
+  DevBuf<uint32_t> deal_tab;         // RunArgs::deal of the one-launch small-n kernel, for the configuration in deal_key
+  std::vector<uint32_t> h_deal;
+  long long deal_key = -1;
   uint64_t meet_total = 0;           // runs repeated because a meeting was abandoned, over the engine's life
   int runs_since_broken = 0;         // runs on the per-segment kernels since then (the one-launch kernel is tried again)
   // time the step stream waits for gathers begun earlier (mcx_counters.exchange_wait_ns): event pairs around each wait
@@ -673,7 +676,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->cull_keys.release(); e->cull_hist.release(); e->cull_sorted.release(); e->cull_stats.release(); e->cull_box.release();
   e->cull_lim.release(); e->cull_excl.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
-  e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release();
+  e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release(); e->deal_tab.release();
   for (int b = 0; b < 2; ++b) {
     e->sink_stage[b].release();
     e->sink_pin[b].release();
@@ -1361,6 +1364,18 @@ static __global__ void k_fill(float *p, size_t n, float v)
   if (i < n) p[i] = v;
 }
 
+// the one-launch small-n kernel's generator deal (mcxk_persist_deal) and steps per phase, for tests: host logic only
+extern "C" int mcx_debug_persist_deal(int lpc2, int bpl, int own, int *rec, int *ksteps, uint32_t *tab, int max_words)
+{
+  if (lpc2 < 1 || lpc2 > 8 || (bpl != 1 && bpl != 2 && bpl != 4) || own < 1 || own > POWN_MAX || !rec || !ksteps || !tab ||
+      max_words < MCXK_PERSIST_DEAL_WORDS)
+    return fail(MCX_ERR_INVALID, "bad arguments");
+  *rec = mcxk_persist_recorders(own) ? 1 : 0;
+  *ksteps = mcxk_persist_ksteps(lpc2, bpl, own);
+  mcxk_persist_deal(lpc2, bpl, own, *rec, *ksteps, tab);
+  return MCX_OK;
+}
+
 extern "C" int mcx_debug_fill_slot(mcx_engine *e, float value)
 {
   MCXCHK(enter(e));
@@ -1916,6 +1931,19 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         const int nwg = std::min(nown, e->ncu);
         ra.own = (nown + nwg - 1) / nwg;
         ra.ksteps = mcxk_persist_ksteps(plpc2, pbpl, ra.own);
+        {  // who generates what: rebuilt and uploaded only when the launch configuration changes
+          const int prec = mcxk_persist_recorders(ra.own) ? 1 : 0;
+          const long long key = (((long long)plpc2 * 8 + pbpl) * 16 + ra.own) * 64 + ra.ksteps + 4096ll * 1024 * prec;
+          if (key != e->deal_key) {
+            HIPCHK(hipStreamSynchronize(st));  // (an earlier launch may still read the table)
+            e->h_deal.assign((size_t)MCXK_PERSIST_DEAL_WORDS, 0u);
+            mcxk_persist_deal(plpc2, pbpl, ra.own, prec, ra.ksteps, e->h_deal.data());
+            MCXCHK(e->deal_tab.alloc((size_t)MCXK_PERSIST_DEAL_WORDS));
+            HIPCHK(hipMemcpyAsync(e->deal_tab.p, e->h_deal.data(), e->h_deal.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            e->deal_key = key;
+          }
+          ra.deal = e->deal_tab.p;
+        }
         ra.meet_timeout = (unsigned long long)e->opt_meet_timeout_ms * 100000ull;  // s_memrealtime: 100 MHz
         ra.meet_expect_extra = e->opt_debug_meet;
         if (snap >= 0) {  // the kernel rewrites this shard's slot: no gather may still be reading it

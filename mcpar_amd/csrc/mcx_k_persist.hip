@@ -3,7 +3,9 @@
 #include "mcx_persist.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 using namespace mcx;
 
@@ -47,6 +49,8 @@ int mcxk_persist_bpl(int lpc, int d, int n, int ncu, int opt)
 // phase's items (a two-step item per owner and step pair, one acceptance item per owner) deal out over the filling
 // wavefronts matters as much as the phase count.  With bpl blocks per lane an owner stands for bpl owners' worth of
 // items and LDS.
+bool mcxk_persist_deal_fits(int bpl, int own, int rec, int K);
+
 int mcxk_persist_ksteps(int lpc2, int bpl, int own)
 {
   const int rec = mcxk_persist_recorders(own) ? 1 : 0;
@@ -54,13 +58,76 @@ int mcxk_persist_ksteps(int lpc2, int bpl, int own)
   int k = eff == 1 ? 32 : (eff == 2 ? 16 : (eff == 3 ? 20 : (eff == 4 ? 16 : std::max(PWAVES - own - rec * own, 2))));
   static const char *env = getenv("MCX_PERSIST_KSTEPS");  // tuning only (tools/persist_sweep.py)
   if (env && *env) k = std::max(atoi(env), 2);
-  while (k > 2 && (k > PKMAX || lds_for(lpc2, bpl, own, rec, k) > MCXK_PERSIST_LDS_LIMIT)) k -= 2;
+  while (k > 2 && (k > PKMAX || lds_for(lpc2, bpl, own, rec, k) > MCXK_PERSIST_LDS_LIMIT || !mcxk_persist_deal_fits(bpl, own, rec, k))) k -= 2;
   return k;
 }
 
 size_t mcxk_persist_lds_bytes(int lpc2, int bpl, int own)
 {
   return lds_for(lpc2, bpl, own, mcxk_persist_recorders(own) ? 1 : 0, mcxk_persist_ksteps(lpc2, bpl, own));
+}
+
+// Who generates what.  A phase's generator items -- the normals of two consecutive steps of one (owner, block) set, the
+// acceptance logs of one owner, the 1/pwgt values -- were dealt round-robin over the generator wavefronts until round 4:
+// every wavefront got the same share, and the SIMD that also carries an owner (36-52 instructions per step at the top
+// priority) finished last: with one owner and two blocks per lane it issues 3/14 of the generators' work PLUS the
+// owner's, against 4/14 on the SIMDs without one -- 117 against 81 instructions per step, and a phase lasts as long as
+// its busiest SIMD (measured: 8192 x 16-D 0.40 ms per launch = 640 cycles per step; the busiest SIMD's 117 instructions
+// at the 4.8 cycles per instruction the hot-path kernel sustains are 560).  Here the items are dealt by cost: longest
+// first, each to the SIMD with the least work so far (owners' and recorders' steps counted in), within it to the
+// wavefront with the least.  Wavefront w of a workgroup runs on SIMD w % 4.  Costs in issued instructions (kernel_asm):
+// cn per step of a normals item, ca per Philox block of an acceptance item, co / cr per owner / recorder step.
+void mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab)
+{
+  float cn = 128.0f, ca = 110.0f, co = bpl == 1 ? 34.0f : 50.0f, cr = bpl == 1 ? 24.0f : 40.0f;
+  int simd_div = 0;
+  static const char *env = getenv("MCX_PERSIST_COST");  // tuning only: "cn,ca,co,cr[,map]"
+  if (env && *env) {
+    float v[5] = {cn, ca, co, cr, 0.0f};
+    (void)sscanf(env, "%f,%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3], &v[4]);
+    cn = v[0]; ca = v[1]; co = v[2]; cr = v[3]; simd_div = v[4] != 0.0f;
+  }
+  const int nrec = rec ? own : 0, npair = (K + 1) / 2, OB = own * bpl;
+  struct Item { float cost; uint32_t code; };
+  std::vector<Item> items;
+  for (int gp = 0; gp < npair; ++gp)
+    for (int ob = 0; ob < OB; ++ob) items.push_back({2.0f * cn, (uint32_t)(gp << 4 | ob)});
+  const float acc_blocks = (float)((K / 4 + 1 + lpc2 - 1) / lpc2);
+  for (int o = 0; o < own; ++o) items.push_back({acc_blocks * ca + 20.0f, 1u << 14 | (uint32_t)o});
+  items.push_back({10.0f, 2u << 14});
+  std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
+  auto simd_of = [&](int w) { return simd_div ? w / 4 : w % 4; };
+  for (int t = 0; t < 3; ++t) {
+    float simd[4] = {0, 0, 0, 0}, wave[PWAVES] = {};
+    int cnt[PWAVES] = {};
+    uint32_t *T = tab + (size_t)t * PWAVES * PDEAL;
+    for (int i = 0; i < PWAVES * PDEAL; ++i) T[i] = PDEAL_END;
+    const int first_filler = t == 0 ? own : own + nrec;
+    if (t > 0)
+      for (int w = 0; w < own; ++w) simd[simd_of(w)] += (float)K * (co + (t == 2 && !rec ? cr : 0.0f));
+    if (t == 2)
+      for (int w = own; w < own + nrec; ++w) simd[simd_of(w)] += (float)K * cr;
+    for (const Item &it : items) {
+      int best = -1;
+      for (int w = first_filler; w < PWAVES; ++w) {
+        if (cnt[w] >= PDEAL) continue;
+        if (best < 0) { best = w; continue; }
+        const float sb = simd[simd_of(best)], sw = simd[simd_of(w)];
+        if (sw < sb || (sw == sb && wave[w] < wave[best])) best = w;
+      }
+      if (best < 0) break;  // (cannot happen: K <= 32 and <= 8 owners give <= 16 * 16 + 9 items for >= 8 lists of 12 ... checked by the caller)
+      T[best * PDEAL + cnt[best]++] = it.code;
+      simd[simd_of(best)] += it.cost;
+      wave[best] += it.cost;
+    }
+  }
+}
+
+// every item of a phase must find a place in some wavefront's list
+bool mcxk_persist_deal_fits(int bpl, int own, int rec, int K)
+{
+  const int nitems = (K + 1) / 2 * own * bpl + own + 1;
+  return nitems <= (PWAVES - own - (rec ? own : 0)) * PDEAL;
 }
 
 template <int LPC2, int BPL, int LIK, bool REC>

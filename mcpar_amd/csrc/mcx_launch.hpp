@@ -23,4 +23,8 @@ hipError_t mcxk_launch_persist(int lpc, int bpl, int lik, const mcx::RunArgs &a,
 int mcxk_persist_bpl(int lpc, int d, int n, int ncu, int opt);
 size_t mcxk_persist_lds_bytes(int lpc2, int bpl, int own);
 int mcxk_persist_ksteps(int lpc2, int bpl, int own);
+bool mcxk_persist_recorders(int own);
+// RunArgs::deal for a launch with `own` owner wavefronts per workgroup, K steps per phase: tab[3 * 16 * 12]
+void mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab);
+constexpr int MCXK_PERSIST_DEAL_WORDS = 3 * 16 * 12;
 constexpr size_t MCXK_PERSIST_LDS_LIMIT = (size_t)152 << 10;  // dynamic LDS a launch may ask for (160 KB per CU less the static part)

@@ -39,8 +39,7 @@
 
 // How an abandoned tuner meeting is handled inside the step loop (an A/B switch for tools/meet_ab.sh; 2 ships):
 //   0  meetings wait without a bound (round 2; not safe -- measurement only)
-//   1  bounded wait, the owner leaves its step loop on the spot (round 3)
-//   2  bounded wait, the owner goes on to the end of its phase with a zero count (no extra loop exit)
+//   2  bounded wait; after an abandoned meeting the owner goes on to the end of its phase with a zero count
 #ifndef MCX_MEET_VARIANT
 #define MCX_MEET_VARIANT 2
 #endif
@@ -52,6 +51,8 @@ constexpr int PWAVES = PBLOCK / 64;
 constexpr int POWN_MAX = 8;           // owner wavefronts per workgroup: measured 1.2-3x faster than the fused kernels up to 6, equal at 7-8 (tools/persist_sweep.py)
 constexpr int PKMAX = 32;             // most steps per phase (LDS double buffers hold 2 phases)
 constexpr int PTRASH = 16;           // floats of RunArgs::trash per thread of the grid (a float4 per block of the lane)
+constexpr int PDEAL = 12;             // most generator items one wavefront is dealt per phase (RunArgs::deal)
+constexpr uint32_t PDEAL_END = 0xffffffffu;
 constexpr int PEVENTS = 64;           // tuner events (steps 51, 101, ... and the end of the burn-in) one launch can hold
 
 struct RunArgs {
@@ -84,6 +85,11 @@ struct RunArgs {
   int nown;                 // owner wavefronts in the whole grid = ceil(n * LPC / 64)
   int own;                  // owner wavefronts per workgroup (1..POWN_MAX)
   int ksteps;               // steps per phase (mcxk_persist_ksteps: what the LDS double buffers hold, <= PKMAX)
+  // Who generates what (mcxk_persist_deal): [3][PWAVES][PDEAL] item codes, PDEAL_END-terminated, one list per wavefront
+  // for [0] the fill before the first phase (every wavefront but the owners), [1] phases whose concurrent phase is
+  // burn-in, [2] main-loop (the recorders are at work too).  An item = kind << 14 | step pair << 4 | (owner, block):
+  // kind 0 the normals of two consecutive steps, 1 the acceptance logs of one owner, 2 the phase's 1/pwgt values.
+  const uint32_t *deal;
   unsigned long long meet_timeout;  // 100 MHz ticks a tuner meeting may take before the launch is abandoned
   int meet_expect_extra;    // debug (MCX_OPT_DEBUG_MEET): workgroups the meetings wait for beyond the grid's own
 };
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   }
   if (threadIdx.x == 0) { lds_sum = 0; lds_cnt = 0; lds_abort = 0; }
   if (threadIdx.x < PEVENTS) lds_out[threadIdx.x] = ~0ull;
-  const int OWN = a.own, NREC = REC ? OWN : 0, K = a.ksteps;  // steps per phase: a multiple of the generator count
+  const int OWN = a.own, K = a.ksteps;  // steps per phase: a multiple of the generator count
   const int T = a.nburn + a.nmain;
   const int nphase = (T + K - 1) / K;
   const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
@@ -192,38 +198,36 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   // The work of one phase is a list of items dealt round-robin to the `nfill` waves that fill in this
   // iteration (a counter in LDS was measured slower: ~40 same-address atomics per phase serialise).
   const int fq = lane % LPC2, fcl = lane / LPC2;  // this lane's place in its chain and its chain within an owner wavefront
-  auto fill = [&](int phase, int me_fill, int nfill) {
+  const __attribute__((address_space(4))) uint32_t *deal_tab = (const __attribute__((address_space(4))) uint32_t *)a.deal;
+  auto fill = [&](int phase, int table) {
     const int buf = phase & 1, tau0 = phase * K;
     const int ns = T - tau0 < K ? T - tau0 : K;  // steps [tau0, tau0 + ns)
-    // normals: one item = TWO consecutive steps of one block-per-lane set of one owner (two independent Philox /
-    // Box-Muller chains per lane: the lone instruction streams of 3-4 waves do not fill a SIMD otherwise)
-    const int npair = (ns + 1) >> 1, nz_items = npair * OB;
-    const int dq = nfill / OB, dr = nfill - dq * OB;
-    int gp = me_fill / OB, ob = me_fill - gp * OB;  // item i = (step pair gp, owner o, block b), i = (gp * OWN + o) * BPL + b
-    for (int i = me_fill; i < nz_items; i += nfill) {
-      const int o = ob / BPL, b = ob % BPL;
-      const int chain = ((int)blockIdx.x * OWN + o) * CPW + fcl;
-      const int qb = fq * BPL + b;  // the block's index within the chain
-      if (chain < a.n && 4 * qb < d) {
+    const __attribute__((address_space(4))) uint32_t *mylist = deal_tab + ((size_t)table * PWAVES + wv) * PDEAL;
+    for (int j = 0; j < PDEAL; ++j) {
+      const uint32_t item = mylist[j];  // (wave-uniform: a scalar load)
+      if (item == PDEAL_END) break;
+      const int kind = (int)(item >> 14);
+      if (kind == 0) {
+        // normals: one item = TWO consecutive steps of one block-per-lane set of one owner (two independent Philox /
+        // Box-Muller chains per lane: the lone instruction streams of 3-4 waves do not fill a SIMD otherwise)
+        const int gp = (int)((item >> 4) & 0x3ffu), ob = (int)(item & 15u);
         const int g0s = 2 * gp;
-        const uint32_t t = a.t0 + (uint32_t)(tau0 + g0s), gch = a.g0 + (uint32_t)chain;
-        f32x2 ze, zo, ye, yo;
-        normal4_packed(philox4x32_10(t, gch, (uint32_t)qb, 0u, a.seed, ST_LOCAL), ze, zo);
-        normal4_packed(philox4x32_10(t + 1u, gch, (uint32_t)qb, 0u, a.seed, ST_LOCAL), ye, yo);
-        float4 *dst = zbuf + ((size_t)(buf * K + g0s) * OB + ob) * 64 + lane;
-        dst[0] = make_float4(ze.x, ze.y, zo.x, zo.y);  // (even pair, odd pair)
-        if (g0s + 1 < ns) dst[(size_t)OB * 64] = make_float4(ye.x, ye.y, yo.x, yo.y);
-      }
-      gp += dq;
-      ob += dr;
-      if (ob >= OB) { ob -= OB; ++gp; }
-    }
-    // then, dealt on from where the normals ended: OWN items = the logs of the phase's acceptance draws of one
-    // owner (one Philox block of the ACCEPT stream serves 4 steps), and one item = the 1/pwgt values
-    const int first = (me_fill - nz_items % nfill + nfill) % nfill;  // this wave's first index among the tail items
-    for (int j = first; j < OWN + 1; j += nfill) {
-      if (j < OWN) {
-        const int oo = j;
+        if (g0s >= ns) continue;  // (a last, shorter phase)
+        const int o = ob / BPL, b = ob % BPL;
+        const int chain = ((int)blockIdx.x * OWN + o) * CPW + fcl;
+        const int qb = fq * BPL + b;  // the block's index within the chain
+        if (chain < a.n && 4 * qb < d) {
+          const uint32_t t = a.t0 + (uint32_t)(tau0 + g0s), gch = a.g0 + (uint32_t)chain;
+          f32x2 ze, zo, ye, yo;
+          normal4_packed(philox4x32_10(t, gch, (uint32_t)qb, 0u, a.seed, ST_LOCAL), ze, zo);
+          normal4_packed(philox4x32_10(t + 1u, gch, (uint32_t)qb, 0u, a.seed, ST_LOCAL), ye, yo);
+          float4 *dst = zbuf + ((size_t)(buf * K + g0s) * OB + ob) * 64 + lane;
+          dst[0] = make_float4(ze.x, ze.y, zo.x, zo.y);  // (even pair, odd pair)
+          if (g0s + 1 < ns) dst[(size_t)OB * 64] = make_float4(ye.x, ye.y, yo.x, yo.y);
+        }
+      } else if (kind == 1) {
+        // the logs of the phase's acceptance draws of one owner (one Philox block of the ACCEPT stream serves 4 steps)
+        const int oo = (int)(item & 15u);
         const uint32_t tf = a.t0 + (uint32_t)tau0, tl = tf + (uint32_t)ns - 1u;
         const uint32_t bf = tf >> 2, bl = tl >> 2;
         const int c = lane % CPW;
@@ -294,8 +298,16 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   asm volatile("" ::"v"(ly));
   if (owner) __builtin_amdgcn_s_setprio(3);  // the owners' dependent instruction stream goes first on its SIMD
   else if (recorder) __builtin_amdgcn_s_setprio(1);
-  uint32_t cnt = 0, wacc = 0;
-  unsigned long long macc = 0;  // accepted main-loop proposals of this wave
+  uint32_t cnt = 0, cnt_mark = 0;  // accepted proposals of this lane's chain; its value at the last tuner event / end of the burn-in
+  // accepted proposals of the wave's chains since `mark`: the per-chain counters of the chains' first lanes, added up
+  // when somebody asks -- at a tuner event, at the end of the launch -- not ballot by ballot in the step loop
+  // (4 of its ~40 instructions)
+  auto wave_accepts = [&](uint32_t mark) -> uint32_t {
+    uint32_t v = (mine && q == 0) ? cnt - mark : 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
+    return v;
+  };
 
   // the first log2(BPL) stages of the butterfly over the block index, inside the lane; the lane group does the rest
   auto blocks_sum = [&](const float p[BPL]) -> float {
@@ -431,9 +443,8 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
     }
   };
 
-  const int NG = PWAVES - OWN - NREC;  // pure generator waves
   __syncthreads();
-  if (!owner) fill(0, wv - OWN, PWAVES - OWN);  // (nobody has anything to record yet)
+  if (!owner) fill(0, 0);  // (nobody has anything to record yet: the recorders fill too)
   __syncthreads();
   // iteration p: owners run phase p, recorders digest phase p - 1, everybody else fills phase p + 1
   for (int p = 0; p < nphase + (REC ? 1 : 0); ++p) {
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
         float lun = *up;
         // proposal, likelihood, acceptance (src/mcpar.cc:302-312, 62-75); returns the chains of the wave that accepted.
         // The next step's numbers are fetched first: they are on their way while this step computes.
-        auto metropolis = [&](int s) -> uint32_t {
+        auto metropolis = [&](int s) {
           float4 z[BPL];
 #pragma unroll
           for (int b = 0; b < BPL; ++b) z[b] = zn[b];
@@ -488,21 +499,28 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
             xo[b] = take ? po[b] : xo[b];
           }
           ly = take ? lyt : ly;
-          cnt += take ? 1u : 0u;
-          return (uint32_t)__popcll(__ballot(take && q == 0));
+          cnt += take ? 1u : 0u;  // (every lane of a chain counts its chain's accepted proposals)
         };
+
         // Two loops, not one with a branch: the main-loop steps write to LDS, and a wait shared by both kinds of
         // step would have to cover those writes (LDS operations retire in order) on every step.
         int s = 0;
-        for (; s < nb; ++s) {  // ---- burn-in steps (src/mcpar.cc:58-75)
-          wacc += metropolis(s);
-          if (tau0 + s == next_event) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
+        while (s < nb) {  // ---- burn-in steps (src/mcpar.cc:58-75), up to and including the next tuner event's step
+          const int ev = next_event - tau0;  // (>= nb: the event lies in a later phase)
+          const int send = ev < nb ? ev + 1 : nb;
+          for (; s < send; ++s) metropolis(s);  // the step loop proper: nothing in it but the steps
+          if (ev < nb) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
             const int last = next_event;
             const int steps = last - seg_start + 1, check = last > irate ? 1 : 0;
-#if MCX_MEET_VARIANT == 2
-            // An abandoned meeting (wave-uniform) does not leave the step loop -- an extra exit would cost the healthy
-            // run its loop shape: the wave goes on with a count of zero, skips later meetings, and the flag ends the
-            // launch at the next phase boundary; nothing an abandoned launch computes is ever written back.
+            const uint32_t wacc = wave_accepts(cnt_mark);
+            cnt_mark = cnt;
+#if MCX_MEET_VARIANT == 0
+            const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent],
+                                                       a.meet_timeout);
+#else
+            // An abandoned meeting (wave-uniform) does not cut the phase short: the wave goes on with a count of zero,
+            // skips later meetings, and the flag ends the launch at the next phase boundary; nothing an abandoned
+            // launch computes is ever written back.
             unsigned long long seg = 0;
             if (!aborted) {
               seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent], a.meet_timeout);
@@ -515,22 +533,8 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
                 seg = 0;
               }
             }
-#else
-            const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent],
-                                                       a.meet_timeout);
-#if MCX_MEET_VARIANT == 1
-            if (seg == MEET_ABORTED) {  // (wave-uniform) the rest of this phase is not run; the flag ends the launch
-              if (lane == 0) {
-                __hip_atomic_store(&lds_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(a.ctr + 5, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-              s = ns;
-              break;
-            }
-#endif
 #endif
             ++nevent;
-            wacc = 0;
             tun_na += seg;
             tun_nt += (unsigned long long)steps * (unsigned long long)a.n;
             burn_acc += seg;
@@ -554,10 +558,11 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
             next_event = irate + 1 < a.nburn ? irate + 1 : a.nburn - 1;
           }
         }
+        if (nb > 0 && tau0 + nb == a.nburn) cnt_mark = cnt;  // the burn-in ends here: the main loop's accepts count from now
         xq += (size_t)nb * OB * 64;
         lq += (size_t)nb * OWN * CPW;
         for (; s < ns; ++s) {  // ---- main-loop steps (src/mcpar.cc:152-209)
-          macc += metropolis(s);
+          metropolis(s);
           if (REC) {  // hand the state to the recorder (every lane of a chain writes the same ly)
 #pragma unroll
             for (int b = 0; b < BPL; ++b) xq[b * 64] = make_float4(xe[b].x, xe[b].y, xo[b].x, xo[b].y);
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
       }
       // (the recorders do not fill: they are the slowest wavefronts of the workgroup as it is -- with one owner, a
       // recorder that was dealt an item held every phase up: 0.283 -> 0.268 ms per launch on 8-D x 4096 chains)
-      if (p + 1 < nphase && !recorder) fill(p + 1, wv - OWN - NREC, NG);
+      if (p + 1 < nphase && !recorder) fill(p + 1, p * K > a.nburn ? 2 : 1);  // (what runs beside this fill: phases p and p - 1)
     }
     __syncthreads();
   }
@@ -635,6 +640,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
       a.ly[chain] = ly;
       a.acc_cnt[chain] = a.fresh ? cnt : a.acc_cnt[chain] + cnt;
     }
+    const unsigned long long macc = wave_accepts(cnt_mark);  // accepted main-loop proposals of this wave
     if (lane == 0 && macc) atomicAdd(a.ctr + 4, macc);
   }
   if ((REC ? recorder : owner) && live && a.nmain > 0) {

@@ -188,6 +188,7 @@ def test_own_gather_in_flight_and_a_launch_with_meetings(occupy, under):
             e.set_exchange(make_hook(s))
             for _ in range(2):
                 e.run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
+            e.synchronize()  # the last gather's WAIT, in step with the other shard's thread
         except Exception as ex:  # pragma: no cover
             errs.append(ex)
             bar.abort()
