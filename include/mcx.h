@@ -331,7 +331,7 @@ int mcx_device_pci_bus_id(char *buf, size_t len);
  * next to the nominal 8 TB/s. */
 int mcx_debug_copy_bandwidth(size_t bytes, int reps, double *gbps);
 /* host logic of the one-launch small-n kernel, for tests (no device): recorders yes/no and steps per phase for `own` owner
- * wavefronts per workgroup of lpc2 lanes per chain x bpl blocks per lane, and who generates what: tab[3][16][12] item
+ * wavefronts per workgroup of lpc2 lanes per chain x bpl blocks per lane, and who generates what: tab[3][16][24] item
  * codes (0xffffffff ends a wavefront's list; kind << 14 | step pair << 4 | (owner, block)) */
 int mcx_debug_persist_deal(int lpc2, int bpl, int own, int *rec, int *ksteps, uint32_t *tab, int max_words);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:

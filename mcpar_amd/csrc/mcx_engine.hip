@@ -27,6 +27,7 @@ typedef enum { ncclFloat = 7 } ncclDataType_t;
 #endif
 
 #include <algorithm>
+#include <chrono>
 #include <cerrno>
 #include <cmath>
 #include <cstdarg>
@@ -466,12 +467,14 @@ struct mcx_engine {
   DevBuf<float> best_row;            // running maximum-likelihood sample: [0] = log-likelihood, [1..np] = parameters
   DevBuf<unsigned long long> best_key;  // scratch of the arg-max reduction
   mcx_counters cnt{};
+  DevBuf<unsigned long long> trace_clk;  // MCX_PERSIST_TRACE (debug builds): per-wavefront phase clocks of the last small-n launch
   DevBuf<uint32_t> deal_tab;         // RunArgs::deal of the one-launch small-n kernel, for the configuration in deal_key
   std::vector<uint32_t> h_deal;
   long long deal_key = -1;
   uint64_t meet_total = 0;           // runs repeated because a meeting was abandoned, over the engine's life
   int runs_since_broken = 0;         // runs on the per-segment kernels since then (the one-launch kernel is tried again)
   // time the step stream waits for gathers begun earlier (mcx_counters.exchange_wait_ns): event pairs around each wait
+  std::chrono::steady_clock::time_point ht_mark[3];  // MCX_VERBOSE=2: first launch queued / everything queued / stream idle
   std::vector<std::pair<hipEvent_t, hipEvent_t>> xw_pool;
   size_t xw_used = 0;
   std::vector<EvPair> evs;
@@ -676,7 +679,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->cull_keys.release(); e->cull_hist.release(); e->cull_sorted.release(); e->cull_stats.release(); e->cull_box.release();
   e->cull_lim.release(); e->cull_excl.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
-  e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release(); e->deal_tab.release();
+  e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release(); e->deal_tab.release(); e->trace_clk.release();
   for (int b = 0; b < 2; ++b) {
     e->sink_stage[b].release();
     e->sink_pin[b].release();
@@ -1710,7 +1713,18 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
                        const float *incov)
 {
   MCXCHK(enter(e));
+  static const int verbose = getenv("MCX_VERBOSE") ? atoi(getenv("MCX_VERBOSE")) : 0;
+  const auto ht0 = std::chrono::steady_clock::now();
+  e->ht_mark[0] = e->ht_mark[1] = e->ht_mark[2] = ht0;
   int rc = run_once(e, nsamp, nburn, pinit, L, incov);
+  if (verbose >= 2) {  // where the host's share of a run goes: set-up / queued everything / stream idle / done
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    const auto ht3 = std::chrono::steady_clock::now();
+    fprintf(stderr, "mcx: run host timing: to first launch %.1f us, queueing %.1f us, waiting for the stream %.1f us, after %.1f us\n",
+            us(ht0, e->ht_mark[0]), us(e->ht_mark[0], e->ht_mark[1]), us(e->ht_mark[1], e->ht_mark[2]), us(e->ht_mark[2], ht3));
+  }
   uint64_t repeated = 0;
   if (rc == MCX_INTERNAL_MEET_ABANDONED) {
     // A tuner meeting of the one-launch small-n kernel was abandoned: some workgroup of its grid was not
@@ -1838,6 +1852,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     MCXCHK(eval_trials(e, e->pvals.p, e->lylast.p, 0));  // :53
   }
 
+  e->ht_mark[0] = std::chrono::steady_clock::now();
   SegArgs sa;
   sa.x = e->pvals.p; sa.ly = e->lylast.p; sa.mu = e->mu.p; sa.psum2 = e->psum2.p;
   sa.acc_cnt = e->acc_cnt.p; sa.acc_slots = e->acc_slots.p; sa.T = e->cov.p; sa.lik = e->lik.params.p; sa.ncomp = e->lik.ncomp;
@@ -1943,6 +1958,14 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
             e->deal_key = key;
           }
           ra.deal = e->deal_tab.p;
+        }
+        ra.trace_clk = nullptr;
+        if (const char *tf = getenv("MCX_PERSIST_TRACE")) {  // (a -DMCX_PERSIST_TRACE build writes it: tools/persist_trace.py)
+          if (*tf) {
+            MCXCHK(e->trace_clk.alloc((size_t)PTRACE_WG * PWAVES * PTRACE_PH * 2));
+            HIPCHK(hipMemsetAsync(e->trace_clk.p, 0, (size_t)PTRACE_WG * PWAVES * PTRACE_PH * 2 * sizeof(unsigned long long), st));
+            ra.trace_clk = e->trace_clk.p;
+          }
         }
         ra.meet_timeout = (unsigned long long)e->opt_meet_timeout_ms * 100000ull;  // s_memrealtime: 100 MHz
         ra.meet_expect_extra = e->opt_debug_meet;
@@ -2135,8 +2158,10 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   unsigned long long *hctr = e->h_ctr.p;
   MCXCHK(cov_reset(e));  // (a run without any step)
   HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  e->ht_mark[1] = std::chrono::steady_clock::now();
   {
     const hipError_t se = hipStreamSynchronize(st);
+    e->ht_mark[2] = std::chrono::steady_clock::now();
     const bool abandoned = e->meet_check && se == hipSuccess && hctr[5] != 0;  // (the word came with the counters)
     e->meet_check = false;
     (void)meet_release(e, true);
@@ -2146,6 +2171,17 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   e->cnt.naccept_burn = hctr[3];
   e->cnt.naccept_main = hctr[4];
   xwait_collect(e);
+  if (e->trace_clk.p) {  // debug: the phase clocks of the run's last small-n launch, as raw u64 words
+    const char *tf = getenv("MCX_PERSIST_TRACE");
+    if (tf && *tf) {
+      std::vector<unsigned long long> h((size_t)PTRACE_WG * PWAVES * PTRACE_PH * 2);
+      HIPCHK(hipMemcpy(h.data(), e->trace_clk.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(tf, "wb")) {
+        (void)fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+        fclose(f);
+      }
+    }
+  }
   if (sink) MCXCHK(sink_drain(e, sink_seq));
   e->samp_steps = (e->opt_samples && !sink) ? nkeep : 0;
   e->last_nsamp = nsamp;

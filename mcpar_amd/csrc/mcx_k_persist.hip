@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 using namespace mcx;
@@ -49,7 +50,7 @@ int mcxk_persist_bpl(int lpc, int d, int n, int ncu, int opt)
 // phase's items (a two-step item per owner and step pair, one acceptance item per owner) deal out over the filling
 // wavefronts matters as much as the phase count.  With bpl blocks per lane an owner stands for bpl owners' worth of
 // items and LDS.
-bool mcxk_persist_deal_fits(int bpl, int own, int rec, int K);
+bool mcxk_persist_deal_fits(int lpc2, int bpl, int own, int rec, int K);
 
 int mcxk_persist_ksteps(int lpc2, int bpl, int own)
 {
@@ -58,7 +59,8 @@ int mcxk_persist_ksteps(int lpc2, int bpl, int own)
   int k = eff == 1 ? 32 : (eff == 2 ? 16 : (eff == 3 ? 20 : (eff == 4 ? 16 : std::max(PWAVES - own - rec * own, 2))));
   static const char *env = getenv("MCX_PERSIST_KSTEPS");  // tuning only (tools/persist_sweep.py)
   if (env && *env) k = std::max(atoi(env), 2);
-  while (k > 2 && (k > PKMAX || lds_for(lpc2, bpl, own, rec, k) > MCXK_PERSIST_LDS_LIMIT || !mcxk_persist_deal_fits(bpl, own, rec, k))) k -= 2;
+  k &= ~1;  // even: a normals item is two consecutive steps, and both are always stored (mcx_persist.hpp)
+  while (k > 2 && (k > PKMAX || lds_for(lpc2, bpl, own, rec, k) > MCXK_PERSIST_LDS_LIMIT || !mcxk_persist_deal_fits(lpc2, bpl, own, rec, k))) k -= 2;
   return k;
 }
 
@@ -77,29 +79,24 @@ size_t mcxk_persist_lds_bytes(int lpc2, int bpl, int own)
 // first, each to the SIMD with the least work so far (owners' and recorders' steps counted in), within it to the
 // wavefront with the least.  Wavefront w of a workgroup runs on SIMD w % 4.  Costs in issued instructions (kernel_asm):
 // cn per step of a normals item, ca per Philox block of an acceptance item, co / cr per owner / recorder step.
-void mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab)
+bool mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab)
 {
-  float cn = 128.0f, ca = 110.0f, co = bpl == 1 ? 34.0f : 50.0f, cr = bpl == 1 ? 24.0f : 40.0f;
-  int simd_div = 0;
-  static const char *env = getenv("MCX_PERSIST_COST");  // tuning only: "cn,ca,co,cr[,map]"
+  bool fits = true;
+  float cn = 185.0f, ca = 110.0f, co = bpl == 1 ? 34.0f : 50.0f, cr = bpl == 1 ? 24.0f : 40.0f;
+  int simd_div = 0, singles = 1;
+  static const char *env = getenv("MCX_PERSIST_COST");  // tuning only: "cn,ca,co,cr[,map[,singles]]"
   if (env && *env) {
-    float v[5] = {cn, ca, co, cr, 0.0f};
-    (void)sscanf(env, "%f,%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3], &v[4]);
-    cn = v[0]; ca = v[1]; co = v[2]; cr = v[3]; simd_div = v[4] != 0.0f;
+    float v[6] = {cn, ca, co, cr, 0.0f, 1.0f};
+    (void)sscanf(env, "%f,%f,%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]);
+    cn = v[0]; ca = v[1]; co = v[2]; cr = v[3]; simd_div = v[4] != 0.0f; singles = v[5] != 0.0f;
   }
-  const int nrec = rec ? own : 0, npair = (K + 1) / 2, OB = own * bpl;
-  struct Item { float cost; uint32_t code; };
-  std::vector<Item> items;
-  for (int gp = 0; gp < npair; ++gp)
-    for (int ob = 0; ob < OB; ++ob) items.push_back({2.0f * cn, (uint32_t)(gp << 4 | ob)});
-  const float acc_blocks = (float)((K / 4 + 1 + lpc2 - 1) / lpc2);
-  for (int o = 0; o < own; ++o) items.push_back({acc_blocks * ca + 20.0f, 1u << 14 | (uint32_t)o});
-  items.push_back({10.0f, 2u << 14});
-  std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
+  const int nrec = rec ? own : 0, OB = own * bpl, nsteps = K * OB;  // (K is even)
+  const float acc_cost = (float)((K / 4 + 1 + lpc2 - 1) / lpc2) * ca + 20.0f;
   auto simd_of = [&](int w) { return simd_div ? w / 4 : w % 4; };
   for (int t = 0; t < 3; ++t) {
     float simd[4] = {0, 0, 0, 0}, wave[PWAVES] = {};
-    int cnt[PWAVES] = {};
+    int quota[PWAVES] = {}, extra[PWAVES] = {};  // single steps of normals per wavefront; its other items
+    uint32_t other[PWAVES][2 * POWN_MAX] = {};
     uint32_t *T = tab + (size_t)t * PWAVES * PDEAL;
     for (int i = 0; i < PWAVES * PDEAL; ++i) T[i] = PDEAL_END;
     const int first_filler = t == 0 ? own : own + nrec;
@@ -107,53 +104,105 @@ void mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab
       for (int w = 0; w < own; ++w) simd[simd_of(w)] += (float)K * (co + (t == 2 && !rec ? cr : 0.0f));
     if (t == 2)
       for (int w = own; w < own + nrec; ++w) simd[simd_of(w)] += (float)K * cr;
-    for (const Item &it : items) {
-      int best = -1;
-      for (int w = first_filler; w < PWAVES; ++w) {
-        if (cnt[w] >= PDEAL) continue;
-        if (best < 0) { best = w; continue; }
+    auto place = [&](float cost) {  // the wavefront of the least loaded SIMD that has done the least itself
+      int best = first_filler;
+      for (int w = first_filler + 1; w < PWAVES; ++w) {
         const float sb = simd[simd_of(best)], sw = simd[simd_of(w)];
         if (sw < sb || (sw == sb && wave[w] < wave[best])) best = w;
       }
-      if (best < 0) break;  // (cannot happen: K <= 32 and <= 8 owners give <= 16 * 16 + 9 items for >= 8 lists of 12 ... checked by the caller)
-      T[best * PDEAL + cnt[best]++] = it.code;
-      simd[simd_of(best)] += it.cost;
-      wave[best] += it.cost;
-    }
+      simd[simd_of(best)] += cost;
+      wave[best] += cost;
+      return best;
+    };
+    // the big odd items first, then the normals in units of `unit` steps (pairs only: 2; pairs and singles: 1)
+    for (int o = 0; o < own; ++o) { const int w = place(acc_cost); other[w][extra[w]++] = 1u << 14 | (uint32_t)o; }
+    const int unit = singles ? 1 : 2;
+    for (int i = 0; i < nsteps; i += unit) quota[place((float)unit * cn)] += unit;
+    { const int w = place(10.0f); other[w][extra[w]++] = 2u << 14; }
+    // quotas -> items: walk the (owner-block, step) grid; a wavefront with an odd quota shares a pair with the next one
+    int w = first_filler, used = 0, cnt[PWAVES] = {};
+    auto next_wave = [&]() { while (w < PWAVES && used >= quota[w]) { ++w; used = 0; } };
+    next_wave();
+    for (int ob = 0; ob < OB; ++ob)
+      for (int gp = 0; gp < K / 2; ++gp) {
+        next_wave();
+        auto push = [&](int v, uint32_t code) {
+          if (v < PWAVES && cnt[v] < PDEAL) T[v * PDEAL + cnt[v]++] = code;
+          else fits = false;
+        };
+        if (w < PWAVES && quota[w] - used >= 2) {
+          push(w, (uint32_t)(gp << 4 | ob));
+          used += 2;
+        } else {  // one step left here: the pair is split between this wavefront and the next with room
+          push(w, 3u << 14 | (uint32_t)((2 * gp) << 4 | ob));
+          used += 1;
+          next_wave();
+          push(w, 3u << 14 | (uint32_t)((2 * gp + 1) << 4 | ob));
+          used += 1;
+        }
+      }
+    for (int v = first_filler; v < PWAVES; ++v)
+      for (int i = 0; i < extra[v]; ++i) {
+        if (cnt[v] < PDEAL) T[v * PDEAL + cnt[v]++] = other[v][i];
+        else fits = false;
+      }
   }
+  return fits;
 }
 
-// every item of a phase must find a place in some wavefront's list
-bool mcxk_persist_deal_fits(int bpl, int own, int rec, int K)
+// every item of a phase must find a place in its wavefront's list
+bool mcxk_persist_deal_fits(int lpc2, int bpl, int own, int rec, int K)
 {
-  const int nitems = (K + 1) / 2 * own * bpl + own + 1;
-  return nitems <= (PWAVES - own - (rec ? own : 0)) * PDEAL;
+  uint32_t scratch[MCXK_PERSIST_DEAL_WORDS];
+  return mcxk_persist_deal(lpc2, bpl, own, rec, K, scratch);
 }
 
 template <int LPC2, int BPL, int LIK, bool REC>
 static hipError_t go2(const RunArgs &a, hipStream_t st)
 {
-  static bool attr_set = false;  // per instantiation; the value is the largest the kernel can be launched with
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run_small<LPC2, BPL, LIK, REC>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)MCXK_PERSIST_LDS_LIMIT);
+  {  // per instantiation and device; the value is the largest the kernel can be launched with
+    static std::mutex amu;
+    static std::vector<int> adevs;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    std::lock_guard<std::mutex> lk(amu);
+    if (std::find(adevs.begin(), adevs.end(), dev) == adevs.end()) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run_small<LPC2, BPL, LIK, REC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)MCXK_PERSIST_LDS_LIMIT);
+      if (e != hipSuccess) return e;
+      adevs.push_back(dev);
+    }
   }
   const unsigned nwg = (unsigned)((a.nown + a.own - 1) / a.own);
   const size_t lds = mcxk_persist_lds_bytes(LPC2, BPL, a.own);
   if (a.nburn > 0) {
     // tuner meetings inside: every workgroup of the grid must be resident at once.  What the occupancy
-    // calculator and the device's CU count promise is checked here (asked again per launch: it is a table lookup in
-    // the runtime, and engines on several devices and threads share this code); what they cannot see (a CU mask, a
+    // calculator and the device's CU count promise is checked here; what they cannot see (a CU mask, a
     // foreign kernel holding LDS) is caught by the meetings' own timeout.
-    int per_cu = 0, ncu = 0, dev = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_run_small<LPC2, BPL, LIK, REC>), PBLOCK, lds);
-    if (e == hipSuccess) e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    // (the answer is cached per instantiation, device and LDS request: the query costs microseconds of a 0.3 ms job;
+    // engines on several devices and threads share this code, hence the lock)
+    struct Cap { int dev; size_t lds; long long resident; };
+    static std::mutex mu;
+    static std::vector<Cap> caps;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if ((long long)per_cu * ncu < (long long)nwg) return hipErrorCooperativeLaunchTooLarge;
+    long long resident = -1;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (const Cap &c : caps)
+        if (c.dev == dev && c.lds == lds) resident = c.resident;
+      if (resident < 0) {
+        int per_cu = 0, ncu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_run_small<LPC2, BPL, LIK, REC>), PBLOCK, lds);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        resident = (long long)per_cu * ncu;
+        caps.push_back({dev, lds, resident});
+      }
+    }
+    if (resident < (long long)nwg) return hipErrorCooperativeLaunchTooLarge;
   }
   hipLaunchKernelGGL((k_run_small<LPC2, BPL, LIK, REC>), dim3(nwg), dim3(PBLOCK), lds, st, a);
   return hipGetLastError();

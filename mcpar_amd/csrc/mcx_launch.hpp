@@ -25,6 +25,7 @@ size_t mcxk_persist_lds_bytes(int lpc2, int bpl, int own);
 int mcxk_persist_ksteps(int lpc2, int bpl, int own);
 bool mcxk_persist_recorders(int own);
 // RunArgs::deal for a launch with `own` owner wavefronts per workgroup, K steps per phase: tab[3 * 16 * 12]
-void mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab);
-constexpr int MCXK_PERSIST_DEAL_WORDS = 3 * 16 * 12;
+// (false: some wavefront's list overflowed -- mcxk_persist_ksteps never returns such a K)
+bool mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab);
+constexpr int MCXK_PERSIST_DEAL_WORDS = 3 * 16 * 24;
 constexpr size_t MCXK_PERSIST_LDS_LIMIT = (size_t)152 << 10;  // dynamic LDS a launch may ask for (160 KB per CU less the static part)

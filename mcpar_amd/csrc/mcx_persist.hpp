@@ -51,7 +51,8 @@ constexpr int PWAVES = PBLOCK / 64;
 constexpr int POWN_MAX = 8;           // owner wavefronts per workgroup: measured 1.2-3x faster than the fused kernels up to 6, equal at 7-8 (tools/persist_sweep.py)
 constexpr int PKMAX = 32;             // most steps per phase (LDS double buffers hold 2 phases)
 constexpr int PTRASH = 16;           // floats of RunArgs::trash per thread of the grid (a float4 per block of the lane)
-constexpr int PDEAL = 12;             // most generator items one wavefront is dealt per phase (RunArgs::deal)
+constexpr int PTRACE_WG = 4, PTRACE_PH = 128;
+constexpr int PDEAL = 24;             // most generator items one wavefront is dealt per phase (RunArgs::deal)
 constexpr uint32_t PDEAL_END = 0xffffffffu;
 constexpr int PEVENTS = 64;           // tuner events (steps 51, 101, ... and the end of the burn-in) one launch can hold
 
@@ -87,9 +88,12 @@ struct RunArgs {
   int ksteps;               // steps per phase (mcxk_persist_ksteps: what the LDS double buffers hold, <= PKMAX)
   // Who generates what (mcxk_persist_deal): [3][PWAVES][PDEAL] item codes, PDEAL_END-terminated, one list per wavefront
   // for [0] the fill before the first phase (every wavefront but the owners), [1] phases whose concurrent phase is
-  // burn-in, [2] main-loop (the recorders are at work too).  An item = kind << 14 | step pair << 4 | (owner, block):
-  // kind 0 the normals of two consecutive steps, 1 the acceptance logs of one owner, 2 the phase's 1/pwgt values.
+  // burn-in, [2] main-loop (the recorders are at work too).  An item = kind << 14 | step or step pair << 4 | (owner, block):
+  // kind 0 the normals of two consecutive steps, 3 of one step, 1 the acceptance logs of one owner, 2 the phase's 1/pwgt values.
   const uint32_t *deal;
+  // builds with -DMCX_PERSIST_TRACE only (tools/persist_trace.py): [PTRACE_WG workgroups][PWAVES][PTRACE_PH phases][2] shader
+  // clock after the wavefront's own work of the phase / after the barrier that ends it; null otherwise
+  unsigned long long *trace_clk;
   unsigned long long meet_timeout;  // 100 MHz ticks a tuner meeting may take before the launch is abandoned
   int meet_expect_extra;    // debug (MCX_OPT_DEBUG_MEET): workgroups the meetings wait for beyond the grid's own
 };
@@ -207,7 +211,19 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
       const uint32_t item = mylist[j];  // (wave-uniform: a scalar load)
       if (item == PDEAL_END) break;
       const int kind = (int)(item >> 14);
-      if (kind == 0) {
+      if (kind == 3) {
+        // normals of ONE step of one (owner, block) set: what evens the wavefronts' shares out when the pairs do not
+        const int g0s = (int)((item >> 4) & 0x3ffu), ob = (int)(item & 15u);
+        if (g0s >= ns) continue;  // (a last, shorter phase)
+        const int o = ob / BPL, b = ob % BPL;
+        const int chain = ((int)blockIdx.x * OWN + o) * CPW + fcl;
+        const int qb = fq * BPL + b;
+        if (chain < a.n && 4 * qb < d) {
+          f32x2 ze, zo;
+          normal4_packed(philox4x32_10(a.t0 + (uint32_t)(tau0 + g0s), a.g0 + (uint32_t)chain, (uint32_t)qb, 0u, a.seed, ST_LOCAL), ze, zo);
+          zbuf[((size_t)(buf * K + g0s) * OB + ob) * 64 + lane] = make_float4(ze.x, ze.y, zo.x, zo.y);
+        }
+      } else if (kind == 0) {
         // normals: one item = TWO consecutive steps of one block-per-lane set of one owner (two independent Philox /
         // Box-Muller chains per lane: the lone instruction streams of 3-4 waves do not fill a SIMD otherwise)
         const int gp = (int)((item >> 4) & 0x3ffu), ob = (int)(item & 15u);
@@ -223,7 +239,10 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
           normal4_packed(philox4x32_10(t + 1u, gch, (uint32_t)qb, 0u, a.seed, ST_LOCAL), ye, yo);
           float4 *dst = zbuf + ((size_t)(buf * K + g0s) * OB + ob) * 64 + lane;
           dst[0] = make_float4(ze.x, ze.y, zo.x, zo.y);  // (even pair, odd pair)
-          if (g0s + 1 < ns) dst[(size_t)OB * 64] = make_float4(ye.x, ye.y, yo.x, yo.y);
+          // Unconditionally: K is even, so the slot of step g0s + 1 exists even when a last, shorter phase does not use
+          // it -- and a store under `if (g0s + 1 < ns)` made the compiler sink the whole second chain behind the first
+          // (no interleaving: the very thing two steps per item are for).
+          dst[(size_t)OB * 64] = make_float4(ye.x, ye.y, yo.x, yo.y);
         }
       } else if (kind == 1) {
         // the logs of the phase's acceptance draws of one owner (one Philox block of the ACCEPT stream serves 4 steps)
@@ -617,7 +636,18 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
       // recorder that was dealt an item held every phase up: 0.283 -> 0.268 ms per launch on 8-D x 4096 chains)
       if (p + 1 < nphase && !recorder) fill(p + 1, p * K > a.nburn ? 2 : 1);  // (what runs beside this fill: phases p and p - 1)
     }
+#ifdef MCX_PERSIST_TRACE
+    unsigned long long trace_t1 = 0;
+    if (a.trace_clk && blockIdx.x < PTRACE_WG && p < PTRACE_PH) trace_t1 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef MCX_PERSIST_TRACE
+    if (a.trace_clk && blockIdx.x < PTRACE_WG && p < PTRACE_PH && lane == 0) {
+      unsigned long long *tc = a.trace_clk + ((((size_t)blockIdx.x * PWAVES + wv) * PTRACE_PH) + p) * 2;
+      tc[0] = trace_t1;
+      tc[1] = __builtin_amdgcn_s_memtime();
+    }
+#endif
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""One-launch small-n kernel: job time against the cost model of the generator deal (MCX_PERSIST_COST = cn,ca,co,cr[,map];
-mcx_k_persist.hip, mcxk_persist_deal).  One process per point.  usage: persist_cost_sweep.py d n bpl [d n bpl]..."""
+"""One-launch small-n kernel: job time against the generator deal's cost model (MCX_PERSIST_COST =
+cn,ca,co,cr,map,singles; mcx_k_persist.hip, mcxk_persist_deal), recorders yes/no and steps per phase.  One process per
+point.  usage: persist_cost_sweep.py d n [quick]"""
 import os
 import sys
 
@@ -8,23 +9,24 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from persist_bpl_probe import one  # noqa: E402
 
 
-def point(d, n, bpl, cost, k=None):
+def point(d, n, bpl, cost, k, rec):
     os.environ["MCX_PERSIST_COST"] = cost
-    r = one(d, n, bpl, k, None)
-    print("d=%d n=%d bpl=%d K=%s cost=%-22s -> %s" % (d, n, bpl, k, cost, r), flush=True)
+    r = one(d, n, bpl, k, rec)
+    print("d=%d n=%d bpl=%d rec=%s K=%s cost=%-24s -> %s" % (d, n, bpl, rec, k, cost, r), flush=True)
     return r.get("ms", 9e9)
 
 
 if __name__ == "__main__":
-    a = [int(x) for x in sys.argv[1:]]
-    shapes = [(a[i], a[i + 1], a[i + 2]) for i in range(0, len(a) - 2, 3)] or [(16, 8192, 2), (16, 8192, 1), (8, 4096, 1)]
-    for d, n, bpl in shapes:
-        best = (9e9, None)
-        for co in (0, 20, 35, 50, 70, 100, 150, 1000):
-            for cr in (0, 25, 40, 60, 100):
-                c = "128,110,%d,%d" % (co, cr)
-                ms = point(d, n, bpl, c)
-                best = min(best, (ms, c))
-        print("best for d=%d n=%d bpl=%d: %s" % (d, n, bpl, best), flush=True)
-        # the other SIMD mapping (wavefront w on SIMD w / 4) with the best costs: slower if w % 4 is the truth
-        point(d, n, bpl, best[1] + ",1")
+    d, n = int(sys.argv[1]), int(sys.argv[2])
+    best = (9e9, None)
+    for bpl in (1, 2):
+        if d % (8 if bpl == 2 else 4):
+            continue
+        for rec in (1, 0):
+            for k in (16, 24, 32):
+                for singles in (1, 0):
+                    for co, cr in ((34, 24), (50, 40), (80, 50), (20, 10)):
+                        c = "185,110,%d,%d,0,%d" % (co, cr, singles)
+                        ms = point(d, n, bpl, c, k, rec)
+                        best = min(best, (ms, (bpl, rec, k, c)))
+    print("best for d=%d n=%d: %s" % (d, n, best), flush=True)
