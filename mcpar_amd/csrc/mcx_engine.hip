@@ -367,7 +367,7 @@ static int eval_device(const LikDev &L, const float *x, float *y, int n, int d, 
 // the engine
 // ---------------------------------------------------------------------------------------------
 // counters of one run: [0..7] tuner / accept totals, [8..] the tuner events' meeting words of k_run_small
-constexpr int CTR_WORDS = 8 + PEVENTS, CTR_RING = 16;
+constexpr int CTR_WORDS = 8 + PEVENTS * PLEAVES, CTR_RING = 16;
 
 constexpr int SINK_RING = 4;  // blocks of the device ring in sink mode
 

@@ -54,6 +54,7 @@ constexpr int PTRASH = 16;           // floats of RunArgs::trash per thread of t
 constexpr int PTRACE_WG = 4, PTRACE_PH = 128;
 constexpr int PDEAL = 24;             // most generator items one wavefront is dealt per phase (RunArgs::deal)
 constexpr uint32_t PDEAL_END = 0xffffffffu;
+constexpr int PLEAVES = 16;           // words a tuner meeting's arrivals are spread over (same-address atomics cost ~10 ns each)
 constexpr int PEVENTS = 64;           // tuner events (steps 51, 101, ... and the end of the burn-in) one launch can hold
 
 struct RunArgs {
@@ -80,7 +81,7 @@ struct RunArgs {
   int final_publish;        // 1: the launch ends the run of a single shard: slot and sig from the final moments
   float armin, armax, dfac, ifac;
   unsigned long long *ctr;  // [1] tuner naccept [2] tuner ntrial [3] burn-in accepts [4] main-loop accepts [5] a meeting was abandoned
-  unsigned long long *bar;  // one word per tuner event of this launch (<= PEVENTS), zero at launch
+  unsigned long long *bar;  // PLEAVES words per tuner event of this launch (<= PEVENTS events), zero at launch
   float *trace;
   int *ntrace;
   int nown;                 // owner wavefronts in the whole grid = ceil(n * LPC / 64)
@@ -102,63 +103,84 @@ constexpr unsigned long long MEET_ABORT_BIT = 1ull << 63;  // in a meeting word:
 constexpr unsigned long long MEET_ABORTED = ~0ull - 1ull;  // in lds_out / as owners_meet's result: abandon the launch
 
 // all owners of the grid meet; returns the sum of `mine` over the workgroups, or MEET_ABORTED when the meeting
-// was abandoned (some workgroup did not arrive within `timeout` wall-clock ticks).  One atomic per workgroup:
-// the owner waves of a workgroup first add up in LDS.  word = abort << 63 | arrivals << 40 | sum.
-__device__ __forceinline__ unsigned long long owners_meet(unsigned long long *word, unsigned mine, int own, int nwg,
+// was abandoned (some workgroup did not arrive within `timeout` wall-clock ticks).  The owner waves of a workgroup
+// first add up in LDS; the last of them speaks for the workgroup: ONE atomic, on leaf blockIdx % PLEAVES of the
+// event's PLEAVES words (256 arrivals on one word are 256 same-address atomics in a row, ~2.5 us of a 4 us meeting:
+// round 4's trace), then lanes 0 .. PLEAVES - 1 of its wavefront poll one leaf each until the arrivals add up to the grid.
+// leaf = abort << 63 | arrivals << 40 | sum (a meeting's sum is < 2^32: <= 50 steps of <= 2^17 chains).
+// Called by whole wavefronts (wave-uniform arguments).
+__device__ __forceinline__ unsigned long long owners_meet(unsigned long long *leaves, unsigned mine, int own, int nwg,
                                                          unsigned *lds_sum, unsigned *lds_cnt, unsigned long long *lds_out,
                                                          unsigned long long timeout)
 {
-  // (lanes of a wave are in step; only lane 0 talks)
-  unsigned long long total = 0;
-  if ((threadIdx.x & 63u) == 0) {
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned arrived = 0;
+  if (lane == 0) {
     atomicAdd(lds_sum, mine);
     __threadfence_block();
-    const unsigned arrived = atomicAdd(lds_cnt, 1u) + 1u;
-    if (arrived == (unsigned)own) {  // last owner of this workgroup: speak for it
+    arrived = atomicAdd(lds_cnt, 1u) + 1u;
+  }
+  const bool speaker = __builtin_amdgcn_readfirstlane(arrived) == (unsigned)own;  // the last owner of this workgroup
+  unsigned long long total = 0;
+  if (speaker) {
+    if (lane == 0) {
       const unsigned s = atomicExch(lds_sum, 0u);
       atomicExch(lds_cnt, 0u);
-      // the word is the only thing the workgroups share: relaxed device-scope atomics, no cache maintenance
+      // the leaves are the only thing the workgroups share: relaxed device-scope atomics, no cache maintenance
       // (the returned value is consumed: an atomic whose result is never read would stay "pending" for the
       // compiler's s_waitcnt bookkeeping and put vmcnt waits -- on the previous step's stores -- into the step loop)
       const unsigned long long add = (1ull << 40) | (unsigned long long)s;
-      unsigned long long v = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-#if MCX_MEET_VARIANT == 0
-      while ((int)(v >> 40) < nwg) {
-        __builtin_amdgcn_s_sleep(4);
-        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long old = __hip_atomic_fetch_add(leaves + (blockIdx.x % PLEAVES), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(old));
+    }
+    // bounded wait: the constant-rate wall clock, looked at once per 64 polls (reading it is a scalar memory
+    // operation of its own: once per poll it stretched every meeting of a healthy run)
+    unsigned long long t_start = 0;
+    unsigned polls = 0, sum = 0;
+    bool abort = false;
+    for (;;) {
+      const unsigned long long v = lane < (unsigned)PLEAVES ? __hip_atomic_load(leaves + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      unsigned arr = (unsigned)((v & ~MEET_ABORT_BIT) >> 40);
+      sum = (unsigned)v;
+#pragma unroll
+      for (int m = PLEAVES / 2; m >= 1; m >>= 1) {
+        arr += (unsigned)__shfl_xor((int)arr, m);
+        sum += (unsigned)__shfl_xor((int)sum, m);
       }
-#else
-      if ((int)((v & ~MEET_ABORT_BIT) >> 40) < nwg && !(v & MEET_ABORT_BIT)) {
-        // bounded wait: the constant-rate wall clock, looked at once per 64 polls (reading it is a scalar memory
-        // operation of its own: once per poll it stretched every meeting of a healthy run)
-        unsigned long long t_start = 0;
-        unsigned polls = 0;
-        do {
-          __builtin_amdgcn_s_sleep(4);
-          v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((int)((v & ~MEET_ABORT_BIT) >> 40) >= nwg || (v & MEET_ABORT_BIT)) break;
-          if ((++polls & 63u) == 0u) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t_start == 0) t_start = now;
-            else if (now - t_start > timeout)  // someone never arrived: tell everybody
-              v = __hip_atomic_fetch_or(word, MEET_ABORT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | MEET_ABORT_BIT;
+      arr = __builtin_amdgcn_readfirstlane(arr);
+      abort = __ballot((v & MEET_ABORT_BIT) != 0ull) != 0ull;
+      if ((int)arr >= nwg || abort) break;
+#if MCX_MEET_VARIANT != 0
+      if ((++polls & 63u) == 0u) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (t_start == 0) t_start = now;
+        else if (now - t_start > timeout) {  // someone never arrived: tell everybody
+          if (lane == 0) {
+            const unsigned long long o2 = __hip_atomic_fetch_or(leaves, MEET_ABORT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(o2));
           }
-        } while (!(v & MEET_ABORT_BIT));
+          abort = true;
+          break;
+        }
       }
 #endif
-      total = (v & MEET_ABORT_BIT) ? MEET_ABORTED : (v & ((1ull << 40) - 1ull));
-      __hip_atomic_store(lds_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
+      __builtin_amdgcn_s_sleep(2);
+    }
+    total = abort ? MEET_ABORTED : (unsigned long long)__builtin_amdgcn_readfirstlane(sum);
+    if (lane == 0) __hip_atomic_store(lds_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    if (lane == 0) {
       for (;;) {
         total = __hip_atomic_load(lds_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (total != ~0ull) break;
         __builtin_amdgcn_s_sleep(1);
       }
     }
+    // broadcast lane 0's value to the wave
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)total), hi = __builtin_amdgcn_readfirstlane((unsigned)(total >> 32));
+    total = ((unsigned long long)hi << 32) | lo;
   }
-  // broadcast lane 0's value to the wave
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)total), hi = __builtin_amdgcn_readfirstlane((unsigned)(total >> 32));
-  return ((unsigned long long)hi << 32) | lo;
+  return total;
 }
 
 // LPC2 lanes per chain, each holding BPL consecutive 4-parameter blocks (LPC = LPC2 * BPL blocks per chain).  BPL = 2
@@ -318,15 +340,17 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   if (owner) __builtin_amdgcn_s_setprio(3);  // the owners' dependent instruction stream goes first on its SIMD
   else if (recorder) __builtin_amdgcn_s_setprio(1);
   uint32_t cnt = 0, cnt_mark = 0;  // accepted proposals of this lane's chain; its value at the last tuner event / end of the burn-in
+  uint32_t btail = 0;              // its accepted burn-in proposals after the tuner's last decision (added up in the epilogue)
   // accepted proposals of the wave's chains since `mark`: the per-chain counters of the chains' first lanes, added up
   // when somebody asks -- at a tuner event, at the end of the launch -- not ballot by ballot in the step loop
   // (4 of its ~40 instructions)
-  auto wave_accepts = [&](uint32_t mark) -> uint32_t {
-    uint32_t v = (mine && q == 0) ? cnt - mark : 0u;
+  auto wave_sum_chains = [&](uint32_t per_chain) -> uint32_t {  // over the chains of the wave: their first lanes' values
+    uint32_t v = (mine && q == 0) ? per_chain : 0u;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
     return v;
   };
+  auto wave_accepts = [&](uint32_t mark) -> uint32_t { return wave_sum_chains(cnt - mark); };
 
   // the first log2(BPL) stages of the butterfly over the block index, inside the lane; the lane group does the rest
   auto blocks_sum = [&](const float p[BPL]) -> float {
@@ -531,10 +555,21 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
           if (ev < nb) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
             const int last = next_event;
             const int steps = last - seg_start + 1, check = last > irate ? 1 : 0;
+            if (!check) {
+              // The event at the burn-in's last step when the tuner decides nothing there (src/mcpar.cc:78 is false):
+              // nobody's next step depends on this count -- it only completes the burn-in's accept total -- so
+              // nobody waits for it: every wave keeps its share and adds it to the total as the launch ends.
+              btail += cnt - cnt_mark;
+              cnt_mark = cnt;
+              ++nevent;
+              seg_start = last + 1;
+              next_event = a.nburn - 1;
+              continue;  // (s == nb: the burn-in's last step is behind us)
+            }
             const uint32_t wacc = wave_accepts(cnt_mark);
             cnt_mark = cnt;
 #if MCX_MEET_VARIANT == 0
-            const unsigned long long seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent],
+            const unsigned long long seg = owners_meet(a.bar + (size_t)nevent * PLEAVES, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent],
                                                        a.meet_timeout);
 #else
             // An abandoned meeting (wave-uniform) does not cut the phase short: the wave goes on with a count of zero,
@@ -542,7 +577,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
             // launch computes is ever written back.
             unsigned long long seg = 0;
             if (!aborted) {
-              seg = owners_meet(a.bar + nevent, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent], a.meet_timeout);
+              seg = owners_meet(a.bar + (size_t)nevent * PLEAVES, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent], a.meet_timeout);
               if (seg == MEET_ABORTED) {
                 if (lane == 0) {
                   __hip_atomic_store(&lds_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -557,7 +592,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
             tun_na += seg;
             tun_nt += (unsigned long long)steps * (unsigned long long)a.n;
             burn_acc += seg;
-            if (check) {
+            {
               const float arate = (float)tun_na / (float)tun_nt;
               float f = 1.0f;
               if (arate < a.armin) { tun_na = tun_nt = 0; f = a.dfac; }
@@ -672,6 +707,8 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
     }
     const unsigned long long macc = wave_accepts(cnt_mark);  // accepted main-loop proposals of this wave
     if (lane == 0 && macc) atomicAdd(a.ctr + 4, macc);
+    const unsigned long long bt = wave_sum_chains(btail);    // and its burn-in proposals that no meeting counted
+    if (lane == 0 && bt) atomicAdd(a.ctr + 3, bt);
   }
   if ((REC ? recorder : owner) && live && a.nmain > 0) {
     const f32x2 w2 = splat2(a.winv[a.isamp0 + a.nmain - 1]);
@@ -691,7 +728,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.ctr[1] = tun_na;
     a.ctr[2] = tun_nt;
-    a.ctr[3] = (a.fresh ? 0ull : a.ctr[3]) + burn_acc;
+    if (burn_acc) atomicAdd(a.ctr + 3, burn_acc);  // (what the meetings counted; the waves add the rest; the run's block starts at zero)
     *a.ntrace = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
   }
 }
