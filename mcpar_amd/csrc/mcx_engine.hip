@@ -1373,7 +1373,7 @@ extern "C" int mcx_debug_persist_deal(int lpc2, int bpl, int own, int *rec, int 
   if (lpc2 < 1 || lpc2 > 8 || (bpl != 1 && bpl != 2 && bpl != 4) || own < 1 || own > POWN_MAX || !rec || !ksteps || !tab ||
       max_words < MCXK_PERSIST_DEAL_WORDS)
     return fail(MCX_ERR_INVALID, "bad arguments");
-  *rec = mcxk_persist_recorders(own) ? 1 : 0;
+  *rec = mcxk_persist_recorders(own, bpl) ? 1 : 0;
   *ksteps = mcxk_persist_ksteps(lpc2, bpl, own);
   mcxk_persist_deal(lpc2, bpl, own, *rec, *ksteps, tab);
   return MCX_OK;
@@ -1947,7 +1947,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         ra.own = (nown + nwg - 1) / nwg;
         ra.ksteps = mcxk_persist_ksteps(plpc2, pbpl, ra.own);
         {  // who generates what: rebuilt and uploaded only when the launch configuration changes
-          const int prec = mcxk_persist_recorders(ra.own) ? 1 : 0;
+          const int prec = mcxk_persist_recorders(ra.own, pbpl) ? 1 : 0;
           const long long key = (((long long)plpc2 * 8 + pbpl) * 16 + ra.own) * 64 + ra.ksteps + 4096ll * 1024 * prec;
           if (key != e->deal_key) {
             HIPCHK(hipStreamSynchronize(st));  // (an earlier launch may still read the table)

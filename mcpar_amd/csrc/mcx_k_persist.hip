@@ -10,13 +10,17 @@
 
 using namespace mcx;
 
-// recorders (one per owner) where the owner's latency is the bound, not the generators' throughput: measured
-// faster with one or two owner wavefronts per workgroup, equal with three, slower with four
-bool mcxk_persist_recorders(int own)
+// Recorder wavefronts (one per owner: Welford, snapshot, sample emission one phase behind) pay where a workgroup holds ONE
+// set of 64 lanes' worth of chains -- there the owner's dependent chain is the bound and everything taken out of it is
+// time won (8-D x 4096: 0.29 ms with, 0.31 without).  From two sets on the workgroup is bound by the instructions its
+// four SIMDs issue: recording in the owner's own loop saves the hand-over through LDS, frees the recorders' wavefronts
+// and LDS for generating, and ends the launch one phase earlier (round 4, one box: 16-D x 8192 0.444 -> 0.422 ms,
+// 16-D x 12288 0.730 -> 0.574, 16-D x 16384 0.767 -> 0.698, 32-D x 8192 0.779 -> 0.684).
+bool mcxk_persist_recorders(int own, int bpl)
 {
-  static const char *env = getenv("MCX_PERSIST_REC");  // tuning only (tools/persist_sweep.py)
+  static const char *env = getenv("MCX_PERSIST_REC");  // tuning only (tools/persist_config_sweep.py)
   if (env && *env) return atoi(env) != 0;
-  return own <= 2;
+  return own * bpl <= 1;
 }
 
 static size_t lds_for(int lpc2, int bpl, int own, int rec, int K)
@@ -24,40 +28,34 @@ static size_t lds_for(int lpc2, int bpl, int own, int rec, int K)
   return (size_t)2 * (1 + rec) * K * own * bpl * 64 * sizeof(float4) + (size_t)2 * (1 + rec) * K * own * (64 / lpc2) * sizeof(float);
 }
 
-// Blocks per lane (mcx_persist.hpp): two where that halves the owner wavefronts of a workgroup that would hold two or
-// more -- one owner wavefront per workgroup is the regime in which a step costs one wavefront's dependent chain and
-// nothing else -- and the chain's parameters split into 8-parameter lanes.  `opt` = MCX_OPT_BLOCKS_PER_LANE.
+// Blocks per lane (mcx_persist.hpp).  Measured (tools/persist_config_sweep.py, one box, 500 + 1000 steps): with two
+// owner wavefronts per workgroup two blocks per lane change nothing (16-D x 8192: 0.422 ms as 2 owners x 1 block, 0.424
+// as 1 owner x 2 blocks; 8-D x 16384: 0.415 / 0.433) -- a workgroup's time is the instructions its SIMDs issue for
+// generating its chains' normals, and those do not care how the owners hold the chains; with four or more they save the
+// per-chain share of the owners' loops: 16-D x 16384 0.732 -> 0.698, 32-D x 8192 0.714 -> 0.684, 16-D x 24576 1.153 -> 1.079.
+// Never where halving the owner wavefronts would leave CUs without a workgroup (16-D x 12288: 768 owner wavefronts
+// = 3 per CU; as 384 they fill 192 CUs: 0.574 -> 0.689).  `opt` = MCX_OPT_BLOCKS_PER_LANE.
 int mcxk_persist_bpl(int lpc, int d, int n, int ncu, int opt)
 {
   auto legal = [&](int bpl) { return bpl >= 1 && bpl <= lpc && d % (4 * bpl) == 0; };
   if (opt > 0) return legal(opt) && (opt == 1 || opt == 2 || opt == 4) ? opt : 1;
-  int bpl = 1;
-  while (bpl < 2 && legal(2 * bpl)) {
-    const int nown = (int)(((size_t)n * (size_t)(lpc / bpl) + 63) / 64);
-    const int nwg = std::max(std::min(nown, ncu), 1);
-    if ((nown + nwg - 1) / nwg < 2) break;
-    bpl *= 2;
-  }
-  return bpl;
+  if (!legal(2) || ncu < 1) return 1;
+  const long long nown1 = ((long long)n * lpc + 63) / 64, nown2 = ((long long)n * (lpc / 2) + 63) / 64;
+  const long long own1 = (nown1 + std::min<long long>(nown1, ncu) - 1) / std::min<long long>(nown1, ncu);
+  return own1 >= 4 && nown2 >= ncu && nown2 % ncu == 0 ? 2 : 1;
 }
 
-// Steps per phase.  The default is the generators' count (16 - owners - recorders); with 1-3 owners per workgroup
-// longer phases are faster (fewer phase changes for the latency-bound owners), by a table measured on one box with
-// every even length the LDS buffers hold: 8-D x 4096 chains (1 owner; recorders not filling) 14 steps 0.290 ms per
-// launch, 20 -> 0.308, 24 -> 0.274, 28 -> 0.269, 32 -> 0.268; 16-D x 8192 (2 owners) 12 -> 0.407,
-// 14 -> 0.395, 16 -> 0.382; 16-D x 12 288 (3 owners) 13 -> 0.548, 16 -> 0.547, 18 -> 0.508, 20 -> 0.501, 22 -> 0.522;
-// 16-D x 16 384 (4 owners) 8 -> 0.750, 10 -> 0.725, 12 -> 0.661, 14 -> 0.663, 16 -> 0.655.  The pattern is not monotonic: how the
-// phase's items (a two-step item per owner and step pair, one acceptance item per owner) deal out over the filling
-// wavefronts matters as much as the phase count.  With bpl blocks per lane an owner stands for bpl owners' worth of
-// items and LDS.
 bool mcxk_persist_deal_fits(int lpc2, int bpl, int own, int rec, int K);
 
+// Steps per phase: as many as the LDS double buffers hold where a workgroup has one or two sets of chains (fewer phase
+// changes: 8-D x 4096 16 -> 0.308 ms, 24 -> 0.293, 32 -> 0.291; 16-D x 8192 without recorders 16 -> 0.446, 24 -> 0.437,
+// 32 -> 0.422), 16 from three on (16-D x 12288: 12 -> 0.655, 16 -> 0.574, 24 / 32 -> 0.595; 32-D x 8192 with two blocks
+// per lane: 12 -> 0.728, 16 -> 0.684, 24 -> 0.705) -- round 4's sweep, one box.  Even: a generator item is two steps.
 int mcxk_persist_ksteps(int lpc2, int bpl, int own)
 {
-  const int rec = mcxk_persist_recorders(own) ? 1 : 0;
-  const int eff = own * bpl;  // the table goes by the generators' load
-  int k = eff == 1 ? 32 : (eff == 2 ? 16 : (eff == 3 ? 20 : (eff == 4 ? 16 : std::max(PWAVES - own - rec * own, 2))));
-  static const char *env = getenv("MCX_PERSIST_KSTEPS");  // tuning only (tools/persist_sweep.py)
+  const int rec = mcxk_persist_recorders(own, bpl) ? 1 : 0;
+  int k = own * bpl <= 2 ? 32 : 16;
+  static const char *env = getenv("MCX_PERSIST_KSTEPS");  // tuning only (tools/persist_config_sweep.py)
   if (env && *env) k = std::max(atoi(env), 2);
   k &= ~1;  // even: a normals item is two consecutive steps, and both are always stored (mcx_persist.hpp)
   while (k > 2 && (k > PKMAX || lds_for(lpc2, bpl, own, rec, k) > MCXK_PERSIST_LDS_LIMIT || !mcxk_persist_deal_fits(lpc2, bpl, own, rec, k))) k -= 2;
@@ -66,7 +64,7 @@ int mcxk_persist_ksteps(int lpc2, int bpl, int own)
 
 size_t mcxk_persist_lds_bytes(int lpc2, int bpl, int own)
 {
-  return lds_for(lpc2, bpl, own, mcxk_persist_recorders(own) ? 1 : 0, mcxk_persist_ksteps(lpc2, bpl, own));
+  return lds_for(lpc2, bpl, own, mcxk_persist_recorders(own, bpl) ? 1 : 0, mcxk_persist_ksteps(lpc2, bpl, own));
 }
 
 // Who generates what.  A phase's generator items -- the normals of two consecutive steps of one (owner, block) set, the
@@ -83,10 +81,10 @@ bool mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab
 {
   bool fits = true;
   float cn = 185.0f, ca = 110.0f, co = bpl == 1 ? 34.0f : 50.0f, cr = bpl == 1 ? 24.0f : 40.0f;
-  int simd_div = 0, singles = 1;
+  int simd_div = 0, singles = 0;  // (single-step items measured slower wherever they were dealt: 8192 x 16-D +1..7 %)
   static const char *env = getenv("MCX_PERSIST_COST");  // tuning only: "cn,ca,co,cr[,map[,singles]]"
   if (env && *env) {
-    float v[6] = {cn, ca, co, cr, 0.0f, 1.0f};
+    float v[6] = {cn, ca, co, cr, 0.0f, 0.0f};
     (void)sscanf(env, "%f,%f,%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]);
     cn = v[0]; ca = v[1]; co = v[2]; cr = v[3]; simd_div = v[4] != 0.0f; singles = v[5] != 0.0f;
   }
@@ -211,7 +209,7 @@ static hipError_t go2(const RunArgs &a, hipStream_t st)
 template <int LPC2, int BPL, int LIK>
 static hipError_t go(const RunArgs &a, hipStream_t st)
 {
-  return mcxk_persist_recorders(a.own) ? go2<LPC2, BPL, LIK, true>(a, st) : go2<LPC2, BPL, LIK, false>(a, st);
+  return mcxk_persist_recorders(a.own, BPL) ? go2<LPC2, BPL, LIK, true>(a, st) : go2<LPC2, BPL, LIK, false>(a, st);
 }
 
 template <int LPC2, int BPL>

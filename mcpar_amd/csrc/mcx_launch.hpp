@@ -23,7 +23,7 @@ hipError_t mcxk_launch_persist(int lpc, int bpl, int lik, const mcx::RunArgs &a,
 int mcxk_persist_bpl(int lpc, int d, int n, int ncu, int opt);
 size_t mcxk_persist_lds_bytes(int lpc2, int bpl, int own);
 int mcxk_persist_ksteps(int lpc2, int bpl, int own);
-bool mcxk_persist_recorders(int own);
+bool mcxk_persist_recorders(int own, int bpl);
 // RunArgs::deal for a launch with `own` owner wavefronts per workgroup, K steps per phase: tab[3 * 16 * 12]
 // (false: some wavefront's list overflowed -- mcxk_persist_ksteps never returns such a K)
 bool mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab);

@@ -125,10 +125,12 @@ def test_small_n_blocks_per_lane_same_bits_as_oracle(kind, d, n, bpl):
     eg.close()
 
 
-@pytest.mark.parametrize("d,n,want_bpl", [(16, 8192, 2), (16, 16384, 2), (8, 4096, 1), (8, 16384, 2)])
+@pytest.mark.parametrize("d,n,want_bpl", [(16, 8192, 1), (16, 16384, 2), (8, 4096, 1), (8, 16384, 1), (16, 12288, 1)])
 def test_small_n_automatic_blocks_per_lane_full_job(d, n, want_bpl):
-    """the automatic choice on the shapes it is made for: 8192 x 16-D -- the per-GPU shape of a strong-scaled C3 job -- runs
-    with one owner wavefront per workgroup; the whole R-local job (nburn 500 + nsamp 1000, thinned store) against the oracle"""
+    """the automatic choice (mcxk_persist_bpl: two blocks per lane from four owner wavefronts per workgroup on, where the
+    halved grid still fills the chip) on 8192 x 16-D -- the per-GPU shape of a strong-scaled C3 job: two owners, no
+    recorders, 32-step phases -- and its neighbours; the whole R-local job (nburn 500 + nsamp 1000, thinned store)
+    against the oracle"""
     import mcpar_amd as M
     from mcpar_amd import engine as E
     nburn, nsamp, stride = 500, 1000, 50
