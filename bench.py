@@ -18,8 +18,12 @@ library's own in-place ncclAllGather (RCCL over xGMI, mcx_exchange_rccl_*).
 
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries: `end_to_end` (the same job with every sample
 row copied out to host memory), `roofline` with hardware counters collected live by child `rocprofv3 --pmc`
-passes of this same script (falling back to the committed summaries under profiles/, labelled as such),
-the other configurations as `config.other_configs`, and `cpu_baseline` (the CPU oracle on the host cores).
+passes of this same script -- of the kernel that actually ran: its name is taken from the child's own kernel
+trace, and without live counters `frac` is null --, the other configurations as `config.other_configs`,
+`host_callback` (the same shape with a user likelihood on the host), `cpu_baseline` (the CPU oracle on the
+host cores) and, as the LAST key, `summary`: every headline number again in a few hundred bytes, because
+whoever keeps only the tail of a long line should still see them.  What each field means and how it is
+computed is written down once, in DESIGN.md section 6 ("the bench line"), not in the line.
 """
 import argparse
 import csv
@@ -130,11 +134,7 @@ def cpu_baseline(cfg):
     return dict(value=v, unit="chain-steps/s", cores=cores, kind="port",
                 sample="%s: %d chains x %d-D, %d burn-in + %d main steps, pl=%.2f (%d Murray passes), samples kept in "
                        "host memory, OpenMP over chains (%.1f s of %d cores)" % (sample, n, d, nburn, nsamp, pl, passes, dt, cores),
-                reference_equivalent=dict(
-                    value=v / PORT_OVER_REFERENCE, unit="chain-steps/s", port_over_reference=PORT_OVER_REFERENCE,
-                    source="cross-calibration in the build container (8 cores, same job shape): this port 1.49e7 chain-steps/s "
-                           "compute-only, the compiled reference under mpiexec -n 8 6.8e6 compute-only (SURVEY §6 / BASELINE.md); "
-                           "the reference itself cannot run on the GPU box (MKL, MPI and /root/reference do not travel)"))
+                reference_equivalent=dict(value=v / PORT_OVER_REFERENCE, unit="chain-steps/s", port_over_reference=PORT_OVER_REFERENCE))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -192,9 +192,9 @@ def collect_pmc(config_name, n, keep_dir=None, budget_s=150.0):
             # the second job's dispatches only (the first job warms allocations and code objects)
             v = v[len(v) // 2:]
             out.setdefault(k, {})[c] = sum(v) / len(v)
-        for k, v in kd.items():  # dispatch durations under the profiler, of this pass
+        for k, v in kd.items():  # dispatch durations under the profiler, of this pass: (mean ns, dispatches of the measured job)
             v = v[len(v) // 2:]
-            dur.setdefault(k, {})["_".join(group)] = sum(v) / len(v)
+            dur.setdefault(k, {})["_".join(group)] = (sum(v) / len(v), len(v))
     if not keep_dir:
         shutil.rmtree(tmp, ignore_errors=True)
     return out, dur, None
@@ -205,6 +205,31 @@ def find_kernel(table, *needles):
         if all(s in k for s in needles):
             return k
     return None
+
+
+def dominant_kernel(pmc, pdur, family):
+    """the kernel of `family` (a name prefix: k_fused_fast covers k_fused_fastb, k_run_small its instantiations) that the
+    measured child job spent the most time in, by the child's own kernel trace: (name as rocprofv3 reports it, launches of
+    the measured job, mean duration ns)"""
+    best = None
+    for k, by_pass in (pdur or {}).items():
+        if family not in k or not by_pass:
+            continue
+        mean_ns = sum(v[0] for v in by_pass.values()) / len(by_pass)
+        count = max(v[1] for v in by_pass.values())
+        if best is None or mean_ns * count > best[1] * best[2]:
+            best = (k, mean_ns, count)
+    return best
+
+
+def job_stats(eng, runs=1):
+    """what the engine says about its last run (mcx_counters): launches, exchanges and the time the step stream waited for
+    them, tuner meetings of the one-launch small-n kernel that were abandoned (over the engine's life)"""
+    c = eng.counters
+    return dict(kernel_launches_per_run=c["kernel_launches"], exchanges_per_run=c["exchanges"],
+                exchange_waits_per_run=c["exchange_waits"], exchange_wait_ms_per_run=c["exchange_wait_ns"] / 1e6,
+                meet_timeouts=c["meet_timeouts_total"], small_n_launches_per_run=c["small_n_launches"],
+                small_n_blocks_per_lane=c["small_n_blocks_per_lane"])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -245,29 +270,22 @@ def claims_under_the_clock(M, E, headline_ms, headline_n, nburn, nsamp):
         t_full = time_job(eng, vl, p, nsamp, nburn, incov=spd_covariance(d))
         eng.close()
         fc["d%d" % d] = dict(diagonal_ms=t_diag * 1e3, full_ms=t_full * 1e3, ratio=t_full / t_diag)
-    fc["what"] = ("Rosenbrock1(d) x 65 536 chains, R-local job (nburn %d, nsamp %d), no sample rows kept; full = run(..., incov) with "
-                  "a dense SPD covariance (x' = x + T z, T its Cholesky factor, src/mcpar.cc:302-312,454-484)" % (nburn, nsamp))
     out["full_cov"] = fc
     d, n = 16, 8192
     vl, _k = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eng = M.Engine(d, n, pl=1.0)
     t_small = time_job(eng, vl, pinit_for(d, n, 0), nsamp, nburn, reps=11)
-    launches = eng.counters["kernel_launches"]
+    st = job_stats(eng)
     eng.close()
     out["strong_proxy"] = dict(chains=n, ms_per_job=t_small * 1e3, value=n * (nburn + nsamp) / t_small, unit="chain-steps/s",
-                               kernel_launches_per_run=launches, headline_chains=headline_n, headline_ms_per_job=headline_ms,
-                               speedup_vs_headline_job=headline_ms / (t_small * 1e3),
-                               what="the per-GPU share of the headline job strong-scaled over 8 GPUs (65 536 / 8 chains x 16-D, same "
-                                    "nburn / nsamp, sample rows kept), timed in this process next to the headline job; the exchange "
-                                    "is not included (one 1 MiB-per-rank all-gather per run in the default schedule)")
+                               headline_chains=headline_n, headline_ms_per_job=headline_ms,
+                               speedup_vs_headline_job=headline_ms / (t_small * 1e3), stats=st)
     d, n = 16, 65536
     eng = M.Engine(d, n, pl=1.0)
     eng.run(20, 100, pinit_for(d, n, 0), vl)
     acc = eng.counters["naccept_main"] / float(n * 20)
     eng.close()
-    out["accept_rate_reference_shape"] = dict(value=acc, reference=0.0468, workload="Rosenbrock1(16) x 65 536 chains, nburn 100 + nsamp 20, pl = 1",
-                                              source="BASELINE.md: derived from the samples of the unmodified reference in the survey "
-                                                     "container (RNG differs by design: statistical agreement)")
+    out["accept_rate_reference_shape"] = dict(value=acc, reference=0.0468, workload="Rosenbrock1(16) x 65 536 chains, nburn 100 + nsamp 20, pl = 1")
     return out
 
 
@@ -499,8 +517,7 @@ def main():
         ke = max(1, args.steps // 2)
         de = timed(job, ke)
         ref_sched = dict(value=float(world) * n * (nburn + nsamp) * ke / de, unit="chain-steps/s", steps=ke,
-                         ms_per_step=de / ke * 1e3, exchanges_per_run=eng.counters["exchanges"],
-                         what="MCX_OPT_EAGER_EXCHANGE=1: one all-gather per SYNCSTEP main-loop steps like the reference")
+                         ms_per_step=de / ke * 1e3, stats=job_stats(eng))  # MCX_OPT_EAGER_EXCHANGE = 1: a gather per sync point
         eng.set_option(E.OPT_EAGER_EXCHANGE, 0)
 
     # ---- live timing of the dominant kernels: HIP events on the engine's stream (MCX_OPT_PROFILE) --------
@@ -516,75 +533,46 @@ def main():
     sync()
 
     def murray_block(c, nn, pr, cn):
-        """k_remote_sweep in flops (n_act N (3d+4) per pass + one exp per pair)"""
+        """k_remote_sweep in ALGORITHMIC flops (n_act N (3d+4) per pass; DESIGN.md 6 "the bench line")"""
         sw = pr["remote_sweep"]
         if sw["launches"] <= 0 or sw["ms"] <= 0:
             return None
         dd = c["d"]
-        dm = 2
-        while dm < dd:
-            dm <<= 1
         flops = sw["chain_steps"] * (3 * dd + 4)
         ach = flops / (sw["ms"] * 1e-3)
-        return dict(bound="valu", kernel="k_remote_sweep<DMAX=%d>" % dm, achieved=ach / 1e12, peak=FP32_VALU_PEAK / 1e12,
-                    unit="TFLOP/s", frac=ach / FP32_VALU_PEAK, pairs=sw["chain_steps"], exp_per_pair=1,
-                    flop_per_pair=3 * dd + 4, launches=sw["launches"], total_ms=sw["ms"],
-                    remote_steps=cn["remote_steps"], passes=cn["remote_passes"], whole_genremote_ms=pr["remote"]["ms"],
-                    pairs_evaluated=cn.get("remote_pairs_evaluated"),
-                    pairs_evaluated_frac=(cn.get("remote_pairs_evaluated", 0) / float(cn["remote_pairs"]) if cn.get("remote_pairs") else None),
-                    formula="ALGORITHMIC flops, exclusions and early-outs included: achieved = pairs * (3d+4) / sum of k_remote_sweep "
-                            "durations (HIP events, this run), pairs = every (chain, Q_i) pair the reference loops over "
-                            "(src/mcpar.cc:367-395, 421-437) whether or not the kernel had to finish it; pairs_evaluated = the "
-                            "pairs left after the exact exclusion bound (mcx_counters.remote_pairs_evaluated); "
-                            "peak = fp32 vector peak 157.3 TFLOP/s (MI355X_MICROARCH.md); the polynomial exp per pair is "
-                            "not counted as flops")
+        return dict(bound="valu", kernel="k_remote_sweep*", achieved=ach / 1e12, peak=FP32_VALU_PEAK / 1e12,
+                    unit="TFLOP/s", frac=ach / FP32_VALU_PEAK, pairs=sw["chain_steps"], flop_per_pair=3 * dd + 4,
+                    launches=sw["launches"], total_ms=sw["ms"], remote_steps=cn["remote_steps"], passes=cn["remote_passes"],
+                    whole_genremote_ms=pr["remote"]["ms"], pairs_evaluated=cn.get("remote_pairs_evaluated"),
+                    pairs_evaluated_frac=(cn.get("remote_pairs_evaluated", 0) / float(cn["remote_pairs"]) if cn.get("remote_pairs") else None))
 
-    roofline = murray = cpu = end_to_end = claims = None
+    roofline = murray = cpu = end_to_end = claims = host_cb = None
     others = {}
     if rank == 0:
         fm, fb, rs = prof["fused_main"], prof["fused_burn"], prof["run_small"]
-        split = prof["gen_normals"]["launches"] > 0
-        lpc = lpc_for(d)
-        likname = {1: "LIK_ROSEN1", 5: "LIK_MIX", 6: "LIK_ROSEN2F"}[cfg["lik"]]
         if rs["launches"] > 0 and rs["ms"] > 0:
             # small-n mode: burn-in and main-loop steps run in ONE launch of k_run_small (mcx_persist.hpp)
-            kmatch = "k_run_small<%d, %d" % (lpc, cfg["lik"])
             t_launch = rs["ms"] * 1e-3 / rs["launches"]
             abytes = float(n) * (nburn * alg_bytes_per_chain_step(d, False, False) + nsamp * alg_bytes_per_chain_step(d, True, emit))
             frac_local = rs["chain_steps"] / float(n * (nburn + nsamp))  # launches cover this share of the job's local steps
             alg = abytes * frac_local / (rs["ms"] * 1e-3)
-            roofline = dict(
-                bound="valu", kernel=kmatch + ", ...> (%s; small-n mode: owner / recorder / generator wavefronts, one launch)" % likname,
-                kernel_match=kmatch, avg_launch_ms=t_launch * 1e3, launches=rs["launches"],
-                chain_steps_per_launch=rs["chain_steps"] / rs["launches"],
-                timing="HIP events on the engine's stream around each launch, this run (MCX_OPT_PROFILE)",
-                hbm_alg=dict(achieved=alg / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=alg / HBM_PEAK,
-                             formula="SURVEY §8d bytes (burn-in 8d+8, main 24d+8 + sample row 4(d+1) per chain-step) / launch duration / 8 TB/s",
-                             note="NOT a fraction of a physical bound (state stays in registers, random numbers in LDS); "
-                                  "hbm_measured is what the memory system sees"))
+            roofline = dict(bound="valu", kernel=None, kernel_family="k_run_small", avg_launch_ms=t_launch * 1e3, launches=rs["launches"],
+                            chain_steps_per_launch=rs["chain_steps"] / rs["launches"],
+                            hbm_alg=dict(achieved=alg / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=alg / HBM_PEAK))
         elif fm["launches"] > 0 and fm["ms"] > 0:
-            kname = "k_fused_fast<%d, true, %d, %s>" % (lpc, cfg["lik"], "true" if split else "false")
             bpc = alg_bytes_per_chain_step(d, True, emit)
             t_launch = fm["ms"] * 1e-3 / fm["launches"]
             alg = fm["chain_steps"] * bpc / (fm["ms"] * 1e-3)
-            roofline = dict(
-                bound="valu", kernel=kname + " (%s%s)" % (likname, ", small-n mode: includes k_gen_normals" if split else ""),
-                kernel_match="k_fused_fast<%d, true" % lpc,
-                avg_launch_ms=t_launch * 1e3, launches=fm["launches"], chain_steps_per_launch=fm["chain_steps"] / fm["launches"],
-                timing="HIP events on the engine's stream around each launch, this run (MCX_OPT_PROFILE)",
-                hbm_alg=dict(achieved=alg / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=alg / HBM_PEAK,
-                             bytes_per_chain_step=bpc,
-                             formula="SURVEY §8d bytes (state round trip 24d+8 + sample row 4(d+1)) x chain-steps per launch / "
-                                     "avg launch duration / 8 TB/s",
-                             note="NOT a fraction of a physical bound: the fused kernel keeps x, ly, mu, S in registers across "
-                                  "the launch's steps, so only the sample rows (and the state once per launch) reach HBM; "
-                                  "a value above 1 is the saved traffic, hbm_measured is what the memory system sees"),
-                burn_kernel=dict(bytes_per_chain_step=alg_bytes_per_chain_step(d, False, False),
-                                 avg_launch_ms=fb["ms"] / max(fb["launches"], 1), launches=fb["launches"],
-                                 hbm_alg_GBps=(fb["chain_steps"] * alg_bytes_per_chain_step(d, False, False)
-                                               / max(fb["ms"] * 1e-3, 1e-12)) / 1e9))
+            roofline = dict(bound="valu", kernel=None, kernel_family="k_fused_fast", avg_launch_ms=t_launch * 1e3, launches=fm["launches"],
+                            chain_steps_per_launch=fm["chain_steps"] / fm["launches"],
+                            hbm_alg=dict(achieved=alg / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=alg / HBM_PEAK, bytes_per_chain_step=bpc),
+                            burn_kernel=dict(bytes_per_chain_step=alg_bytes_per_chain_step(d, False, False),
+                                             avg_launch_ms=fb["ms"] / max(fb["launches"], 1), launches=fb["launches"],
+                                             hbm_alg_GBps=(fb["chain_steps"] * alg_bytes_per_chain_step(d, False, False)
+                                                           / max(fb["ms"] * 1e-3, 1e-12)) / 1e9))
         if cfg["pl"] < 1.0:
             murray = murray_block(cfg, n, prof, pcnt)
+    headline_stats = job_stats(eng)
 
     # ---- N > 1: a Murray (pl < 1) configuration over the same ranks, first-class next to the R-local number ----
     murray_multi = None
@@ -595,11 +583,12 @@ def main():
         j5.run()
         k5 = max(1, min(3, args.steps))
         d5 = timed(j5, k5)
+        st5 = job_stats(j5.eng)
         p5, c5cnt = profiled(j5)
         sync()
         murray_multi = dict(workload=workload_text(c5, c5["n"]), value=float(world) * c5["n"] * (c5["nburn"] + c5["nsamp"]) * k5 / d5,
                             unit="chain-steps/s", steps=k5, ms_per_step=d5 / k5 * 1e3, remote_steps=c5cnt["remote_steps"],
-                            passes=c5cnt["remote_passes"], exchanges_per_run=c5cnt["exchanges"],
+                            passes=c5cnt["remote_passes"], stats=st5,
                             sweep=murray_block(c5, c5["n"], p5, c5cnt) if rank == 0 else None)
         j5.close()
         job = None
@@ -611,16 +600,19 @@ def main():
         ns_ = total // world
         cs["n"] = ns_
         js = make_job(cs, ns_, emit)
-        for _ in range(3):
-            js.run()
-        ks = max(10, args.steps)
-        ds_ = timed(js, ks)
-        strong_multi = dict(workload=workload_text(cs, ns_), chains_total=total, chains_per_gpu=ns_,
-                            value=float(total) * (nburn + nsamp) * ks / ds_, unit="chain-steps/s", steps=ks,
-                            ms_per_step=ds_ / ks * 1e3, exchanges_per_run=js.eng.counters["exchanges"],
-                            kernel_launches_per_run=js.eng.counters["kernel_launches"],
-                            what="the N = 1 job (%d chains in all) split evenly over the ranks: ms_per_step against the N = 1 "
-                                 "run's ms_per_step is the strong-scaling speed-up" % total)
+        strong_multi = dict(workload=workload_text(cs, ns_), chains_total=total, chains_per_gpu=ns_, unit="chain-steps/s")
+        # default: a launch with tuner meetings starts behind the engine's own in-flight gather; then with the next run's
+        # burn-in under it (MCX_OPT_MEET_UNDER_GATHER = 1; the meetings' timeout is the net: meet_timeouts says if it was needed)
+        for key, under in (("behind_the_gather", 0), ("under_the_gather", 1)):
+            js.eng.set_option(E.OPT_MEET_UNDER_GATHER, under)
+            for _ in range(3):
+                js.run()
+            ks = max(10, args.steps)
+            ds_ = timed(js, ks)
+            strong_multi[key] = dict(value=float(total) * (nburn + nsamp) * ks / ds_, steps=ks, ms_per_step=ds_ / ks * 1e3,
+                                     stats=job_stats(js.eng))
+        strong_multi["value"] = strong_multi["behind_the_gather"]["value"]
+        strong_multi["ms_per_step"] = strong_multi["behind_the_gather"]["ms_per_step"]
         js.close()
 
     # ---- N = 1 extras: end to end, other configurations, counters, CPU baseline ---------------------------
@@ -667,10 +659,7 @@ def main():
                 got = eng.samples_text_into(nsamp - ts, ts, tbuf)
                 dtx = time.perf_counter() - t0
                 text = dict(steps=ts, numbers=ts * n * (d + 1), bytes=int(got), ms=dtx * 1e3, GBps=got / dtx / 1e9,
-                            numbers_per_s=ts * n * (d + 1) / dtx, first_row=bytes(tbuf[:min(got, 60)]).decode("ascii", "replace"),
-                            what="mcx_samples_text: %d steps of the run's rows as the text the reference prints (printf %%g, two blanks "
-                                 "per field), two formatting passes on the GPU + one copy into pageable host memory; glibc's "
-                                 "snprintf does ~7e6 such numbers per second and core" % ts)
+                            numbers_per_s=ts * n * (d + 1) / dtx, first_row=bytes(tbuf[:min(got, 60)]).decode("ascii", "replace"))
                 del tbuf
             except Exception as ex:  # noqa: BLE001
                 text = dict(error=repr(ex))
@@ -690,21 +679,14 @@ def main():
                 dts = time.perf_counter() - t0
                 eng.set_text_sink(None, 0)
                 if isinstance(text, dict):
-                    text["whole_job_through_the_text_sink"] = dict(
-                        ms_per_step=dts * 1e3, bytes=int(tbytes[0]), GBps=tbytes[0] / dts / 1e9, value=n * (nburn + nsamp) / dts,
-                        unit="chain-steps/s", what="the job of `value` with all %d x %d rows delivered as text in pinned host memory, "
-                        "blocks of %d steps" % (nsamp, n, blk))
+                    text["whole_job_through_the_text_sink"] = dict(ms_per_step=dts * 1e3, bytes=int(tbytes[0]), GBps=tbytes[0] / dts / 1e9,
+                                                                   value=n * (nburn + nsamp) / dts, unit="chain-steps/s")
             except Exception as ex:  # noqa: BLE001
                 if isinstance(text, dict):
                     text["whole_job_through_the_text_sink"] = dict(error=repr(ex))
             end_to_end = dict(value=n * (nburn + nsamp) / de, unit="chain-steps/s", ms_per_step=de * 1e3, steps=ke,
                               host_bytes_per_job=int(nbytes), host_GBps=nbytes / de / 1e9, sink_block_steps=blk,
-                              what="the same job with every sample row (MCout layout, np+1 columns) delivered to a consumer in "
-                                   "pinned host memory through mcx_set_sink, copy-out overlapped with the steps; `value` keeps "
-                                   "the rows in HBM",
-                              copy_after_the_run=dict(value=n * (nburn + nsamp) / dc, ms_per_step=dc * 1e3,
-                                                      what="whole run kept in HBM, then mcx_samples_copy into pageable host memory"),
-                              text=text)
+                              copy_after_the_run=dict(value=n * (nburn + nsamp) / dc, ms_per_step=dc * 1e3), text=text)
         job.close()
         job = None
         if not args.no_extras:
@@ -722,10 +704,10 @@ def main():
                 for _ in range(k):
                     j.run()
                 dd = (time.perf_counter() - t0) / k
+                st = job_stats(j.eng)
                 pr, cn = profiled(j)
                 o = dict(workload=workload_text(c, c["n"]), value=c["n"] * (c["nburn"] + c["nsamp"]) / dd, unit="chain-steps/s",
-                         ms_per_step=dd * 1e3, steps=k, accept_rate_main=cn["naccept_main"] / float(c["n"] * c["nsamp"]),
-                         kernel_launches_per_run=cn["kernel_launches"])
+                         ms_per_step=dd * 1e3, steps=k, accept_rate_main=cn["naccept_main"] / float(c["n"] * c["nsamp"]), stats=st)
                 if c["pl"] < 1.0:
                     o["remote_steps"], o["passes"] = cn["remote_steps"], cn["remote_passes"]
                     o["sweep"] = murray_block(c, c["n"], pr, cn)
@@ -736,43 +718,45 @@ def main():
             try:  # the HBM figures also against a device-copy bandwidth measured on this box
                 g = C.c_double(0.0)
                 if lib.mcx_debug_copy_bandwidth(C.c_size_t(1 << 30), 10, C.byref(g)) == 0 and g.value > 0:
-                    roofline["device_copy_GBps"] = dict(value=g.value, what="10 device-to-device copies of 1 GiB, (read + written bytes) / "
-                                                        "HIP-event time (mcx_debug_copy_bandwidth)", frac_of_nominal=g.value * 1e9 / HBM_PEAK)
+                    roofline["device_copy_GBps"] = dict(value=g.value, frac_of_nominal=g.value * 1e9 / HBM_PEAK)
             except Exception as ex:  # noqa: BLE001
-                roofline["device_copy_GBps"] = dict(value=None, what=repr(ex))
+                roofline["device_copy_GBps"] = dict(value=None, error=repr(ex))
             pmc = pdur = None
             note = "--no-pmc"
             if not args.no_pmc:
                 pmc, pdur, note = collect_pmc(args.config, n, keep_dir=args.keep_pmc or None)
-            kk = find_kernel(pmc, roofline["kernel_match"])
+            # the kernel that RAN: the one of the family the child job spent the most time in, under the name its kernel
+            # trace gives it (k_fused_fastb<LPC2, BPL, ...> when the engine chose several blocks per lane, ...)
+            dom = dominant_kernel(pmc, pdur, roofline["kernel_family"])
+            kk = dom[0] if dom else None
+            if kk:
+                roofline["kernel"] = kk.split("(")[0].replace("void mcx::", "")
+                roofline["kernel_trace"] = dict(avg_ns_under_the_profiler=dom[1], launches_per_job=dom[2])
+            else:
+                roofline["kernel"] = roofline["kernel_family"] + "<?> (no kernel trace: %s)" % note
             t_launch = roofline["avg_launch_ms"] * 1e-3
+            small = roofline["kernel_family"] == "k_run_small"
             if kk and all(c in pmc[kk] for c in ("FETCH_SIZE", "WRITE_SIZE")):
                 traffic = (2.0 * pmc[kk]["FETCH_SIZE"] + pmc[kk]["WRITE_SIZE"]) * 1024.0
-                src = ("live: child `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of `bench.py --pmc-child` "
-                       "(same configuration), mean over the measured job's launches of this kernel")
                 roofline["hbm_measured"] = dict(
                     traffic=traffic, achieved=traffic / t_launch / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                    frac=traffic / t_launch / HBM_PEAK, source=src,
+                    frac=traffic / t_launch / HBM_PEAK, source="live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes",
                     frac_of_measured_copy_bandwidth=(traffic / t_launch / 1e9 / roofline["device_copy_GBps"]["value"]
                                                      if (roofline.get("device_copy_GBps") or {}).get("value") else None),
-                    formula="bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (FETCH_SIZE doubled: gfx950 correction for 16-B/lane "
-                            "streaming reads, MI355X_MICROARCH.md HBM section); frac = bytes / avg launch duration (HIP events) / 8 TB/s",
-                    unavoidable_bytes=fm_unavoidable(d, n, roofline["chain_steps_per_launch"] * (nsamp / float(nburn + nsamp) if "k_run_small" in roofline["kernel_match"] else 1.0), emit))
+                    unavoidable_bytes=fm_unavoidable(d, n, roofline["chain_steps_per_launch"] * (nsamp / float(nburn + nsamp) if small else 1.0), emit))
                 roofline["traffic"] = traffic
             if kk and all(c in pmc[kk] for c in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
                 busy, insts, gui = pmc[kk]["SQ_ACTIVE_INST_VALU"], pmc[kk]["SQ_INSTS_VALU"], pmc[kk]["GRBM_GUI_ACTIVE"]
                 cyc = gui / 8.0
-                dur_ns = (pdur.get(kk) or {}).get("GRBM_GUI_ACTIVE")
+                dur_ns = ((pdur.get(kk) or {}).get("GRBM_GUI_ACTIVE") or (None,))[0]
                 waves = (n * lpc_for(d) + 63) // 64
                 steps_per_launch = roofline["chain_steps_per_launch"] / n
-                if "k_run_small" in roofline["kernel_match"]:
+                if small:
                     waves = 16 * min(waves, 256)  # every wavefront of the grid: owners, recorders, generators
                 v = dict(SQ_INSTS_VALU=insts, SQ_ACTIVE_INST_VALU=busy, GRBM_GUI_ACTIVE=gui,
                          valu_instructions_per_wave_step=insts / (waves * steps_per_launch),
                          kernel_clock_GHz=(cyc / dur_ns) if dur_ns else None,
-                         instructions_per_4_cycles_per_simd=4.0 * insts / (N_SIMD * cyc),
-                         source="live: child `rocprofv3 --pmc <group>` passes of `bench.py --pmc-child` (one pass per group: %s)"
-                                % " | ".join(" ".join(g) for g in PMC_PASSES[2:]))
+                         instructions_per_4_cycles_per_simd=4.0 * insts / (N_SIMD * cyc), source="live rocprofv3 --pmc child passes")
                 need = ("SQ_INSTS_VALU_FLOPS_FP32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_FMA_F32",
                         "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32")
                 if all(c in pmc[kk] for c in need):
@@ -783,38 +767,29 @@ def main():
                     packed = min(max((flops - base) / max(base, 1.0), 0.0), 1.0) * (fma + add + mul)  # v_pk_*_f32 count twice in FLOPS
                     plain = max(insts - packed - i64 - trans, 0.0)
                     issue = 2.0 * plain + 4.0 * (packed + i64) + 8.0 * trans  # wave64 on a SIMD-32: MI355X_MICROARCH.md
-                    t_prof = dur_ns * 1e-9 if dur_ns else None
                     v.update(SQ_INSTS_VALU_FLOPS_FP32=flops, SQ_INSTS_VALU_FMA_F32=fma, SQ_INSTS_VALU_ADD_F32=add,
                              SQ_INSTS_VALU_MUL_F32=mul, SQ_INSTS_VALU_INT64=i64, SQ_INSTS_VALU_TRANS_F32=trans,
                              SQ_INSTS_VALU_IOPS=c_.get("SQ_INSTS_VALU_IOPS"), packed_f32_instructions_est=packed,
                              plain_instructions_est=plain, issue_cycles=issue,
                              frac_at_measured_issue_intervals=(2.7 * plain + 4.7 * (packed + i64) + 8.2 * trans) / (N_SIMD * cyc),
-                             frac_at_measured_issue_intervals_note="same counters priced with the issue intervals tools/ubench.hip "
-                                                                   "measured on this chip at 4 waves/SIMD (full-rate 2.7 cycles, "
-                                                                   "v_pk_*_f32 / v_mad_u64_u32 4.7, v_sqrt_f32 8.2) instead of the "
-                                                                   "architectural 2 / 4 / 8",
                              fp32_TFLOPs=(flops * 64.0 / t_launch / 1e12),
                              fp32_frac_of_vector_peak=(flops * 64.0 / t_launch) / FP32_VALU_PEAK)
-                    roofline.update(
-                        achieved=issue / cyc, peak=float(N_SIMD), unit="SIMDs' worth of VALU issue slots in use (of 1024)",
-                        frac=issue / (N_SIMD * cyc),
-                        formula="frac = (2*plain + 4*(packed_f32 + int64) + 8*transcendental) issue cycles / (1024 SIMDs * "
-                                "GRBM_GUI_ACTIVE/8 kernel cycles).  A wave64 instruction occupies its SIMD-32 for 2 cycles, "
-                                "v_pk_*_f32 and 64-bit integer multiplies (Philox) for 4, v_sqrt_f32 for 8 (MI355X_MICROARCH.md, "
-                                "instruction table); instruction classes from SQ_INSTS_VALU_{INT64,TRANS_F32,FMA_F32,ADD_F32,"
-                                "MUL_F32}; packed_f32 = the share of f32 instructions that SQ_INSTS_VALU_FLOPS_FP32 counts twice. "
-                                "DPP and cross-lane instructions are priced as plain, so the figure errs low: 1.0 means every "
-                                "SIMD issues a vector instruction whenever it can")
+                    roofline.update(achieved=issue / cyc, peak=float(N_SIMD), unit="SIMDs' worth of VALU issue slots in use (of 1024)",
+                                    frac=issue / (N_SIMD * cyc))
                 else:
                     roofline.update(achieved=2.0 * insts / cyc, peak=float(N_SIMD), unit="VALU instructions per 2 cycles (of 1024 SIMDs)",
-                                    frac=2.0 * insts / (N_SIMD * cyc),
-                                    formula="frac = 2*SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8): instruction classes were "
-                                            "not collected, every instruction priced at the 2-cycle minimum (lower bound)")
+                                    frac=2.0 * insts / (N_SIMD * cyc), frac_note="instruction classes not collected: every instruction at 2 cycles")
                 roofline["valu"] = v
             if "frac" not in roofline or "traffic" not in roofline:
-                fallback_from_profiles(roofline, note, args.config)
+                # never another run's counters under this kernel's name: the figures stay empty and say why
+                roofline.setdefault("frac", None)
+                roofline.setdefault("achieved", None)
+                roofline.setdefault("peak", float(N_SIMD))
+                roofline.setdefault("unit", "SIMDs' worth of VALU issue slots in use (of 1024)")
+                roofline.setdefault("traffic", None)
+                roofline["counters_note"] = "no live counters for this kernel (%s)" % (note or "kernel not in the child's trace")
             if murray is not None and pmc:
-                # the sweep kernels of the same child passes: how busy their VALU issue slots and their LDS are
+                # the sweep kernels of the same child passes: how busy their VALU issue slots are
                 vi = {}
                 need = ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_FLOPS_FP32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT64",
                         "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32")
@@ -831,15 +806,45 @@ def main():
                         frac=(2.0 * plain + 4.0 * packed) / (N_SIMD * cyc2),
                         frac_at_measured_issue_intervals=(2.7 * plain + 4.7 * packed) / (N_SIMD * cyc2))
                 if vi:
-                    murray["valu_issue"] = dict(kernels=vi, formula="per kernel, mean per launch of the measured child job: (2*plain + "
-                                                "4*packed_f32) issue cycles / (1024 SIMDs * GRBM_GUI_ACTIVE/8), as roofline.frac; the second "
-                                                "figure prices the same counts with the issue intervals tools/ubench.hip measured (2.7 / 4.7)")
+                    murray["valu_issue"] = dict(kernels=vi)
         if not args.no_extras and args.config == "c3" and not args.chains and args.dim == 0:
             claims = claims_under_the_clock(M, E, dt / args.steps * 1e3, n, nburn, nsamp)
+            host_cb = host_callback_leg(M, E, cfg, n)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg)
 
     if rank == 0:
+        def pick(dct, *path):
+            for k in path:
+                if not isinstance(dct, dict) or dct.get(k) is None:
+                    return None
+                dct = dct[k]
+            return dct
+        sp = (claims or {}).get("strong_proxy")
+        summary = {
+            "value": value, "ms_per_job": dt / args.steps * 1e3, "n_gpus": world,
+            "roofline_frac": pick(roofline, "frac"), "roofline_kernel": pick(roofline, "kernel"),
+            "hbm_measured_frac": pick(roofline, "hbm_measured", "frac"),
+            "meet_timeouts": headline_stats["meet_timeouts"], "exchange_wait_ms_per_run": headline_stats["exchange_wait_ms_per_run"],
+            "other_configs_ms": {k: round(v["ms_per_step"], 4) for k, v in others.items()} or None,
+            "other_configs_meet_timeouts": sum(v["stats"]["meet_timeouts"] for v in others.values()) if others else None,
+            "c5_pairs_evaluated_frac": pick(others.get("c5"), "sweep", "pairs_evaluated_frac"),
+            "c3_murray_pairs_evaluated_frac": pick(others.get("c3-murray"), "sweep", "pairs_evaluated_frac"),
+            "full_cov_ratio": {k: round(v["ratio"], 3) for k, v in ((claims or {}).get("full_cov") or {}).items() if isinstance(v, dict)} or None,
+            "strong_proxy_ms": pick(sp, "ms_per_job"), "strong_proxy_speedup": pick(sp, "speedup_vs_headline_job"),
+            "strong_proxy_meet_timeouts": pick(sp, "stats", "meet_timeouts"),
+            "end_to_end_rows_ms": pick(end_to_end, "ms_per_step"),
+            "end_to_end_text_ms": pick(end_to_end, "text", "whole_job_through_the_text_sink", "ms_per_step"),
+            "host_callback_ms_per_step": pick(host_cb, "ms_per_step"), "host_callback_path_ms_per_step": pick(host_cb, "path_ms_per_step"),
+            "cpu_baseline": pick(cpu, "value"),
+            "weak_reference_schedule_ms": pick(ref_sched, "ms_per_step"),
+            "murray_multi_ms": pick(murray_multi, "ms_per_step"), "murray_multi_meet_timeouts": pick(murray_multi, "stats", "meet_timeouts"),
+            "strong_multi_ms": pick(strong_multi, "ms_per_step"),
+            "strong_multi_under_the_gather_ms": pick(strong_multi, "under_the_gather", "ms_per_step"),
+            "strong_multi_meet_timeouts": (pick(strong_multi, "behind_the_gather", "stats", "meet_timeouts"),
+                                           pick(strong_multi, "under_the_gather", "stats", "meet_timeouts")) if strong_multi else None,
+            "strong_multi_exchange_wait_ms_per_run": pick(strong_multi, "behind_the_gather", "stats", "exchange_wait_ms_per_run"),
+        }
         out = {
             "metric": "chain-steps/sec (all chains), 16-D Rosenbrock" if (cfg["lik"] == 1 and d == 16) else
                       "chain-steps/sec (all chains)",
@@ -850,21 +855,21 @@ def main():
                        "chains_per_gpu": n, "nparam": d, "nburn": nburn, "nsamp": nsamp, "pl": cfg["pl"],
                        "samples": "all kept in HBM" if emit else "none (summary only)",
                        "parallelism": ("chains sharded x%d (contiguous blocks, g = shard*n + j), in-place all-gather of the "
-                                       "(mu, sig^2) slots: default schedule gathers the snapshots a Murray step or the end of "
-                                       "the run reads" % world) if world > 1 else "single GPU",
+                                       "(mu, sig^2) slots" % world) if world > 1 else "single GPU",
                        "exchange_backend": state["backend"], "rccl_comm_ranks": state["rccl_ranks"],
                        "pci_bus_ids": pci_ids,
+                       "stats": headline_stats,
                        "reference_schedule": ref_sched,
                        "murray": murray_multi,
                        "strong_scaling": strong_multi,
                        "accept_rate_main": cnt["naccept_main"] / float(n * nsamp) if nsamp else None,
                        "remote_steps": cnt["remote_steps"], "remote_passes": cnt["remote_passes"],
                        "value_with_host_pinit": value_host_pinit,
-                       "exchanges_per_run": cnt["exchanges"], "kernel_launches_per_run": cnt["kernel_launches"],
                        "other_configs": others or None,
-                       "full_cov": (claims or {}).get("full_cov"), "strong_proxy": (claims or {}).get("strong_proxy"),
+                       "full_cov": (claims or {}).get("full_cov"), "strong_proxy": sp,
                        "accept_rate_reference_shape": (claims or {}).get("accept_rate_reference_shape")},
-            "end_to_end": end_to_end, "roofline": roofline, "murray_roofline": murray, "cpu_baseline": cpu,
+            "end_to_end": end_to_end, "host_callback": host_cb, "murray_roofline": murray, "cpu_baseline": cpu, "roofline": roofline,
+            "summary": summary,  # LAST: whoever keeps only the tail of this line still has every headline number
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
@@ -875,33 +880,50 @@ def main():
         dist.destroy_process_group()
 
 
+def host_callback_leg(M, E, cfg, n):
+    """The path every user likelihood of the reference takes (src/vlfunc.hh:9-12 called at src/mcpar.cc:60,160; its R
+    wrapper src/rfunc.cc:48-67): the configuration's shape with Rosenbrock1 as a HOST functor through MCX_VL_HOST -- the
+    proposals of all chains copied to pinned host memory, the functor called once per step on x[n][d], its y[n] copied
+    back.  The functor here is four numpy expressions; the time spent inside it is measured and reported apart from the
+    path around it (propose / accept kernels, two PCIe copies, one stream sync per step)."""
+    import numpy as np
+    d = cfg["d"]
+    inside = [0.0, 0]
+
+    def rosen1(x):
+        t0 = time.perf_counter()
+        a, b = x[:, 0::2], x[:, 1::2]
+        t1 = 1.0 - a
+        t2 = b - a * a
+        y = -(t1 * t1 + 100.0 * t2 * t2).sum(axis=1)
+        inside[0] += time.perf_counter() - t0
+        inside[1] += 1
+        return y
+    nburn, nsamp = 60, 40  # one tuner event, 40 main-loop steps: enough to time a per-step path
+    vl, _keep = M.make_vlfunc(M.VL_HOST, d, host_fn=rosen1)
+    eng = M.Engine(d, n, pl=1.0)
+    eng.set_option(E.OPT_SAMPLES, 0)
+    p = pinit_for(d, n, 0)
+    eng.run(nsamp, nburn, p, vl)  # warm
+    inside[0], inside[1] = 0.0, 0
+    t0 = time.perf_counter()
+    eng.run(nsamp, nburn, p, vl)
+    dt = time.perf_counter() - t0
+    calls = inside[1]
+    eng.close()
+    steps = nburn + nsamp
+    bytes_per_step = n * d * 4 + n * 4
+    path = (dt - inside[0]) / steps
+    return dict(workload="Rosenbrock1(%d) as a host VLFunc (numpy) x %d chains, nburn %d + nsamp %d, no rows kept" % (d, n, nburn, nsamp),
+                ms_per_step=dt / steps * 1e3, value=n * steps / dt, unit="chain-steps/s", functor_calls=calls,
+                functor_ms_per_step=inside[0] / steps * 1e3, path_ms_per_step=path * 1e3,
+                pcie_bytes_per_step=bytes_per_step, pcie_GBps_over_path_time=bytes_per_step / path / 1e9)
+
+
 def fm_unavoidable(d, n, chain_steps_per_launch, emit):
     """bytes one launch cannot avoid: the sample rows it emits + state and moments once in and once out"""
     rows = chain_steps_per_launch * 4 * (d + 1) if emit else 0
     return rows + n * (2 * 4 * (3 * d + 1))
-
-
-def fallback_from_profiles(roofline, why, config_name="c3"):
-    """counters not collected in this run: use the committed summaries of the same command, and say so"""
-    try:  # the latest round's committed summary
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_fused_kernel_counters.json" % config_name)))
-        sq = json.load(open(cands[-1]))
-        rel = os.path.relpath(cands[-1], ROOT)
-    except Exception:  # noqa: BLE001
-        roofline.setdefault("traffic", None)
-        roofline.setdefault("frac", None)
-        roofline["counters_note"] = "no live PMC (%s) and no committed summary" % why
-        return
-    t_launch = roofline["avg_launch_ms"] * 1e-3
-    src = "%s (committed rocprofv3 --pmc passes of this command; live collection: %s)" % (rel, why)
-    if "traffic" not in roofline and sq.get("traffic_bytes_per_launch"):
-        tr = sq["traffic_bytes_per_launch"]
-        roofline["traffic"] = tr
-        roofline["hbm_measured"] = dict(traffic=tr, achieved=tr / t_launch / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                                        frac=tr / t_launch / HBM_PEAK, source=src)
-    if "frac" not in roofline and sq.get("valu_busy_fraction"):
-        roofline.update(achieved=sq["valu_busy_fraction"] * N_SIMD, peak=float(N_SIMD), unit="SIMDs' worth of VALU issue slots in use (of 1024)",
-                        frac=sq["valu_busy_fraction"], valu=dict(source=src, formula=sq.get("valu_formula")))
 
 
 if __name__ == "__main__":

@@ -99,6 +99,7 @@ struct RunArgs {
   int meet_expect_extra;    // debug (MCX_OPT_DEBUG_MEET): workgroups the meetings wait for beyond the grid's own
 };
 
+static_assert(PLEAVES == 16, "a meeting's leaves are polled by the 16 lanes of one DPP row");
 constexpr unsigned long long MEET_ABORT_BIT = 1ull << 63;  // in a meeting word: a waiting owner gave up
 constexpr unsigned long long MEET_ABORTED = ~0ull - 1ull;  // in lds_out / as owners_meet's result: abandon the launch
 
@@ -140,13 +141,13 @@ __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *le
     bool abort = false;
     for (;;) {
       const unsigned long long v = lane < (unsigned)PLEAVES ? __hip_atomic_load(leaves + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      // arrivals over the 16 leaves = the 16 lanes of DPP row 0: four rotate-and-add steps, no LDS crossbar in the poll
       unsigned arr = (unsigned)((v & ~MEET_ABORT_BIT) >> 40);
       sum = (unsigned)v;
-#pragma unroll
-      for (int m = PLEAVES / 2; m >= 1; m >>= 1) {
-        arr += (unsigned)__shfl_xor((int)arr, m);
-        sum += (unsigned)__shfl_xor((int)sum, m);
-      }
+      arr += (unsigned)__builtin_amdgcn_update_dpp(0, (int)arr, 0x128, 0xF, 0xF, true);  // row_ror:8
+      arr += (unsigned)__builtin_amdgcn_update_dpp(0, (int)arr, 0x124, 0xF, 0xF, true);  // row_ror:4
+      arr += (unsigned)__builtin_amdgcn_update_dpp(0, (int)arr, 0x122, 0xF, 0xF, true);  // row_ror:2
+      arr += (unsigned)__builtin_amdgcn_update_dpp(0, (int)arr, 0x121, 0xF, 0xF, true);  // row_ror:1
       arr = __builtin_amdgcn_readfirstlane(arr);
       abort = __ballot((v & MEET_ABORT_BIT) != 0ull) != 0ull;
       if ((int)arr >= nwg || abort) break;
@@ -166,6 +167,10 @@ __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *le
 #endif
       __builtin_amdgcn_s_sleep(2);
     }
+    sum += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sum, 0x128, 0xF, 0xF, true);
+    sum += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sum, 0x124, 0xF, 0xF, true);
+    sum += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sum, 0x122, 0xF, 0xF, true);
+    sum += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sum, 0x121, 0xF, 0xF, true);
     total = abort ? MEET_ABORTED : (unsigned long long)__builtin_amdgcn_readfirstlane(sum);
     if (lane == 0) __hip_atomic_store(lds_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   } else {

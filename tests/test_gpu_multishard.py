@@ -54,6 +54,8 @@ def run_sharded_gpu(d, n, nshards, nburn, nsamp, pl, sync=10, eager=0, mask=1, v
             engs[s].set_exchange(make_hook(s))
             for _ in range(runs):
                 engs[s].run(nsamp, nburn, O.default_pinit(d, n, g0=s * n), vl)
+            if deferred:  # a gather left in flight moves its data in WAIT: every shard's thread must get there together
+                engs[s].synchronize()
         except Exception as ex:  # pragma: no cover
             errs.append(ex)
             bar.abort()
