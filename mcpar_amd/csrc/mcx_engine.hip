@@ -1824,9 +1824,12 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   // (with two 4-parameter blocks per lane where that takes a workgroup from two or more owner wavefronts towards one)
   const int pbpl = mcxk_persist_bpl(e->lpc, d, n, e->ncu, e->opt_bpl), plpc2 = e->lpc / pbpl;
   const int nown = (int)(((size_t)n * plpc2 + 63) / 64);
+  // (the mode is for chains that fill at most POWN_MAX wavefronts per CU at ONE block per lane: beyond that the per-segment
+  // kernels are as fast or faster -- 65 536 x 16-D would fit the grid with two blocks per lane and run 35 % slower)
+  const size_t nown_one_block = ((size_t)n * e->lpc + 63) / 64;
   const bool fast_lik = e->lik.kind == LIK_ROSEN1 || e->lik.kind == LIK_GAUSS || (e->lik.kind == LIK_MIX && e->lik.ncomp <= 8);
   const bool persist = fused && e->lpc <= 8 && fast_lik && e->diag && e->vec4 && !e->opt_mask && e->ncu > 0 &&
-                       nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
+                       nown_one_block <= (size_t)POWN_MAX * (size_t)e->ncu && nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
                        mcxk_persist_lds_bytes(plpc2, pbpl, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
                        (e->opt_persist > 0 || (e->opt_persist < 0 && e->opt_split != 0)) && !e->persist_broken &&
                        (nburn == 0 || meet_lock_open(e));
@@ -1886,9 +1889,15 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         ++pj;
       }
       const size_t pj_burn_end = pj;
-      if (pj + 1 < plan.size() && plan[pj].kind == MCX_PLAN_INIT_MOMENTS && plan[pj + 1].kind == MCX_PLAN_MAIN_SEGMENT) {
-        init = 1;
-        ++pj;
+      if (pj + 1 < plan.size() && plan[pj].kind == MCX_PLAN_INIT_MOMENTS) {
+        // (a sharded run's first sync point is step 0: its slot publish -- of zero steps, i.e. nothing -- sits between
+        // the start of the moments and the first segment and must not cost the run a second launch)
+        size_t pk = pj + 1;
+        while (pk < plan.size() && plan[pk].kind == MCX_PLAN_PUBLISH && plan[pk].first == 0) ++pk;
+        if (pk < plan.size() && plan[pk].kind == MCX_PLAN_MAIN_SEGMENT) {
+          init = 1;
+          pj = pk;
+        }
       }
       if (pj < plan.size() && plan[pj].kind == MCX_PLAN_MAIN_SEGMENT) {
         is0 = plan[pj].first;

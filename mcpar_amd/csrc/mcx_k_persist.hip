@@ -82,11 +82,14 @@ bool mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab
   bool fits = true;
   float cn = 185.0f, ca = 110.0f, co = bpl == 1 ? 34.0f : 50.0f, cr = bpl == 1 ? 24.0f : 40.0f;
   int simd_div = 0, singles = 0;  // (single-step items measured slower wherever they were dealt: 8192 x 16-D +1..7 %)
-  static const char *env = getenv("MCX_PERSIST_COST");  // tuning only: "cn,ca,co,cr[,map[,singles]]"
+  // From three sets of chains per workgroup on, equal shares per WAVEFRONT (what the round-robin deal of rounds 2-3 gave)
+  // measured better than equal work per SIMD: 16-D x 12288 0.557 -> 0.53 ms per launch
+  int per_wave = own * bpl >= 3;
+  static const char *env = getenv("MCX_PERSIST_COST");  // tuning only: "cn,ca,co,cr[,map[,singles[,per_wave]]]"
   if (env && *env) {
-    float v[6] = {cn, ca, co, cr, 0.0f, 0.0f};
-    (void)sscanf(env, "%f,%f,%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]);
-    cn = v[0]; ca = v[1]; co = v[2]; cr = v[3]; simd_div = v[4] != 0.0f; singles = v[5] != 0.0f;
+    float v[7] = {cn, ca, co, cr, 0.0f, 0.0f, (float)per_wave};
+    (void)sscanf(env, "%f,%f,%f,%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+    cn = v[0]; ca = v[1]; co = v[2]; cr = v[3]; simd_div = v[4] != 0.0f; singles = v[5] != 0.0f; per_wave = v[6] != 0.0f;
   }
   const int nrec = rec ? own : 0, OB = own * bpl, nsteps = K * OB;  // (K is even)
   const float acc_cost = (float)((K / 4 + 1 + lpc2 - 1) / lpc2) * ca + 20.0f;
@@ -105,7 +108,7 @@ bool mcxk_persist_deal(int lpc2, int bpl, int own, int rec, int K, uint32_t *tab
     auto place = [&](float cost) {  // the wavefront of the least loaded SIMD that has done the least itself
       int best = first_filler;
       for (int w = first_filler + 1; w < PWAVES; ++w) {
-        const float sb = simd[simd_of(best)], sw = simd[simd_of(w)];
+        const float sb = per_wave ? wave[best] : simd[simd_of(best)], sw = per_wave ? wave[w] : simd[simd_of(w)];
         if (sw < sb || (sw == sb && wave[w] < wave[best])) best = w;
       }
       simd[simd_of(best)] += cost;

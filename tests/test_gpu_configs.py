@@ -47,6 +47,9 @@ def test_c3_full_job_bit_exact():
     eg.run(nsamp, nburn, p, vg)  # hot-path kernel, all 65.5 M sample rows kept in HBM
     c = eg.counters
     assert c["naccept_burn"] == eo.naccept_burn and c["naccept_main"] == eo.naccept_main
+    # the headline job runs on the hot-path kernel, not in small-n mode (with two blocks per lane its 65 536 chains
+    # would fit the one-launch kernel's grid -- and run 35 % slower: round 4's bench caught the engine choosing that)
+    assert c["small_n_launches"] == 0 and c["kernel_launches"] <= 20, c
     assert np.array_equal(eg.accept_counts, eo.accept_counts)
     assert np.array_equal(eg.tuner_trace, eo.tuner_trace) and len(eo.tuner_trace) == 9
     for name in ("state", "loglike", "mean", "var", "musigall"):

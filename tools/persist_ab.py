@@ -19,7 +19,7 @@ def pinit(d, n):
     g = np.arange(n, dtype=np.float64)[:, None]; i = np.arange(d, dtype=np.float64)[None, :]
     return (0.5 * np.sin(0.37 * (g * d + i))).astype(np.float32)
 out = {}
-for d, n, bpl in ((8, 4096, 0), (16, 8192, 1), (16, 8192, 2), (16, 4096, 0)):
+for d, n, bpl in ((8, 4096, 0), (16, 8192, 0), (16, 4096, 0), (8, 16384, 0), (16, 16384, 0), (16, 12288, 0)):
     vl, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     e = M.Engine(d, n, pl=1.0)
     e.set_option(E.OPT_PERSIST, 1)
@@ -45,19 +45,20 @@ print(json.dumps(out))
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    variants = sys.argv[2:] or ["r3", "v0", "v2"]  # build/ab/libmcx_<name>.so: round 3's library, unbounded meetings, what ships
     res = {}
     for r in range(rounds):
-        for v in (0, 1, 2):
-            lib = os.path.join(ROOT, "build", "ab", "libmcx_v%d.so" % v)
+        for v in variants:
+            lib = os.path.join(ROOT, "build", "ab", "libmcx_%s.so" % v)
             env = dict(os.environ, MCX_LIBMCX=lib)
             o = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
             if o.returncode != 0:
-                print("variant %d failed:\n%s" % (v, o.stderr[-2000:]))
+                print("variant %s failed:\n%s" % (v, o.stderr[-2000:]))
                 return 1
             got = json.loads(o.stdout.strip().splitlines()[-1])
             for k, val in got.items():
                 res.setdefault(k, {}).setdefault(v, []).append(val)
-            print("round %d variant %d: %s" % (r, v, got), flush=True)
+            print("round %d variant %s: %s" % (r, v, got), flush=True)
     print("\nshape: variant -> min job ms / min kernel ms over %d rounds" % rounds)
     for k, byv in res.items():
         print(k, {v: (min(x[0] for x in xs), min(x[1] for x in xs)) for v, xs in byv.items()})
