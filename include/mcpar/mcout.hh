@@ -63,6 +63,16 @@ public:
   void text_only(bool on) { text_only_ = on; }
   bool text_only(void) const { return text_only_; }
   void write_text(const char *text, std::size_t nbytes);              // (MCPar::run's text sink; collective)
+  // addition: the text of text_only() / of a plain-text dump goes to this FILE instead of rank 0's stream, and with
+  // several ranks every rank writes its own share of a block itself, at the byte offset an MPI_Exscan of the shares'
+  // sizes gives it -- the file is byte for byte what the funnel through rank 0 (the scheme the reference calls a
+  // stop-gap, src/mcout.cc:22-35) would have written, without 8 ranks' text squeezing through one loop.  The file
+  // must be on a file system every rank sees (one node: any).  COLLECTIVE; an empty or null path closes the file and
+  // switches it off (like the reference's MCout, this class has no destructor: close the file when the run is over).
+  // false: the file could not be opened on some rank (nothing changes then).
+  bool text_file(const char *path);
+  // (MCPar::run, collective) do all ranks have their block's text?  One rank without it sends every rank to the row path
+  bool all_ranks_agree(bool mine);
   // (MCPar::run) would output() print the rows exactly as printf("%g") does -- a stream in its default state, no
   // binary mode, nothing waiting to be printed?  Then the text of a block may come from the GPU next to its rows ...
   bool prints_plain_text(void) const;
@@ -83,6 +93,8 @@ private:
   MPI_Comm comm_;
   int rank_, nranks_;
   bool binary_, text_only_;
+  int text_fd_;                   // text_file(): this rank's descriptor of the shared file, or -1
+  unsigned long long text_pos_;   // bytes of it written by all ranks so far
   void note_row(const float *row);
 };
 

@@ -8,10 +8,12 @@
 #include "../../include/mcpar/mcpar.hh"
 #include "../../include/mcpar/mcutil.hh"
 
+#include <fcntl.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <cassert>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -38,7 +40,8 @@ static void die(const char *where)
 // ---------------------------------------------------------------------------------------------
 MCout::MCout(int np, std::ostream *aoutstream, MPI_Comm acomm)
     : nparam_(np), width_(np + 1), fill_(0), flushed_(0), stored_rows_(0), capacity_rows_(0),
-      best_l_(-std::numeric_limits<float>::infinity()), best_p_(static_cast<size_t>(np), 0.0f), sink_(0), binary_(false), text_only_(false)
+      best_l_(-std::numeric_limits<float>::infinity()), best_p_(static_cast<size_t>(np), 0.0f), sink_(0), binary_(false), text_only_(false),
+      text_fd_(-1), text_pos_(0)
 {
 #ifdef MCX_WITH_MPI
   if (MPI_Comm_dup(acomm, &comm_) != MPI_SUCCESS) {
@@ -61,20 +64,92 @@ void MCout::note_row(const float *row)
   }
 }
 
-// COLLECTIVE with several ranks: the ranks' texts of one block reach the stream in rank order -- the row order of a dump
-// (src/mcout.cc:62-69: rank-major, then step, then chain)
-void MCout::write_text(const char *text, size_t nbytes)
+bool MCout::all_ranks_agree(bool mine)
 {
+  int ok = mine ? 1 : 0;
 #ifdef MCX_WITH_MPI
   if (nranks_ > 1) {
-    if (nbytes > 0x7fffffffu) {
-      std::cerr << "MCout::write_text: a block of " << nbytes << " bytes does not fit an MPI message.  Aborting.\n";
-      MPI_Abort(MPI_COMM_WORLD, 1);
+    int all = 0;
+    if (MPI_Allreduce(&ok, &all, 1, MPI_INT, MPI_MIN, comm_) != MPI_SUCCESS) MPI_Abort(MPI_COMM_WORLD, 1);
+    ok = all;
+  }
+#endif
+  return ok != 0;
+}
+
+bool MCout::text_file(const char *path)
+{
+  if (text_fd_ >= 0) close(text_fd_);
+  text_fd_ = -1;
+  text_pos_ = 0;
+  if (!path || !*path) return true;
+  // rank 0 creates (and empties) the file, then everybody opens it for writing at offsets of its own
+  int fd = -1;
+  if (rank_ == 0) fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+  if (!all_ranks_agree(rank_ != 0 || fd >= 0)) {
+    if (fd >= 0) close(fd);
+    return false;
+  }
+  if (rank_ != 0) fd = open(path, O_WRONLY | O_CLOEXEC);
+  if (!all_ranks_agree(fd >= 0)) {
+    if (fd >= 0) close(fd);
+    return false;
+  }
+  text_fd_ = fd;
+  return true;
+}
+
+static bool write_all_at(int fd, const char *p, size_t n, unsigned long long at)
+{
+  while (n > 0) {
+    const ssize_t w = pwrite(fd, p, std::min<size_t>(n, size_t(1) << 30), static_cast<off_t>(at));
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
     }
+    p += w;
+    n -= static_cast<size_t>(w);
+    at += static_cast<unsigned long long>(w);
+  }
+  return true;
+}
+
+// COLLECTIVE with several ranks: the ranks' texts of one block reach the stream in rank order -- the row order of a dump
+// (src/mcout.cc:62-69: rank-major, then step, then chain).  Two ways: through rank 0's stream, each rank's share sent
+// to it in pieces of at most 1 GiB (an MPI count is an int: a 65 536-chain rank's block passes 2^31 characters from
+// nsamp ~ 1900 on); or, text_file(), every rank writing its share itself where an exclusive scan of the sizes puts it.
+void MCout::write_text(const char *text, size_t nbytes)
+{
+  if (text_fd_ >= 0) {
+    unsigned long long mine = nbytes, before = 0, total = nbytes;
+    (void)mine;
+#ifdef MCX_WITH_MPI
+    if (nranks_ > 1) {
+      if (MPI_Exscan(&mine, &before, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, comm_) != MPI_SUCCESS ||
+          MPI_Allreduce(&mine, &total, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, comm_) != MPI_SUCCESS)
+        MPI_Abort(MPI_COMM_WORLD, 1);
+      if (rank_ == 0) before = 0;  // (MPI_Exscan leaves rank 0's result undefined)
+    }
+#endif
+    if (nbytes && !write_all_at(text_fd_, text, nbytes, text_pos_ + before)) {
+      std::cerr << "MCout::write_text: writing the sample text failed on rank " << rank_ << ".  Aborting.\n";
+#ifdef MCX_WITH_MPI
+      MPI_Abort(MPI_COMM_WORLD, 1);
+#endif
+      abort();
+    }
+    text_pos_ += total;
+    return;
+  }
+#ifdef MCX_WITH_MPI
+  if (nranks_ > 1) {
+    const size_t piece = size_t(1) << 30;
     if (rank_ != 0) {
       long long mine = static_cast<long long>(nbytes);
-      if (MPI_Send(&mine, 1, MPI_LONG_LONG, 0, 7101, comm_) != MPI_SUCCESS ||
-          MPI_Send(const_cast<char *>(text), static_cast<int>(nbytes), MPI_CHAR, 0, 7102, comm_) != MPI_SUCCESS) {
+      bool ok = MPI_Send(&mine, 1, MPI_LONG_LONG, 0, 7101, comm_) == MPI_SUCCESS;
+      for (size_t at = 0; ok && at < nbytes; at += piece)
+        ok = MPI_Send(const_cast<char *>(text + at), static_cast<int>(std::min(piece, nbytes - at)), MPI_CHAR, 0, 7102, comm_) == MPI_SUCCESS;
+      if (!ok) {
         std::cerr << "Unable to send output text.  Aborting.\n";
         MPI_Abort(MPI_COMM_WORLD, 1);
       }
@@ -85,10 +160,13 @@ void MCout::write_text(const char *text, size_t nbytes)
     for (int r = 1; r < nranks_; ++r) {
       long long n = 0;
       if (MPI_Recv(&n, 1, MPI_LONG_LONG, r, 7101, comm_, MPI_STATUS_IGNORE) != MPI_SUCCESS) MPI_Abort(MPI_COMM_WORLD, 1);
-      theirs.resize(static_cast<size_t>(n) + 1);
-      if (MPI_Recv(theirs.data(), static_cast<int>(n), MPI_CHAR, r, 7102, comm_, MPI_STATUS_IGNORE) != MPI_SUCCESS)
-        MPI_Abort(MPI_COMM_WORLD, 1);
-      if (sink_ && n) sink_->write(theirs.data(), static_cast<std::streamsize>(n));
+      theirs.resize(std::min(static_cast<size_t>(n), piece) + 1);
+      for (size_t at = 0; at < static_cast<size_t>(n); at += piece) {
+        const size_t len = std::min(piece, static_cast<size_t>(n) - at);
+        if (MPI_Recv(theirs.data(), static_cast<int>(len), MPI_CHAR, r, 7102, comm_, MPI_STATUS_IGNORE) != MPI_SUCCESS)
+          MPI_Abort(MPI_COMM_WORLD, 1);
+        if (sink_) sink_->write(theirs.data(), static_cast<std::streamsize>(len));
+      }
     }
     return;
   }
@@ -109,7 +187,7 @@ bool MCout::prints_plain_text(void) const
 {
   if (binary_ || text_only_ || fill_ != flushed_) return false;
   // (the stream lives on rank 0; the others follow its answer in MCPar::run)
-  return rank_ != 0 || (sink_ && stream_prints_like_printf(*sink_));
+  return rank_ != 0 || text_fd_ >= 0 || (sink_ && stream_prints_like_printf(*sink_));
 }
 
 void MCout::note_best(float lval, const float *params)
@@ -507,7 +585,9 @@ int sample_sink(void *vctx, int first_step, int nsteps, const float *rows)
   write_step_diagnostics(c, steps_done);  // iterations before this dump point
   const char *text = 0;
   size_t nbytes = 0;
-  const bool have_text = c->gpu_text && mcx_sink_text(c->eng, &text, &nbytes) == MCX_OK;
+  // (collective: a rank whose text could not be made -- an allocation failure inside the engine's sink -- must not go
+  // down the row path, MPI_Gather, while the others send text: one "no" sends every rank of this block to the rows)
+  const bool have_text = c->gpu_text && c->out->all_ranks_agree(mcx_sink_text(c->eng, &text, &nbytes) == MCX_OK);
   if (steps_done < c->nsamp) (*c->log) << "Beginning output at step " << steps_done << std::endl;
   if (have_text) {  // the characters output() would produce for these rows, made on the GPU (the last block's too:
     c->out->write_text(text, nbytes);  // its text exists only now; the run's final output() then finds nothing new)

@@ -1,9 +1,10 @@
 // mcpar-run -- the BASELINE configurations as a first-class driver (the reference reaches them
 // only through its library API: SURVEY fact 3).
 //   mcpar-run [--func rosen1|rosen2|rosen2fixed|gauss|dgauss|mix] [--np D] [--nc CHAINS] [--nsamp N]
-//             [--nburn B] [--pl P] [--sync S] [--ncomp K] [--quiet] [--iter] [--binary] [--stream-text]
+//             [--nburn B] [--pl P] [--sync S] [--ncomp K] [--quiet] [--iter] [--binary] [--stream-text] [--out FILE]
 // Output: the reference's row format (src/mcout.cc:41-45); --iter prepends the iteration index
-// that src/anly/mcpar-analysis.R:80-120 reconstructs; --quiet prints only the summary (stderr).
+// that src/anly/mcpar-analysis.R:80-120 reconstructs; --quiet prints only the summary (stderr); --out FILE: the sample
+// text goes to FILE, every rank writing its own share at its place (MCout::text_file) instead of through rank 0.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -26,6 +27,7 @@ int main(int argc, char *argv[])
   int np = 16, nc = 4096, nsamp = 100, nburn = 500, sync = 10, ncomp = 8;
   float pl = 1.0f;
   bool quiet = false, iter = false, binary = false, stream_text = false;
+  std::string out_file;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : "0"; };
@@ -41,6 +43,7 @@ int main(int argc, char *argv[])
     else if (a == "--iter") iter = true;
     else if (a == "--binary") binary = true;  // rows as raw float32 (np+1 per row) instead of text
     else if (a == "--stream-text") stream_text = true;  // the same text, formatted on the GPU, nothing kept on the host
+    else if (a == "--out") out_file = val();
     else { std::cerr << "unknown option " << a << "\n"; return 2; }
   }
   MPI_Init(&argc, &argv);
@@ -73,6 +76,11 @@ int main(int argc, char *argv[])
   MCout rslts(np, (quiet || iter) ? static_cast<std::ostream *>(&sink) : &std::cout, MPI_COMM_WORLD);
   rslts.binary(binary);
   rslts.text_only(stream_text && !binary && !iter);
+  if (!out_file.empty() && !rslts.text_file(out_file.c_str())) {
+    std::cerr << "cannot open " << out_file << "\n";
+    MPI_Finalize();
+    return 2;
+  }
   std::vector<float> pinit((size_t)nc * np);
   for (int j = 0; j < nc; ++j)
     for (int i = 0; i < np; ++i)
@@ -105,6 +113,7 @@ int main(int argc, char *argv[])
     std::cerr << msg << "\n";
     return 2;
   }
+  rslts.text_file(0);
   float lmax;
   const std::vector<float> &pmax = rslts.maxlike(&lmax);
   if (rank == 0) {

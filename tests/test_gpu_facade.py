@@ -172,3 +172,34 @@ def test_two_mpi_ranks_through_the_facade(tmp_path):
     assert st.returncode == 0, st.stderr[-2000:]
     assert st.stdout == expect
     assert st.stderr.split("max likelihood value:")[1] == r.stderr.split("max likelihood value:")[1]
+
+
+@pytest.mark.skipif(not os.path.exists(MPIEXEC), reason="no MPI launcher in this image")
+@pytest.mark.parametrize("stream", [True, False], ids=["text-only", "rows-and-text"])
+def test_two_mpi_ranks_write_their_text_side_by_side(tmp_path, stream):
+    """MCout::text_file / mcpar-run --out: every rank writes its share of a dump itself, at the byte offset an MPI_Exscan
+    of the shares' sizes gives it; the file must be byte for byte what the funnel through rank 0 prints"""
+    r = subprocess.run(["make", "-C", DRV, "mpi"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("MPI build not available: " + r.stderr[-300:])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [MPIEXEC, "-n", "2", os.path.join(DRV, "mcpar-run-mpi"), "--func", "rosen1", "--np", "8", "--nc", "640",
+            "--nsamp", "60", "--nburn", "60", "--pl", "0.9"] + (["--stream-text"] if stream else [])
+    funnel = subprocess.run(base, cwd=tmp_path, capture_output=True, timeout=300, env=env)
+    assert funnel.returncode == 0, funnel.stderr[-2000:]
+    out = tmp_path / "samples.txt"
+    side = subprocess.run(base + ["--out", str(out)], cwd=tmp_path, capture_output=True, timeout=300, env=env)
+    assert side.returncode == 0, side.stderr[-2000:]
+    assert side.stdout == b""  # everything went to the file
+    got = out.read_bytes()
+    assert len(got) > 100000 and got == funnel.stdout
+    # and it is the oracle's two-shard run in dump order (each dump: rank 0's new rows, then rank 1's)
+    vl, keep = O.make_vlfunc(O.VL_ROSENBROCK1, 8)
+    engs = [O.Engine(8, 640, nshards=2, shard=s, pl=0.9) for s in range(2)]
+    O.run_all(engs, 60, 60, [O.default_pinit(8, 640, g0=s * 640) for s in range(2)], vl)
+    expect, lo = "", 0
+    for hi in list(range(6, 60, 6)) + [60]:
+        for e in engs:
+            expect += fmt_rows(e.samples[lo * 640:hi * 640])
+        lo = hi
+    assert got.decode() == expect
