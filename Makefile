@@ -19,7 +19,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 # the Murray kernels are seen by the engine's translation unit only
-$(CSRC)/mcx_engine.o: $(CSRC)/mcx_remote.hpp
+$(CSRC)/mcx_engine.o: $(CSRC)/mcx_remote.hpp $(CSRC)/mcx_cull_proj.hpp $(CSRC)/mcx_text.hpp $(CSRC)/fmt_g6.hpp
 $(CSRC)/mcx_k_fastb.o: $(CSRC)/mcx_fastb.hpp
 
 mcpar_amd/libmcx.so: $(OBJS)

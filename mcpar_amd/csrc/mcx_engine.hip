@@ -8,6 +8,7 @@
 #include "mcx_launch.hpp"
 #include "mcx_persist.hpp"
 #include "mcx_remote.hpp"
+#include "mcx_cull_proj.hpp"
 #include "mcx_text.hpp"
 
 #include <dlfcn.h>
@@ -401,8 +402,10 @@ struct mcx_engine {
   DevBuf<unsigned long long> text_wg;    // mcx_samples_text: per-workgroup byte counts / offsets
   DevBuf<char> text_dev;                 // and the text itself
   DevBuf<float> cull_stats, cull_box, cull_lim;
+  DevBuf<double> proj_acc, proj_p, proj_lohi;  // mcx_cull_proj.hpp: two power iterations' sums, e.x per chain, [lo, hi] per group
   DevBuf<unsigned long long> cull_excl;
-  int opt_cull = -1;  // -1 auto (many chains, many Gaussians, np = 16 or 32), 0 off, 1 whenever the kernels allow
+  int opt_cull = -1;  // -1 auto (many chains, many Gaussians; np = 16: boxes, np = 32: along one direction), 0 off,
+                      // 1 boxes whenever the kernels allow, 2 one direction whenever they allow
   int cull_skip[2] = {0, 0};  // auto mode: genRemote calls for which the min-arg / sum sweeps go without the test,
                               // because it excluded too little last time it was tried (then it is tried again)
   DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev, zpre, upre, trash;
@@ -677,7 +680,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->cull_keys.release(); e->cull_hist.release(); e->cull_sorted.release(); e->cull_stats.release(); e->cull_box.release();
-  e->cull_lim.release(); e->cull_excl.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
+  e->cull_lim.release(); e->cull_excl.release(); e->proj_acc.release(); e->proj_p.release(); e->proj_lohi.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
   e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release(); e->deal_tab.release(); e->trace_clk.release();
   for (int b = 0; b < 2; ++b) {
@@ -740,7 +743,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
   case MCX_OPT_ASYNC_TAIL: e->opt_async_tail = value == 2 ? 2 : (value ? 1 : 0); break;
   case MCX_OPT_SPLIT_RNG: e->opt_split = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_PERSIST: e->opt_persist = value < 0 ? -1 : (value ? 1 : 0); break;
-  case MCX_OPT_CULL: e->opt_cull = value < 0 ? -1 : (value ? 1 : 0); break;
+  case MCX_OPT_CULL: e->opt_cull = value < 0 ? -1 : (value == 2 ? 2 : (value ? 1 : 0)); break;
   case MCX_OPT_BLOCKS_PER_LANE:
     if (value != 0 && value != 1 && value != 2 && value != 4) return fail(MCX_ERR_INVALID, "BLOCKS_PER_LANE must be 0 (auto), 1, 2 or 4");
     e->opt_bpl = (int)value;
@@ -951,6 +954,40 @@ static int cull_prepare(mcx_engine *e, const float *xrows, const int *ain, int n
   return MCX_OK;
 }
 
+// The same with the chains sorted along ONE direction and every (group, Q_i) row bounded by Cauchy-Schwarz along it
+// (mcx_cull_proj.hpp): for chain clouds no box of a few coordinates separates.
+template <int DMAX>
+static int cull_prepare_proj(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, hipStream_t st)
+{
+  const int N = e->tchains;
+  const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64;
+  double *acc0 = e->proj_acc.p, *acc1 = e->proj_acc.p + PROJ_ACC;
+  // (acc0 and the histogram are zero here: zeroed when allocated, and again by every k_proj_groups; acc1 is zeroed now)
+  HIPCHK(hipMemsetAsync(acc1, 0, PROJ_ACC * sizeof(double), st));
+  hipLaunchKernelGGL((k_proj_moments<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc0, 0, acc0);
+  hipLaunchKernelGGL((k_proj_moments<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc0, 1, acc1);
+  hipLaunchKernelGGL((k_proj_keys<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc1,
+                     e->proj_p.p, e->cull_keys.p, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
+                     e->cull_sorted.p);
+  const dim3 gb((unsigned)((ng + BLOCK / 64 - 1) / (BLOCK / 64)));
+  if (sums)
+    hipLaunchKernelGGL((k_proj_groups<DMAX, true>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
+                       (const float *)e->winvall.p, own0, (const double *)e->proj_p.p, e->proj_lohi.p, e->cull_lim.p, acc0, e->cull_hist.p);
+  else
+    hipLaunchKernelGGL((k_proj_groups<DMAX, false>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
+                       (const float *)e->winvall.p, own0, (const double *)e->proj_p.p, e->proj_lohi.p, e->cull_lim.p, acc0, e->cull_hist.p);
+  const int gchunk = 64;
+  hipLaunchKernelGGL((k_proj_test<DMAX>), dim3((unsigned)((nw + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)((ng + gchunk - 1) / gchunk)),
+                     dim3(BLOCK), 0, st, (const float *)e->winvall.p, N, (const double *)acc1, (const double *)e->proj_lohi.p,
+                     (const float *)e->cull_lim.p, ng, nact, gchunk, e->cull_excl.p, nw,
+                     reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
+  HIPCHK(hipGetLastError());
+  e->cnt.kernel_launches += 8;
+  return MCX_OK;
+}
+
 // MCPar::genRemote on device buffers (src/mcpar.cc:315-451)
 static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
                          float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
@@ -981,7 +1018,13 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
       HIPCHK(hipMemsetAsync(e->cull_hist.p, 0, CULL_BINS * sizeof(unsigned), st));
     } MCXCHK(e->cull_box.alloc(ngmax * 2 * CULL_KD)); MCXCHK(e->cull_lim.alloc(ngmax));
     MCXCHK(e->cull_excl.alloc(ngmax * nw));
+    const bool fresh_p = !e->proj_acc.p;
+    MCXCHK(e->proj_acc.alloc(2 * PROJ_ACC)); MCXCHK(e->proj_p.alloc((size_t)n)); MCXCHK(e->proj_lohi.alloc(2 * ngmax));
+    if (fresh_p) HIPCHK(hipMemsetAsync(e->proj_acc.p, 0, 2 * PROJ_ACC * sizeof(double), st));
   }
+  // which exact screen: boxes of four coordinates (the narrow per-chain Gaussians of C3's shape) or one direction (np = 32:
+  // the mixture of C5, whose components lie on a line no coordinate axis is close to)
+  const bool proj = e->opt_cull == 2 || (e->opt_cull < 0 && dm == 32);
   HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
   uint64_t evaluated_host = 0;  // pairs of the sweeps that ran without an exclusion test
   // auto mode gives the test up where it excludes too little to pay for itself (the 32-D mixture: per-chain
@@ -1006,7 +1049,11 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
     const int *order = nullptr;
     const unsigned long long *excl = nullptr;
     if (cull) {
-      DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
+      if (proj) {
+        DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
+      } else {
+        DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
+      }
       order = e->cull_sorted.p;
       excl = e->cull_excl.p;
     } else {
@@ -1054,7 +1101,11 @@ static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const fl
       const int *list = ain;
       const unsigned long long *excl = nullptr;
       if (cull) {  // the proposals have just been drawn: sort, box and test them
-        DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
+        if (proj) {
+          DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
+        } else {
+          DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
+        }
         list = e->cull_sorted.p;
         excl = e->cull_excl.p;
         a.active_in = list;  // positions of psum / pmax are positions of the sorted list

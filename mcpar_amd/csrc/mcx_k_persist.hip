@@ -49,12 +49,13 @@ bool mcxk_persist_deal_fits(int lpc2, int bpl, int own, int rec, int K);
 
 // Steps per phase: as many as the LDS double buffers hold where a workgroup has one or two sets of chains (fewer phase
 // changes: 8-D x 4096 16 -> 0.308 ms, 24 -> 0.293, 32 -> 0.291; 16-D x 8192 without recorders 16 -> 0.446, 24 -> 0.437,
-// 32 -> 0.422), 16 from three on (16-D x 12288: 12 -> 0.655, 16 -> 0.574, 24 / 32 -> 0.595; 32-D x 8192 with two blocks
-// per lane: 12 -> 0.728, 16 -> 0.684, 24 -> 0.705) -- round 4's sweep, one box.  Even: a generator item is two steps.
+// 32 -> 0.422), 20 with three (16-D x 12288, equal shares per wavefront: 12 -> 0.590, 16 -> 0.603, 20 -> 0.571, 24 -> 0.587),
+// 16 from four on (32-D x 8192 with two blocks per lane: 12 -> 0.728, 16 -> 0.684, 24 -> 0.705; 16-D x 16384: 16 to 24
+// within 0.3 %) -- round 4's sweeps, one box each.  Even: a generator item is two steps.
 int mcxk_persist_ksteps(int lpc2, int bpl, int own)
 {
   const int rec = mcxk_persist_recorders(own, bpl) ? 1 : 0;
-  int k = own * bpl <= 2 ? 32 : 16;
+  int k = own * bpl <= 2 ? 32 : (own * bpl == 3 ? 20 : 16);
   static const char *env = getenv("MCX_PERSIST_KSTEPS");  // tuning only (tools/persist_config_sweep.py)
   if (env && *env) k = std::max(atoi(env), 2);
   k &= ~1;  // even: a normals item is two consecutive steps, and both are always stored (mcx_persist.hpp)
