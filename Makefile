@@ -11,15 +11,16 @@ all: lib oracle
 lib:
 	$(MAKE) -j6 mcpar_amd/libmcx.so
 
-OBJS = $(CSRC)/mcx_engine.o $(CSRC)/mcx_k_fast.o $(CSRC)/mcx_k_fastb.o $(CSRC)/mcx_k_fast_full.o $(CSRC)/mcx_k_pregen.o $(CSRC)/mcx_k_generic_burn.o \
+OBJS = $(CSRC)/mcx_engine.o $(CSRC)/mcx_plan.o $(CSRC)/mcx_exchange.o $(CSRC)/mcx_sink.o $(CSRC)/mcx_murray.o $(CSRC)/mcx_k_fast.o $(CSRC)/mcx_k_fastb.o $(CSRC)/mcx_k_fast_full.o $(CSRC)/mcx_k_pregen.o $(CSRC)/mcx_k_generic_burn.o \
        $(CSRC)/mcx_k_generic_main.o $(CSRC)/mcx_k_persist.o
-HDRS = $(CSRC)/mcx_device.hpp $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_launch.hpp $(CSRC)/mcx_persist.hpp include/mcx.h
+HDRS = $(CSRC)/mcx_device.hpp $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_launch.hpp $(CSRC)/mcx_persist.hpp $(CSRC)/mcx_engine_internal.hpp include/mcx.h
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-# the Murray kernels are seen by the engine's translation unit only
-$(CSRC)/mcx_engine.o: $(CSRC)/mcx_remote.hpp $(CSRC)/mcx_cull_proj.hpp $(CSRC)/mcx_text.hpp $(CSRC)/fmt_g6.hpp
+# what only one translation unit sees
+$(CSRC)/mcx_murray.o: $(CSRC)/mcx_remote.hpp $(CSRC)/mcx_cull_proj.hpp
+$(CSRC)/mcx_sink.o: $(CSRC)/mcx_text.hpp $(CSRC)/fmt_g6.hpp
 $(CSRC)/mcx_k_fastb.o: $(CSRC)/mcx_fastb.hpp
 
 mcpar_amd/libmcx.so: $(OBJS)

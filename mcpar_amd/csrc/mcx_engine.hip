@@ -3,48 +3,15 @@
 //
 // There is no CPU compute path in this file: every entry point that computes anything needs a
 // HIP device and returns MCX_ERR_NO_DEVICE without one.
-#include "../../include/mcx.h"
-#include "mcx_device.hpp"
-#include "mcx_launch.hpp"
-#include "mcx_persist.hpp"
-#include "mcx_remote.hpp"
-#include "mcx_cull_proj.hpp"
-#include "mcx_text.hpp"
+#include "mcx_engine_internal.hpp"
 
-#include <dlfcn.h>
-#include <fcntl.h>
-#include <sys/file.h>
-#include <sys/stat.h>
-#include <unistd.h>
-// RCCL types only: librccl.so.1 is loaded at run time (mcx_rccl_*), never linked, and a build machine without the
-// RCCL development headers gets the handful of declarations the dlopen shim needs
-#if __has_include(<rccl/rccl.h>)
-#include <rccl/rccl.h>
-#else
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclFloat = 7 } ncclDataType_t;
-#endif
-
-#include <algorithm>
-#include <chrono>
-#include <cerrno>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
-
-using namespace mcx;
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-static int fail(int code, const char *fmt, ...)
+int fail(int code, const char *fmt, ...)
 {
   char buf[512];
   va_list ap;
@@ -55,29 +22,11 @@ static int fail(int code, const char *fmt, ...)
   return code;
 }
 
-#define HIPCHK(expr)                                                                       \
-  do {                                                                                     \
-    hipError_t e_ = (expr);                                                                \
-    if (e_ != hipSuccess)                                                                  \
-      return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? MCX_ERR_NO_DEVICE \
-                                                                        : MCX_ERR_HIP,      \
-                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-#define MCXCHK(expr)          \
-  do {                        \
-    int s_ = (expr);          \
-    if (s_ != MCX_OK) return s_; \
-  } while (0)
-
 extern "C" const char *mcx_last_error(void) { return g_err.c_str(); }
 extern "C" int mcx_abi_version(void) { return MCX_ABI_VERSION; }
 
-// Test hook, not part of the public header: mcx_set_option(e, 12, k) makes the tuner meetings of the one-launch small-n
-// kernel wait for k workgroups more than the grid has, i.e. they can never complete (tests/test_gpu_small_n_safety.py).
-enum { MCX_OPT_DEBUG_MEET = 12 };
 
-static int need_device()
+int need_device()
 {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -110,21 +59,6 @@ extern "C" int mcx_device_info(char *name, size_t namelen, int *cu_count, size_t
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
-static inline int lpc_for(int d)
-{
-  const int nb = (d + 3) / 4;
-  int l = 1;
-  while (l < nb) l <<= 1;
-  return l;
-}
-static inline int dmax_for(int d)
-{
-  int m = 2;
-  while (m < d) m <<= 1;
-  return m;
-}
-static inline unsigned nblocks(size_t threads) { return (unsigned)((threads + BLOCK - 1) / BLOCK); }
-
 // Cholesky factor, lower, row-major, strict upper triangle zeroed: the role of spotrf('U') on the
 // column-major view in MCPar::covar_setup (src/mcpar.cc:470-480).  Host side, np <= 32, once per run.
 static int cholesky_lower(int d, float *a)
@@ -144,70 +78,6 @@ static int cholesky_lower(int d, float *a)
   }
   return 0;
 }
-
-template <typename T>
-struct DevBuf {
-  T *p = nullptr;
-  size_t n = 0;
-  int alloc(size_t count)
-  {
-    if (count <= n && p) return MCX_OK;
-    release();
-    if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-    if (e != hipSuccess) {
-      (void)hipGetLastError();  // clear the sticky error: later launch checks must not see it
-      p = nullptr;
-      n = 0;
-      return fail(MCX_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-    }
-    n = count;
-    return MCX_OK;
-  }
-  void release()
-  {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-};
-
-// pinned host staging (host-callback likelihoods move nc*np floats out and nc floats in every step)
-template <typename T>
-struct PinBuf {
-  T *p = nullptr;
-  size_t n = 0;
-  int alloc(size_t count)
-  {
-    if (count <= n && p) return MCX_OK;
-    release();
-    if (count == 0) count = 1;
-    if (hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) {
-      (void)hipGetLastError();
-      p = nullptr;
-      return fail(MCX_ERR_ALLOC, "hipHostMalloc(%zu bytes) failed", count * sizeof(T));
-    }
-    n = count;
-    return MCX_OK;
-  }
-  void release()
-  {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    n = 0;
-  }
-};
-
-// device-side likelihood descriptor built from an mcx_vlfunc
-struct LikDev {
-  int kind = 0;  // LikKind, or MCX_VL_HOST
-  int ncomp = 0;
-  DevBuf<float> params;
-  std::vector<float> host;  // staging for the asynchronous upload (must outlive it)
-  mcx_host_fn fn = nullptr;
-  void *ctx = nullptr;
-  bool fusable() const { return kind == LIK_ROSEN1 || kind == LIK_GAUSS || kind == LIK_MIX || kind == LIK_ROSEN2F; }
-};
 
 // uploads asynchronously on st; the caller synchronises before L.host is touched again
 static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
@@ -284,36 +154,6 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   return MCX_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// kernel dispatch on (LPC, likelihood)
-// ---------------------------------------------------------------------------------------------
-#define DISPATCH_LPC(lpc, CALL)                                   \
-  switch (lpc) {                                                  \
-  case 1: { constexpr int LPC_ = 1; CALL; } break;                \
-  case 2: { constexpr int LPC_ = 2; CALL; } break;                \
-  case 4: { constexpr int LPC_ = 4; CALL; } break;                \
-  case 8: { constexpr int LPC_ = 8; CALL; } break;                \
-  case 16: { constexpr int LPC_ = 16; CALL; } break;              \
-  case 32: { constexpr int LPC_ = 32; CALL; } break;              \
-  case 64: { constexpr int LPC_ = 64; CALL; } break;              \
-  default: return fail(MCX_ERR_UNSUPPORTED, "np > 256 is not supported"); \
-  }
-
-// chains per lane of the Murray sweep when np == DMAX (mcx_device.hpp, sweep_rows2): two at 16-D and 32-D, where the
-// LDS broadcast reads bind with one (measured on one box: R-murray jobs 3.5 % faster at 16-D, 5 % faster sweeps at 32-D;
-// the coarser early-outs of 128 chains per wavefront cost less than the reads save)
-#define SWEEP_CPL(DMAX) ((DMAX) == 16 || (DMAX) == 32 ? 2 : 1)
-#define DISPATCH_DMAX(dm, CALL)                                   \
-  switch (dm) {                                                   \
-  case 2: { constexpr int DMAX_ = 2; CALL; } break;               \
-  case 4: { constexpr int DMAX_ = 4; CALL; } break;               \
-  case 8: { constexpr int DMAX_ = 8; CALL; } break;               \
-  case 16: { constexpr int DMAX_ = 16; CALL; } break;             \
-  case 32: { constexpr int DMAX_ = 32; CALL; } break;             \
-  case 64: { constexpr int DMAX_ = 64; CALL; } break;             \
-  default: return fail(MCX_ERR_UNSUPPORTED, "internal: register Murray kernels cover np <= 64"); \
-  }
-
 // The fused-kernel families are compiled in their own translation units (mcx_k_fast.hip,
 // mcx_k_pregen.hip, mcx_k_generic_*.hip) so that the library builds in parallel; see mcx_launch.hpp.
 static int launch_fused_plain(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st, bool fast, int bpl = 1)
@@ -363,156 +203,6 @@ static int eval_device(const LikDev &L, const float *x, float *y, int n, int d, 
   DISPATCH_LPC(lpc, MCXCHK((launch_eval<LPC_>(L.kind, x, y, n, d, L.params.p, L.ncomp, vec4, st))));
   return MCX_OK;
 }
-
-// ---------------------------------------------------------------------------------------------
-// the engine
-// ---------------------------------------------------------------------------------------------
-// counters of one run: [0..7] tuner / accept totals, [8..] the tuner events' meeting words of k_run_small
-constexpr int CTR_WORDS = 8 + PEVENTS * PLEAVES, CTR_RING = 16;
-
-constexpr int SINK_RING = 4;  // blocks of the device ring in sink mode
-
-struct EvPair {
-  hipEvent_t a, b;
-  int kind;
-  uint64_t chain_steps;
-};
-
-struct mcx_engine {
-  // problem (src/mcpar.hh:47-59)
-  int nparam, nchain, ntot, ncov, size, rank, tchains;
-  float PLOCAL, TGT_ARATE_MIN, TGT_ARATE_MAX, SCALE_DEC, SCALE_INC;
-  int SYNCSTEP;
-  uint32_t seed, tbase = 0;
-  int lpc, vec4;
-  int device = 0;  // the HIP device the engine lives on (current device at mcx_create)
-  // device state (src/mcpar.hh:61-88)
-  DevBuf<float> pvals, ptrial, mu, sig, psum2, mutrial, sigtrial, musigall, winvall;
-  DevBuf<float> lylast, lytrial, cfac, cmax, cov, cov0, trace;  // cov0 = the factor as installed (cov is rescaled by the tuner)
-  DevBuf<uint32_t> acc_cnt, acc_slots;
-  int nslots = 0;
-  DevBuf<unsigned long long> ctr;  // [0..3] tuner (k_tuner), [4] main-loop accepts
-  DevBuf<int> active0, active1, nact, ntrace;  // nact: [0] survivors of the pass; as u64: [1 .. 1 + CULL_NCOUNT) / the next
-                                               // CULL_NCOUNT cells: pairs kept by the exclusion tests of the min-arg sweep /
-                                               // of the sum sweeps of this genRemote call (spread: same-address atomics are slow)
-  // exact exclusion of far Gaussians in the Murray sweeps (mcx_remote.hpp, k_cull_*)
-  DevBuf<unsigned> cull_keys, cull_hist;
-  DevBuf<int> cull_sorted;
-  DevBuf<unsigned long long> tun_cells;  // SegArgs::Tuner::cells
-  DevBuf<unsigned long long> text_wg;    // mcx_samples_text: per-workgroup byte counts / offsets
-  DevBuf<char> text_dev;                 // and the text itself
-  DevBuf<float> cull_stats, cull_box, cull_lim;
-  DevBuf<double> proj_acc, proj_p, proj_lohi;  // mcx_cull_proj.hpp: two power iterations' sums, e.x per chain, [lo, hi] per group
-  DevBuf<unsigned long long> cull_excl;
-  int opt_cull = -1;  // -1 auto (many chains, many Gaussians; np = 16: boxes, np = 32: along one direction), 0 off,
-                      // 1 boxes whenever the kernels allow, 2 one direction whenever they allow
-  int cull_skip[2] = {0, 0};  // auto mode: genRemote calls for which the min-arg / sum sweeps go without the test,
-                              // because it excluded too little last time it was tried (then it is tried again)
-  DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev, zpre, upre, trash;
-  bool pinit_staged = false;
-  DevBuf<uint8_t> mask;
-  // host staging
-  PinBuf<float> h_ptrial, h_lytrial;
-  PinBuf<unsigned long long> h_ctr;  // the run's counters, read back once at its end
-  PinBuf<unsigned long long> h_nact;  // a Murray pass's survivor count (and the exclusion tests' counters)
-  std::vector<float> h_cov, h_cov_dev, h_winv;  // h_cov_dev = what cov0 holds
-  bool cov_pending = false;  // cov has not been reset to cov0 for the current run yet
-  bool cov_offdiag = false;  // cov (device) may hold non-zero entries below the diagonal
-  int ctr_set = 0;           // counter block of the current run (ring of CTR_RING blocks, zeroed when it wraps)
-  int meet_fd = -1;          // lock file of this GPU: at most one kernel with grid-wide meetings in flight (see meet_lock_open)
-  bool meet_held = false;    // this engine holds the lock: a launch with meetings may still be running
-  bool meet_check = false;   // a launch with meetings is in flight: its "abandoned" word has not been looked at yet
-  unsigned long long *meet_word = nullptr;  // that word (ctr[5] of the run's counter block)
-  bool persist_broken = false;  // a meeting was abandoned once on this engine: the one-launch kernel is not used again
-  int opt_meet_timeout_ms = 50, opt_debug_meet = 0;
-  int opt_meet_under_gather = -1;  // may a launch with tuner meetings start under this engine's in-flight gather: -1 auto (= no), 0 no, 1 yes
-  // run bookkeeping
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  int opt_stride = 1;
-  int opt_split = -1;  // small-n mode: -1 auto, 0 off, 1 on (when the hot-path kernel applies)
-  int opt_bpl = 0;     // 4-parameter blocks per lane of the hot-path kernel: 0 auto, 1, 2, 4
-  int opt_persist = -1;  // small-n mode, one launch per stretch of local steps (k_run_small): -1 auto, 0 off, 1 on
-  int ncu = 0;           // compute units of the device (the persistent grid must be resident at once)
-  int opt_samples = 1, opt_mask = 0, opt_fuse = 1, opt_maxseg = 256, opt_profile = 0, opt_eager = 0, opt_async_tail = 1, opt_sink_text = 0;
-  int last_nsamp = 0, last_nburn = 0, samp_steps = 0;
-  bool have_run = false, diag = true, xchg_pending = false;
-  int published_steps = 0;  // main-loop steps reflected in this shard's musigall slot
-  int tail_publish = 0;     // > 0: the run's last gather is still in flight; publish that many steps once it is done (finish_tail)
-  LikDev lik;
-  mcx_exchange_fn xfn = nullptr;
-  void *xctx = nullptr;
-  // native RCCL exchange (mcx_exchange_rccl_*): in-place ncclAllGather of the musigall slots on a side stream
-  ncclComm_t xcomm = nullptr;
-  bool xcomm_owned = false;
-  hipStream_t xstream = nullptr;
-  hipEvent_t xready = nullptr, xdone = nullptr;
-  mcx_output_fn ofn = nullptr;
-  void *octx = nullptr;
-  // streaming sample sink (mcx_set_sink): ring of SINK_RING blocks in samp_x / samp_ly, staged out on cstream
-  mcx_sink_fn sfn = nullptr;
-  mcx_text_sink_fn tfn = nullptr;  // mcx_set_text_sink: the blocks as text instead of rows (one of the two at most)
-  DevBuf<unsigned long long> sink_text_wg[2];  // per staging buffer: the text kernels' byte counts / offsets
-  PinBuf<unsigned long long> sink_text_total[2];
-  PinBuf<char> sink_text_pin;
-  bool run_sink_text = false;        // this run's row sink also gets every block's text (MCX_OPT_SINK_TEXT)
-  const char *cb_text = nullptr;     // valid while a sink callback runs: mcx_sink_text
-  size_t cb_text_bytes = 0;
-  void *sctx = nullptr;
-  int sink_block = 0;  // main-loop steps per block (0 = no sink: the whole run stays in HBM)
-  bool run_sink = false;           // the current / last run streamed its samples
-  int last_sink_total = 0;         // kept steps handed to the copy stream so far
-  int run_sblock = 0, run_kb = 0;  // its block length in steps / in kept steps
-  hipStream_t cstream = nullptr;
-  hipEvent_t ev_steps[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
-  DevBuf<float> sink_stage[2];
-  PinBuf<float> sink_pin[2];
-  DevBuf<float> best_row;            // running maximum-likelihood sample: [0] = log-likelihood, [1..np] = parameters
-  DevBuf<unsigned long long> best_key;  // scratch of the arg-max reduction
-  mcx_counters cnt{};
-  DevBuf<unsigned long long> trace_clk;  // MCX_PERSIST_TRACE (debug builds): per-wavefront phase clocks of the last small-n launch
-  DevBuf<uint32_t> deal_tab;         // RunArgs::deal of the one-launch small-n kernel, for the configuration in deal_key
-  std::vector<uint32_t> h_deal;
-  long long deal_key = -1;
-  uint64_t meet_total = 0;           // runs repeated because a meeting was abandoned, over the engine's life
-  int runs_since_broken = 0;         // runs on the per-segment kernels since then (the one-launch kernel is tried again)
-  // time the step stream waits for gathers begun earlier (mcx_counters.exchange_wait_ns): event pairs around each wait
-  std::chrono::steady_clock::time_point ht_mark[3];  // MCX_VERBOSE=2: first launch queued / everything queued / stream idle
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> xw_pool;
-  size_t xw_used = 0;
-  std::vector<EvPair> evs;
-  mcx_profile prof{};
-};
-
-// every entry point may be called from a thread whose current device is another one
-static inline int enter(mcx_engine *e)
-{
-  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
-  HIPCHK(hipSetDevice(e->device));
-  return MCX_OK;
-}
-
-struct ProfScope {
-  mcx_engine *e;
-  EvPair p{};
-  bool on;
-  ProfScope(mcx_engine *e_, int kind, uint64_t cs) : e(e_), on(e_->opt_profile != 0)
-  {
-    e->cnt.kernel_launches++;
-    if (!on) return;
-    p.kind = kind;
-    p.chain_steps = cs;
-    (void)hipEventCreate(&p.a);
-    (void)hipEventCreate(&p.b);
-    (void)hipEventRecord(p.a, e->stream);
-  }
-  ~ProfScope()
-  {
-    if (!on) return;
-    (void)hipEventRecord(p.b, e->stream);
-    e->evs.push_back(p);
-  }
-};
 
 // Launch one segment of consecutive local steps.  Small-n mode (MCX_OPT_SPLIT_RNG): with few chains the
 // fused kernel is bound by the latency of a single wave's instruction stream, two thirds of it random
@@ -639,7 +329,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   A(e->tun_cells.alloc(TUN_CELLS + 1));
   if (st == MCX_OK && hipMemset(e->tun_cells.p, 0, (TUN_CELLS + 1) * sizeof(unsigned long long)) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipMemset failed");
-  A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(2 * (1 + 2 * CULL_NCOUNT))); A(e->ntrace.alloc(1));
+  A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(2 * (1 + 2 * NACT_CULL_CELLS))); A(e->ntrace.alloc(1));
   if (st == MCX_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipStreamCreate failed");
   if (st != MCX_OK) { mcx_destroy(e); return st; }
@@ -703,7 +393,6 @@ extern "C" int mcx_destroy(mcx_engine *e)
   return MCX_OK;
 }
 
-static int finish_tail(mcx_engine *e);
 
 extern "C" int mcx_set_exchange(mcx_engine *e, mcx_exchange_fn fn, void *ctx)
 {
@@ -849,7 +538,7 @@ static int eval_trials(mcx_engine *e, const float *x_dev, float *y_dev, uint64_t
 // Base pointers such that kept step r = isamp / stride of the run lives at base + r * rowsize: the whole-run
 // store itself, or -- in sink mode -- the ring slot of isamp's block shifted back by the block's first row
 // (kernels index rows of the run; a launch never straddles a block).
-static void samp_vbase(const mcx_engine *e, int isamp, float **px, float **pl)
+void samp_vbase(const mcx_engine *e, int isamp, float **px, float **pl)
 {
   if (!e->run_sink) { *px = e->samp_x.p; *pl = e->samp_ly.p; return; }
   const long long b = isamp / e->run_sblock, slot = b % SINK_RING, shift = (slot - b) * (long long)e->run_kb;
@@ -897,527 +586,6 @@ static int launch_accept(mcx_engine *e, const StepArgs &a, bool main)
   return MCX_OK;
 }
 
-constexpr int SROW_UNMASKED_MAX_CHAINS = 8192;  // see launch_sweep_exact
-
-// the all-pairs sweep over chains whose np is a power of two (d == DMAX): one or two chains per lane (SWEEP_CPL).
-// Workgroups of 512 / 1024 threads (fewer copies of a block's Gaussians staged through LDS) were measured on the
-// two-chain kernels: C3 R-murray 39.2 ms with 256 threads, 40.0 with 512, 49.4 with 1024; the 32-D mixture 43.4 / 42.7
-// / 42.7 -- the staging is not what a sweep waits for.
-template <int DM, bool SUMS>
-static void launch_sweep_exact(const float *x, const int *list, int cnt, const float *qpar, float *psum, float *pmax,
-                               int N, int own0, const unsigned long long *excl, int ngroups, int S, hipStream_t st)
-{
-  constexpr int CPL = SWEEP_CPL(DM);
-  if constexpr (DM == 16) {
-    // masked, or few chains: every wavefront reads its own rows through the scalar cache (no LDS, no barriers);
-    // unmasked over many chains the rows are better staged once per 512 chains (4.3 GB through L2 otherwise)
-    if (excl || cnt <= SROW_UNMASKED_MAX_CHAINS) {
-      hipLaunchKernelGGL((k_remote_sweep_srow16<SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), S), dim3(BLOCK), 0, st,
-                         x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups);
-      return;
-    }
-  }
-  hipLaunchKernelGGL((k_remote_sweep<DM, SUMS, true, CPL>), dim3(nblocks(((size_t)cnt + CPL - 1) / CPL), S), dim3(BLOCK), 0, st, x,
-                     list, cnt, qpar, psum, pmax, DM, N, own0, excl, ngroups);
-}
-
-// Sort the active chains by their spatial key, box every group of CULL_W of them and test every (group, Q_i)
-// pair (mcx_remote.hpp, "Exact exclusion of far Gaussians").  Leaves the sorted list in e->cull_sorted and the
-// masks in e->cull_excl ([group][words]); the pairs kept are added to the device counter behind e->nact.
-constexpr int CULL_MIN_CHAINS = 4096, CULL_MIN_GAUSSIANS = 4096;
-
-template <int DMAX>
-static int cull_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, hipStream_t st)
-{
-  const int d = e->nparam, N = e->tchains;
-  const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64;
-  // (the sums and the histogram are zero here: zeroed when allocated, and again by every k_cull_boxes)
-  hipLaunchKernelGGL(k_cull_stats, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p);
-  hipLaunchKernelGGL(k_cull_keys, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p,
-                     e->cull_keys.p, e->cull_hist.p);
-  hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
-  hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
-                     e->cull_sorted.p);
-  const dim3 gb((unsigned)((ng + BLOCK / 64 - 1) / (BLOCK / 64)));
-  if (sums)
-    hipLaunchKernelGGL((k_cull_boxes<DMAX, true>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
-                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p, e->cull_stats.p, e->cull_hist.p);
-  else
-    hipLaunchKernelGGL((k_cull_boxes<DMAX, false>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
-                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p, e->cull_stats.p, e->cull_hist.p);
-  const int gchunk = 64;  // (every chunk re-reads the Gaussians' key dimensions: 74 us per 65 536 x 65 536 test with 16, 35 with 64)
-  hipLaunchKernelGGL((k_cull_test<DMAX>), dim3((unsigned)((nw + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)((ng + gchunk - 1) / gchunk)),
-                     dim3(BLOCK), 0, st, (const float *)e->winvall.p, N, (const float *)e->cull_box.p, (const float *)e->cull_lim.p, ng, nact,
-                     gchunk, e->cull_excl.p, nw, reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
-  HIPCHK(hipGetLastError());
-  e->cnt.kernel_launches += 6;
-  return MCX_OK;
-}
-
-// The same with the chains sorted along ONE direction and every (group, Q_i) row bounded by Cauchy-Schwarz along it
-// (mcx_cull_proj.hpp): for chain clouds no box of a few coordinates separates.
-template <int DMAX>
-static int cull_prepare_proj(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, hipStream_t st)
-{
-  const int N = e->tchains;
-  const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64;
-  double *acc0 = e->proj_acc.p, *acc1 = e->proj_acc.p + PROJ_ACC;
-  // (acc0 and the histogram are zero here: zeroed when allocated, and again by every k_proj_groups; acc1 is zeroed now)
-  HIPCHK(hipMemsetAsync(acc1, 0, PROJ_ACC * sizeof(double), st));
-  hipLaunchKernelGGL((k_proj_moments<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc0, 0, acc0);
-  hipLaunchKernelGGL((k_proj_moments<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc0, 1, acc1);
-  hipLaunchKernelGGL((k_proj_keys<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc1,
-                     e->proj_p.p, e->cull_keys.p, e->cull_hist.p);
-  hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
-  hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
-                     e->cull_sorted.p);
-  const dim3 gb((unsigned)((ng + BLOCK / 64 - 1) / (BLOCK / 64)));
-  if (sums)
-    hipLaunchKernelGGL((k_proj_groups<DMAX, true>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
-                       (const float *)e->winvall.p, own0, (const double *)e->proj_p.p, e->proj_lohi.p, e->cull_lim.p, acc0, e->cull_hist.p);
-  else
-    hipLaunchKernelGGL((k_proj_groups<DMAX, false>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
-                       (const float *)e->winvall.p, own0, (const double *)e->proj_p.p, e->proj_lohi.p, e->cull_lim.p, acc0, e->cull_hist.p);
-  const int gchunk = 64;
-  hipLaunchKernelGGL((k_proj_test<DMAX>), dim3((unsigned)((nw + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)((ng + gchunk - 1) / gchunk)),
-                     dim3(BLOCK), 0, st, (const float *)e->winvall.p, N, (const double *)acc1, (const double *)e->proj_lohi.p,
-                     (const float *)e->cull_lim.p, ng, nact, gchunk, e->cull_excl.p, nw,
-                     reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
-  HIPCHK(hipGetLastError());
-  e->cnt.kernel_launches += 8;
-  return MCX_OK;
-}
-
-// MCPar::genRemote on device buffers (src/mcpar.cc:315-451)
-static int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
-                         float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
-{
-  const int n = e->nchain, d = e->nparam, N = e->tchains, dm = d <= 64 ? dmax_for(d) : 64;
-  const bool big = d > 64;  // chain vector in registers up to np = 64, re-read from memory above
-  const int S = (N + QBLOCK - 1) / QBLOCK;
-  if (!big && S > 65535)  // blocks of Gaussians go in gridDim.y
-    return fail(MCX_ERR_UNSUPPORTED, "Murray proposals over %d chains in all: at most %d", N, 65535 * QBLOCK);
-  hipStream_t st = e->stream;
-  ProfScope ps(e, MCX_K_REMOTE, (uint64_t)n);
-  if (!big) {
-    MCXCHK(e->psum.alloc((size_t)n * S));
-    MCXCHK(e->pmax.alloc((size_t)n * S));
-    MCXCHK(e->racpt.alloc((size_t)n));
-  }
-  // exclusion of far Gaussians: the two-chains-per-lane sweeps (np = 16, 32) over enough chains and Gaussians to
-  // pay for the sort and the tests (or whenever possible: MCX_OPT_CULL = 1, for the tests)
-  const bool cull_can = !big && d == dm && SWEEP_CPL(dm) == 2 && e->opt_cull != 0;
-  auto cull_now = [&](int na) { return cull_can && (e->opt_cull > 0 || (na >= CULL_MIN_CHAINS && N >= CULL_MIN_GAUSSIANS)); };
-  if (cull_can) {
-    const size_t ngmax = ((size_t)n + CULL_W - 1) / CULL_W, nw = ((size_t)N + 63) / 64;
-    const bool fresh = !e->cull_hist.p || !e->cull_stats.p;
-    MCXCHK(e->cull_keys.alloc((size_t)n)); MCXCHK(e->cull_hist.alloc(CULL_BINS)); MCXCHK(e->cull_sorted.alloc((size_t)n));
-    MCXCHK(e->cull_stats.alloc(2 * CULL_KD));
-    if (fresh) {  // (k_cull_boxes leaves them zero for the next sort)
-      HIPCHK(hipMemsetAsync(e->cull_stats.p, 0, 2 * CULL_KD * sizeof(float), st));
-      HIPCHK(hipMemsetAsync(e->cull_hist.p, 0, CULL_BINS * sizeof(unsigned), st));
-    } MCXCHK(e->cull_box.alloc(ngmax * 2 * CULL_KD)); MCXCHK(e->cull_lim.alloc(ngmax));
-    MCXCHK(e->cull_excl.alloc(ngmax * nw));
-    const bool fresh_p = !e->proj_acc.p;
-    MCXCHK(e->proj_acc.alloc(2 * PROJ_ACC)); MCXCHK(e->proj_p.alloc((size_t)n)); MCXCHK(e->proj_lohi.alloc(2 * ngmax));
-    if (fresh_p) HIPCHK(hipMemsetAsync(e->proj_acc.p, 0, 2 * PROJ_ACC * sizeof(double), st));
-  }
-  // which exact screen: boxes of four coordinates (the narrow per-chain Gaussians of C3's shape) or one direction (np = 32:
-  // the mixture of C5, whose components lie on a line no coordinate axis is close to)
-  const bool proj = e->opt_cull == 2 || (e->opt_cull < 0 && dm == 32);
-  HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
-  uint64_t evaluated_host = 0;  // pairs of the sweeps that ran without an exclusion test
-  // auto mode gives the test up where it excludes too little to pay for itself (the 32-D mixture: per-chain
-  // Gaussians too broad for any 128-chain box), per kind of sweep, and tries again every eighth call
-  constexpr double CULL_USELESS = 0.85;
-  bool cull_min = true, cull_sums = true;
-  if (e->opt_cull < 0) {
-    if (e->cull_skip[0] > 0) { cull_min = false; e->cull_skip[0]--; }
-    if (e->cull_skip[1] > 0) { cull_sums = false; e->cull_skip[1]--; }
-  }
-  uint64_t tested_min = 0, tested_sums = 0;
-  hipLaunchKernelGGL(k_remote_prep, dim3(nblocks((size_t)N * d)), dim3(BLOCK), 0, st, musigall,
-                     e->winvall.p, (size_t)N * d);
-  const int own0 = e->rank * e->nchain;
-  if (big) {
-    hipLaunchKernelGGL(k_remote_cmax_big, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, pvals, e->winvall.p,
-                       e->cmax.p, n, d, N);
-    evaluated_host += (uint64_t)n * (uint64_t)N;
-  } else {
-    const bool cull = cull_now(n) && cull_min;
-    if (cull) tested_min = (uint64_t)n * (uint64_t)N;
-    const int *order = nullptr;
-    const unsigned long long *excl = nullptr;
-    if (cull) {
-      if (proj) {
-        DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
-      } else {
-        DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
-      }
-      order = e->cull_sorted.p;
-      excl = e->cull_excl.p;
-    } else {
-      evaluated_host += (uint64_t)n * (uint64_t)N;
-    }
-    {
-      ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)n * (uint64_t)N);
-      if (d == dm) {
-        DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, false>(pvals, order, n, e->winvall.p, (float *)nullptr, e->pmax.p,
-                                                           N, own0, excl, (n + CULL_W - 1) / CULL_W, S, st)));
-      } else {
-        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
-                                             0, st, pvals, (const int *)nullptr, n, e->winvall.p,
-                                             (float *)nullptr, e->pmax.p, d, N, own0, (const unsigned long long *)nullptr, 0));
-      }
-    }
-    hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S, order);
-  }
-  HIPCHK(hipGetLastError());
-  e->cnt.remote_pairs += (uint64_t)n * (uint64_t)N;
-  int nact = n, pass = 0;
-  int *ain = nullptr, *aout = e->active0.p;
-  unsigned long long kept_min = 0, kept_sums = 0;
-  MCXCHK(e->h_nact.alloc(1 + 2 * CULL_NCOUNT));  // pinned: the per-pass read-back queues behind the pass's last kernel
-  while (nact > 0) {
-    // two survivor counters in turn: a pass counts in one and zeroes the other for the next pass (the first pass's
-    // draw zeroes its own) -- no fill between the passes
-    int *const cnt_here = e->nact.p + (pass & 1);
-    if (big) HIPCHK(hipMemsetAsync(cnt_here, 0, sizeof(int), st));
-    RemoteArgs a;
-    a.active_in = ain; a.nact = nact; a.active_out = aout; a.nact_out = cnt_here;
-    a.nact_zero = big ? nullptr : e->nact.p + ((pass + 1) & 1);
-    a.musigall = musigall; a.winv = e->winvall.p; a.cmax = e->cmax.p;
-    a.ptrial = ptrial; a.mutrial = mutrial; a.sigtrial = sigtrial; a.cfac = cfac;
-    a.racpt = e->racpt.p; a.psum = e->psum.p; a.pmax = e->pmax.p;
-    a.n = n; a.d = d; a.N = N; a.pass = pass; a.S = S;
-    a.g0 = (uint32_t)(e->rank * e->nchain); a.t = t; a.seed = e->seed;
-    if (big) {
-      hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
-      evaluated_host += (uint64_t)nact * (uint64_t)N;
-    } else {
-      // (later passes: the k_remote_decide that rejected a chain has drawn its next proposal already)
-      if (pass == 0) DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
-      const bool cull = cull_now(nact) && cull_sums;
-      const int *list = ain;
-      const unsigned long long *excl = nullptr;
-      if (cull) {  // the proposals have just been drawn: sort, box and test them
-        if (proj) {
-          DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
-        } else {
-          DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
-        }
-        list = e->cull_sorted.p;
-        excl = e->cull_excl.p;
-        a.active_in = list;  // positions of psum / pmax are positions of the sorted list
-      } else {
-        evaluated_host += (uint64_t)nact * (uint64_t)N;
-      }
-      {
-      ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)nact * (uint64_t)N);
-      if (d == dm) {
-        DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, true>(ptrial, list, nact, e->winvall.p, e->psum.p, e->pmax.p, N,
-                                                          -1, excl, (nact + CULL_W - 1) / CULL_W, S, st)));
-      } else {
-        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, false>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
-                                             0, st, ptrial, (const int *)ain, nact, e->winvall.p,
-                                             e->psum.p, e->pmax.p, d, N, -1, (const unsigned long long *)nullptr, 0));
-      }
-      }
-      hipLaunchKernelGGL(k_remote_decide, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
-    }
-    HIPCHK(hipGetLastError());
-    e->cnt.remote_pairs += (uint64_t)nact * (uint64_t)N;
-    unsigned long long *back = e->h_nact.p;  // survivors (low word), cells of the pairs kept by the min-arg / sum tests so far
-    HIPCHK(hipMemcpyAsync(back, e->nact.p, (cull_can ? 1 + 2 * CULL_NCOUNT : 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const unsigned long long before = kept_sums;
-    const uint64_t pairs_now = (uint64_t)nact * (uint64_t)N;
-    nact = (int)(unsigned)((pass & 1) ? back[0] >> 32 : back[0] & 0xffffffffull);
-    if (cull_can) {
-      kept_min = kept_sums = 0;
-      for (int c = 0; c < CULL_NCOUNT; ++c) { kept_min += back[1 + c]; kept_sums += back[1 + CULL_NCOUNT + c]; }
-    }
-    if (pairs_now && kept_sums > before) {  // this pass was tested
-      tested_sums += pairs_now;
-      if (e->opt_cull < 0 && (double)(kept_sums - before) > CULL_USELESS * (double)pairs_now) cull_sums = false;
-    }
-    ain = aout;
-    aout = (aout == e->active0.p) ? e->active1.p : e->active0.p;
-    e->cnt.kernel_launches += (big || pass > 0) ? 1 : 2;  // (+1: the sweep's own scope)
-    ++pass;
-  }
-  e->cnt.remote_pairs_evaluated += evaluated_host + (uint64_t)kept_min + (uint64_t)kept_sums;
-  if (e->opt_cull < 0) {
-    if (tested_min && (double)kept_min > CULL_USELESS * (double)tested_min) e->cull_skip[0] = 7;
-    if (tested_sums && (double)kept_sums > CULL_USELESS * (double)tested_sums) e->cull_skip[1] = 7;
-  }
-  hipLaunchKernelGGL(k_square, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, sigtrial, (size_t)e->ntot);
-  HIPCHK(hipGetLastError());
-  if (npass_out) *npass_out = pass;
-  return MCX_OK;
-}
-
-static int meet_release(mcx_engine *e, bool stream_is_idle);
-
-constexpr size_t XW_MAX = 256;  // waits of one run that are timed (a job has one per Murray step at most)
-
-static int exchange_wait(mcx_engine *e)
-{
-  if (!e->xchg_pending) return MCX_OK;
-  MCXCHK(meet_release(e, false));
-  e->xchg_pending = false;
-  // the wait as the step stream sees it: an event on either side (collected by xwait_collect once the stream is idle)
-  const bool timed = e->xw_used < XW_MAX;
-  if (timed && e->xw_used == e->xw_pool.size()) {
-    hipEvent_t a = nullptr, b = nullptr;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
-    e->xw_pool.emplace_back(a, b);
-  }
-  if (timed) HIPCHK(hipEventRecord(e->xw_pool[e->xw_used].first, e->stream));
-  if (e->xfn(e->xctx, MCX_XCHG_WAIT, e->musigall.p, 2 * (size_t)e->ntot, e->rank, e->size, e->stream) != 0)
-    return fail(MCX_ERR_EXCHANGE, "exchange hook failed in WAIT");
-  if (timed) HIPCHK(hipEventRecord(e->xw_pool[e->xw_used++].second, e->stream));
-  e->cnt.exchange_waits++;
-  return MCX_OK;
-}
-
-// the step stream is idle: add up what the timed waits took
-static void xwait_collect(mcx_engine *e)
-{
-  for (size_t i = 0; i < e->xw_used; ++i) {
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, e->xw_pool[i].first, e->xw_pool[i].second) == hipSuccess && ms > 0.0f)
-      e->cnt.exchange_wait_ns += (uint64_t)((double)ms * 1e6);
-  }
-  e->xw_used = 0;
-}
-
-// write this shard's slot from the resident moments after `steps_done` main-loop steps
-static int publish(mcx_engine *e, int steps_done)
-{
-  if (steps_done <= 0 || e->published_steps == steps_done) return MCX_OK;
-  MCXCHK(exchange_wait(e));  // an in-flight gather still reads the slot
-  ProfScope ps(e, MCX_K_MISC, 0);
-  hipLaunchKernelGGL(k_publish, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, e->stream, e->mu.p,
-                     e->psum2.p, e->musigall.p + 2 * (size_t)e->rank * e->ntot, (size_t)e->ntot,
-                     1.0f / (float)steps_done);
-  HIPCHK(hipGetLastError());
-  e->published_steps = steps_done;
-  return MCX_OK;
-}
-
-// The last all-gather of a sharded run feeds nothing inside that run: it leaves the other shards' slots as of the
-// last sync point for whoever looks at musigall next.  When the library's own RCCL exchange carries it (a side stream,
-// nothing for the host to do), mcx_run does not wait for it: the gather runs on under the caller's next steps -- e.g.
-// the burn-in of the next run, which never touches musigall -- and whatever does touch it (mcx_get_musigall, the next
-// gather or publish, mcx_synchronize, mcx_destroy) waits first.  The slot's final publish (own moments after the last
-// step) cannot precede the gather that still reads the slot, so it waits with it.
-static int finish_tail(mcx_engine *e)
-{
-  if (!e->tail_publish) return MCX_OK;
-  const int steps = e->tail_publish;
-  e->tail_publish = 0;
-  MCXCHK(exchange_wait(e));
-  MCXCHK(publish(e, steps));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  xwait_collect(e);
-  return MCX_OK;
-}
-
-static int exchange_begin(mcx_engine *e)
-{
-  MCXCHK(meet_release(e, false));  // a hook may wait for other engines: never while holding the GPU's meeting lock
-  MCXCHK(exchange_wait(e));
-  if (e->xfn(e->xctx, MCX_XCHG_BEGIN, e->musigall.p, 2 * (size_t)e->ntot, e->rank, e->size, e->stream) != 0)
-    return fail(MCX_ERR_EXCHANGE, "exchange hook failed in BEGIN");
-  e->xchg_pending = true;
-  e->cnt.exchanges++;
-  return MCX_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Native RCCL exchange: the MPI_Allgather(MPI_IN_PLACE, ..., musigall, 2*ntot, MPI_FLOAT) of
-// src/mcpar.cc:127-140 as an in-place ncclAllGather over xGMI.  One process (or thread) per GPU, one
-// communicator rank per shard, slot layout of src/mcpar.cc:206 (rank r owns floats [r*2*ntot, (r+1)*2*ntot)).
-// BEGIN enqueues the collective on a side stream behind everything already queued on the engine's
-// stream; WAIT makes the engine's stream wait for it -- so under the reference's own schedule
-// (MCX_OPT_EAGER_EXCHANGE) the gather overlaps the next segment of local steps.  librccl.so.1 is loaded
-// on first use: single-GPU users never need it.
-// ---------------------------------------------------------------------------------------------
-namespace {
-struct RcclApi {
-  void *handle = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
-  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
-  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  const char *(*GetErrorString)(ncclResult_t) = nullptr;
-  std::string why;
-};
-RcclApi g_rccl;
-
-bool rccl_load()
-{
-  if (g_rccl.handle) return true;
-  if (!g_rccl.why.empty()) return false;
-  // if another RCCL is already in the process (e.g. the one PyTorch-ROCm ships) the soname resolves to it
-  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  void *h = nullptr;
-  for (const char *n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-  if (!h) {
-    g_rccl.why = std::string("librccl.so.1 not loadable: ") + (dlerror() ? dlerror() : "?");
-    return false;
-  }
-  bool ok = true;
-  auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) { ok = false; g_rccl.why = std::string("missing RCCL symbol ") + n; } return p; };
-  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
-  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
-  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
-  g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
-  g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
-  g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
-  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
-  if (!ok) return false;
-  g_rccl.handle = h;
-  return true;
-}
-
-#define NCCLCHK(expr)                                                                          \
-  do {                                                                                         \
-    ncclResult_t r_ = (expr);                                                                  \
-    if (r_ != ncclSuccess)                                                                     \
-      return fail(MCX_ERR_EXCHANGE, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));        \
-  } while (0)
-
-// the exchange hook itself: mcx_exchange_fn with ctx = the engine
-int rccl_exchange(void *ctx, int phase, void *dev, size_t slot, int shard, int nshards, void *stream)
-{
-  mcx_engine *e = static_cast<mcx_engine *>(ctx);
-  hipStream_t st = (hipStream_t)stream;
-  (void)nshards;
-  if (phase == MCX_XCHG_BEGIN) {
-    HIPCHK(hipEventRecord(e->xready, st));
-    HIPCHK(hipStreamWaitEvent(e->xstream, e->xready, 0));
-    float *base = static_cast<float *>(dev);
-    NCCLCHK(g_rccl.AllGather(base + slot * (size_t)shard, base, slot, ncclFloat, e->xcomm, e->xstream));  // in place
-    HIPCHK(hipEventRecord(e->xdone, e->xstream));
-  } else {
-    HIPCHK(hipStreamWaitEvent(st, e->xdone, 0));
-  }
-  return 0;
-}
-
-int rccl_install(mcx_engine *e, ncclComm_t comm, bool owned)
-{
-  int cnt = 0, rk = -1;
-  NCCLCHK(g_rccl.CommCount(comm, &cnt));
-  NCCLCHK(g_rccl.CommUserRank(comm, &rk));
-  if (cnt != e->size || rk != e->rank)
-    return fail(MCX_ERR_INVALID, "communicator is rank %d of %d but the engine is shard %d of %d", rk, cnt, e->rank, e->size);
-  if (!e->xstream) HIPCHK(hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking));
-  if (!e->xready) HIPCHK(hipEventCreateWithFlags(&e->xready, hipEventDisableTiming));
-  if (!e->xdone) HIPCHK(hipEventCreateWithFlags(&e->xdone, hipEventDisableTiming));
-  e->xcomm = comm;
-  e->xcomm_owned = owned;
-  e->xfn = rccl_exchange;
-  e->xctx = e;
-  return MCX_OK;
-}
-}  // namespace
-
-extern "C" int mcx_rccl_available(void)
-{
-  if (rccl_load()) return 1;
-  (void)fail(MCX_ERR_EXCHANGE, "%s", g_rccl.why.c_str());
-  return 0;
-}
-
-extern "C" int mcx_rccl_unique_id(void *id)
-{
-  if (!id) return fail(MCX_ERR_INVALID, "id is NULL");
-  if (!rccl_load()) return fail(MCX_ERR_EXCHANGE, "%s", g_rccl.why.c_str());
-  static_assert(sizeof(ncclUniqueId) == MCX_RCCL_ID_BYTES, "MCX_RCCL_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
-  ncclUniqueId u;
-  NCCLCHK(g_rccl.GetUniqueId(&u));
-  std::memcpy(id, &u, sizeof u);
-  return MCX_OK;
-}
-
-extern "C" int mcx_exchange_rccl_init(mcx_engine *e, const void *id)
-{
-  MCXCHK(enter(e));
-  if (!id) return fail(MCX_ERR_INVALID, "id is NULL");
-  if (!rccl_load()) return fail(MCX_ERR_EXCHANGE, "%s", g_rccl.why.c_str());
-  MCXCHK(mcx_exchange_rccl_destroy(e));
-  ncclUniqueId u;
-  std::memcpy(&u, id, sizeof u);
-  ncclComm_t comm = nullptr;
-  NCCLCHK(g_rccl.CommInitRank(&comm, e->size, u, e->rank));  // collective over the nshards engines
-  const int rc = rccl_install(e, comm, true);
-  if (rc != MCX_OK) (void)g_rccl.CommDestroy(comm);
-  return rc;
-}
-
-extern "C" int mcx_exchange_rccl_adopt(mcx_engine *e, void *nccl_comm)
-{
-  MCXCHK(enter(e));
-  if (!nccl_comm) return fail(MCX_ERR_INVALID, "communicator is NULL");
-  if (!rccl_load()) return fail(MCX_ERR_EXCHANGE, "%s", g_rccl.why.c_str());
-  MCXCHK(mcx_exchange_rccl_destroy(e));
-  return rccl_install(e, (ncclComm_t)nccl_comm, false);
-}
-
-extern "C" int mcx_exchange_rccl_destroy(mcx_engine *e)
-{
-  if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
-  if (e->xcomm) {
-    (void)hipSetDevice(e->device);
-    (void)finish_tail(e);
-    if (e->xstream) (void)hipStreamSynchronize(e->xstream);
-    if (e->xcomm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->xcomm);
-    if (e->xfn == rccl_exchange) { e->xfn = nullptr; e->xctx = nullptr; }
-    e->xcomm = nullptr;
-    e->xcomm_owned = false;
-    e->xchg_pending = false;
-  }
-  if (e->xready) { (void)hipEventDestroy(e->xready); e->xready = nullptr; }
-  if (e->xdone) { (void)hipEventDestroy(e->xdone); e->xdone = nullptr; }
-  if (e->xstream) { (void)hipStreamDestroy(e->xstream); e->xstream = nullptr; }
-  return MCX_OK;
-}
-
-extern "C" int mcx_exchange_rccl_info(mcx_engine *e, int *nranks, int *rank)
-{
-  if (!e || !nranks || !rank) return fail(MCX_ERR_INVALID, "bad arguments");
-  if (!e->xcomm) return fail(MCX_ERR_EXCHANGE, "no RCCL exchange installed");
-  NCCLCHK(g_rccl.CommCount(e->xcomm, nranks));
-  NCCLCHK(g_rccl.CommUserRank(e->xcomm, rank));
-  return MCX_OK;
-}
-
-// One exchange right now (publish is the caller's business): BEGIN + WAIT + drain.  Lets a test (or a
-// start-up self-check) push the installed hook through the device without running a job.
-extern "C" int mcx_debug_exchange(mcx_engine *e)
-{
-  MCXCHK(enter(e));
-  if (!e->xfn) return fail(MCX_ERR_EXCHANGE, "no exchange hook installed");
-  MCXCHK(finish_tail(e));
-  MCXCHK(exchange_begin(e));
-  MCXCHK(exchange_wait(e));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return MCX_OK;
-}
-
-static __global__ void k_fill(float *p, size_t n, float v)
-{
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
 // the one-launch small-n kernel's generator deal (mcxk_persist_deal) and steps per phase, for tests: host logic only
 extern "C" int mcx_debug_persist_deal(int lpc2, int bpl, int own, int *rec, int *ksteps, uint32_t *tab, int max_words)
 {
@@ -1427,18 +595,6 @@ extern "C" int mcx_debug_persist_deal(int lpc2, int bpl, int own, int *rec, int 
   *rec = mcxk_persist_recorders(own, bpl) ? 1 : 0;
   *ksteps = mcxk_persist_ksteps(lpc2, bpl, own);
   mcxk_persist_deal(lpc2, bpl, own, *rec, *ksteps, tab);
-  return MCX_OK;
-}
-
-extern "C" int mcx_debug_fill_slot(mcx_engine *e, float value)
-{
-  MCXCHK(enter(e));
-  MCXCHK(finish_tail(e));
-  MCXCHK(exchange_wait(e));  // (a gather in flight still reads the slot)
-  const size_t slot = 2 * (size_t)e->ntot;
-  hipLaunchKernelGGL(k_fill, dim3(nblocks(slot)), dim3(BLOCK), 0, e->stream, e->musigall.p + slot * (size_t)e->rank, slot, value);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(e->stream));
   return MCX_OK;
 }
 
@@ -1462,115 +618,6 @@ extern "C" int mcx_device_pci_bus_id(char *buf, size_t len)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Schedule of one run(): pure host logic (no device), exported as mcx_plan() so that it can be
-// tested without a GPU.  It is what mcx_run executes.
-// ---------------------------------------------------------------------------------------------
-struct PlanCfg {
-  int nsamp, nburn, sync;
-  float pl;
-  uint32_t seed, tbase;
-  bool sharded, eager, fused, output_hook;
-  int maxseg;
-  int sink_block;  // > 0: cut the main loop into blocks of this many steps for the sample sink
-};
-
-// one Philox draw per step for the whole job (the reference draws per rank: src/mcpar.cc:142-146)
-static inline bool coin_is_remote(const PlanCfg &c, int isamp)
-{
-  if (isamp < c.sync) return false;  // :143-144
-  const uint32_t t = c.tbase + (uint32_t)c.nburn + (uint32_t)isamp;
-  const float rndlocal = u24(philox4x32_10(t, 0u, 0u, 0u, c.seed, ST_COIN).x);
-  return !(rndlocal <= c.pl);  // :152
-}
-
-static std::vector<mcx_plan_item> build_plan(const PlanCfg &c)
-{
-  std::vector<mcx_plan_item> p;
-  auto add = [&](int kind, int first, int nsteps, int aux) { p.push_back(mcx_plan_item{kind, first, nsteps, aux}); };
-  // burn-in (src/mcpar.cc:55-97): the tuner looks at the counters when isamp > irate, irate = 50, 100, ...
-  int irate = 50;
-  for (int isamp = 0; isamp < c.nburn;) {
-    int last = irate + 1 < c.nburn ? irate + 1 : c.nburn - 1;
-    if (last - isamp + 1 > c.maxseg) last = isamp + c.maxseg - 1;
-    const int steps = last - isamp + 1, check = last > irate ? 1 : 0;
-    add(MCX_PLAN_BURN_SEGMENT, isamp, steps, 0);
-    add(MCX_PLAN_TUNER, last, steps, check);
-    if (check) irate += 50;
-    isamp = last + 1;
-  }
-  if (c.nsamp > 0) add(MCX_PLAN_INIT_MOMENTS, 0, 0, 0);  // :99-104
-  const int outstep = c.nsamp > 50 ? c.nsamp / 10 : 5;  // :110
-  // Exchange schedule.  The reference gathers at every sync point (isamp % SYNCSTEP == 0, :127-140),
-  // but the gathered slots are read only by genRemote, and every gather overwrites all of them: a
-  // gather that is followed by another gather before the next Murray step is dead.  Default (lazy):
-  // snapshot this shard's slot at every sync point, gather the latest snapshot right before a Murray
-  // step reads it (and once at the end) -- bit-identical results, fused segments may span sync points.
-  // eager = the reference's schedule (each gather overlapped with the next segment).
-  bool need_gather = false;
-  for (int isamp = 0; isamp < c.nsamp;) {
-    if (c.sink_block > 0 && isamp % c.sink_block == 0 && isamp > 0) add(MCX_PLAN_SINK, isamp, c.sink_block, 0);
-    if (isamp % outstep == 0 && isamp > 0 && c.output_hook) add(MCX_PLAN_OUTPUT, isamp, 0, 0);  // :115-119
-    if (c.sharded && isamp % c.sync == 0) {  // :127-140
-      add(MCX_PLAN_PUBLISH, isamp, 0, 0);
-      if (c.eager) add(MCX_PLAN_GATHER_BEGIN, isamp, 0, 0);
-      else need_gather = true;
-    }
-    if (coin_is_remote(c, isamp)) {  // :152-159
-      if (need_gather) {  // the slot holds the snapshot of the last sync point
-        add(MCX_PLAN_GATHER_BEGIN, isamp, 0, 0);
-        need_gather = false;
-      }
-      if (c.sharded) add(MCX_PLAN_GATHER_WAIT, isamp, 0, 0);
-      add(MCX_PLAN_PUBLISH, isamp, 0, 0);  // own slot is always current (:205-208)
-      add(MCX_PLAN_REMOTE_STEP, isamp, 1, 0);
-      ++isamp;
-      continue;
-    }
-    // run of local steps up to the next output dump / Murray step (/ sync point when eager or unfused)
-    const bool span_sync = c.fused && c.sharded && !c.eager;
-    int steps = 1;
-    while (isamp + steps < c.nsamp && steps < c.maxseg) {
-      const int nx = isamp + steps;
-      if (nx % outstep == 0 && c.output_hook) break;
-      if (c.sink_block > 0 && nx % c.sink_block == 0) break;
-      if (c.sharded && !span_sync && nx % c.sync == 0) break;
-      if (coin_is_remote(c, nx)) break;
-      ++steps;
-    }
-    int snap_after = -1;
-    if (span_sync) {  // last sync point strictly inside the segment: the kernel snapshots the slot there
-      const int last = ((isamp + steps - 1) / c.sync) * c.sync;
-      if (last > isamp) {
-        snap_after = last - 1 - isamp;
-        need_gather = true;
-      }
-    }
-    add(MCX_PLAN_MAIN_SEGMENT, isamp, steps, snap_after);
-    isamp += steps;
-  }
-  if (c.sink_block > 0 && c.nsamp > 0) add(MCX_PLAN_SINK, c.nsamp, c.nsamp - ((c.nsamp - 1) / c.sink_block) * c.sink_block, 0);
-  if (need_gather) add(MCX_PLAN_GATHER_BEGIN, c.nsamp, 0, 0);  // remote slots end as of the last sync point
-  if (c.sharded) add(MCX_PLAN_GATHER_WAIT, c.nsamp, 0, 0);
-  add(MCX_PLAN_PUBLISH, c.nsamp, 0, 0);
-  return p;
-}
-
-extern "C" int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed, uint32_t tbase, int nshards,
-                        int eager, int fused, int max_segment, int has_output_hook, int sink_block_steps,
-                        mcx_plan_item *items, int max_items, int *nitems)
-{
-  if (nsamp < 0 || nburn < 0 || sync < 1 || nshards < 1 || max_segment < 1 || sink_block_steps < 0 || !nitems)
-    return fail(MCX_ERR_INVALID, "bad arguments");
-  const PlanCfg c = {nsamp, nburn, sync, pl, seed, tbase, nshards > 1, eager != 0, fused != 0, has_output_hook != 0, max_segment,
-                     sink_block_steps};
-  const std::vector<mcx_plan_item> p = build_plan(c);
-  *nitems = (int)p.size();
-  if (items)
-    for (int i = 0; i < (int)p.size() && i < max_items; ++i) items[i] = p[(size_t)i];
-  return MCX_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_run_small's tuner events are meetings of ALL its workgroups at a device counter: every workgroup of the
 // grid must be resident.  The grid is sized to fit the GPU on its own (one workgroup per CU), but two such
 // kernels dispatched at the same time -- two engines of one process, or two processes sharing a GPU -- could
@@ -1581,11 +628,11 @@ extern "C" int mcx_plan(int nsamp, int nburn, int sync, float pl, uint32_t seed,
 // ---------------------------------------------------------------------------------------------
 // internal status of run_once(): a tuner meeting of k_run_small was abandoned (or its grid cannot be resident):
 // mcx_run repeats the run on the per-segment kernels.  Never leaves this file.
-constexpr int MCX_INTERNAL_MEET_ABANDONED = 1000;
+
 
 // the launch that took the lock has completed (or is waited for here): let the next one in, and look at the
 // launch's "abandoned" word -- before any of its results is used or shown to a hook
-static int meet_release(mcx_engine *e, bool stream_is_idle)
+int meet_release(mcx_engine *e, bool stream_is_idle)
 {
   if (!e->meet_held && !e->meet_check) return MCX_OK;
   hipError_t se = hipSuccess;
@@ -1637,123 +684,6 @@ static int meet_lock_take(mcx_engine *e)
   while (rc != 0 && errno == EINTR);
   if (rc != 0) return fail(MCX_ERR_HIP, "cannot lock the GPU's meeting lock file: %s", strerror(errno));
   e->meet_held = true;
-  return MCX_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Streaming sample sink (mcx_set_sink).  Block number seq (main-loop steps [done - nsteps, done)) has just been
-// queued on the step stream: note its maximum-likelihood sample, then stage it out on the copy stream -- rows
-// interleaved into MCout's layout on the device, one D2H into pinned memory -- while the step stream runs on.
-// Two staging buffers: before block seq may take buffer seq % 2, the consumer is given block seq - 2 (the host
-// waits for THAT copy only; the device ring holds SINK_RING = 4 blocks, so steps are never held up by a slot
-// that is still being read as long as the consumer keeps up).
-// ---------------------------------------------------------------------------------------------
-static int sink_deliver(mcx_engine *e, int seq)
-{
-  MCXCHK(meet_release(e, false));  // (the consumer may take its time)
-  const int b = seq & 1;
-  HIPCHK(hipEventSynchronize(e->ev_copy[b]));
-  const int first = seq * e->run_kb;  // kept steps before this block
-  const int kept = std::min(e->run_kb, (e->last_sink_total - first));
-  if (e->tfn || e->run_sink_text) {
-    // text sink: the block's byte count has arrived with the event; now that its size is known, the fields are
-    // formatted once more into place (mcx_text.hpp) and copied out -- the staging buffer still holds the rows (the block
-    // that reuses it is queued only after this call)
-    const size_t total = (size_t)e->sink_text_total[b].p[0];
-    const size_t count = (size_t)kept * e->nchain * (size_t)(e->nparam + 1), nwg = (count + BLOCK - 1) / BLOCK;
-    int arc = e->text_dev.alloc(total);
-    if (arc == MCX_OK && total > e->sink_text_pin.n) arc = e->sink_text_pin.alloc(total + total / 8);
-    if (arc != MCX_OK && e->tfn) return arc;
-    if (arc == MCX_OK) {
-      hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
-                         (const float *)nullptr, count, e->nparam, (const unsigned long long *)e->sink_text_wg[b].p, e->text_dev.p);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(e->sink_text_pin.p, e->text_dev.p, total, hipMemcpyDeviceToHost, e->cstream));
-      HIPCHK(hipStreamSynchronize(e->cstream));
-      if (e->tfn) {
-        if (e->tfn(e->sctx, first, kept, e->sink_text_pin.p, total) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
-        return MCX_OK;
-      }
-      e->cb_text = e->sink_text_pin.p;  // (row sink with MCX_OPT_SINK_TEXT: the callback asks mcx_sink_text for it)
-      e->cb_text_bytes = total;
-    }
-    // (a row sink whose block's text found no memory gets its rows all the same: mcx_sink_text then says so)
-  }
-  const int rc = e->sfn(e->sctx, first, kept, e->sink_pin[b].p);
-  e->cb_text = nullptr;
-  e->cb_text_bytes = 0;
-  if (rc != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
-  return MCX_OK;
-}
-
-static int sink_block_done(mcx_engine *e, int done, int nsteps, int seq)
-{
-  const int n = e->nchain, d = e->nparam, b = seq & 1;
-  const int first_step = done - nsteps;  // the block's first main-loop step: a multiple of the block length
-  float *vx, *vl;
-  samp_vbase(e, first_step, &vx, &vl);
-  const size_t row0 = (size_t)(first_step / e->opt_stride);
-  const size_t kept = (size_t)((done + e->opt_stride - 1) / e->opt_stride) - row0;
-  const float *sx = vx + row0 * e->ntot, *sl = vl + row0 * n;
-  e->last_sink_total = (int)(row0 + kept);
-  // running maximum (src/mcout.cc:140-144), on the step stream: cheap, and ordered before the slot's reuse
-  hipLaunchKernelGGL(k_argmax_first, dim3(std::min<unsigned>(nblocks(kept * n), 1024u)), dim3(BLOCK), 0, e->stream, sl, kept * n, e->best_key.p);
-  hipLaunchKernelGGL(k_best_update, dim3(1), dim3(BLOCK), 0, e->stream, e->best_key.p, sl, sx, d, e->best_row.p);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e->ev_steps[b], e->stream));
-  if (seq >= 2) MCXCHK(sink_deliver(e, seq - 2));  // frees staging buffer b
-  HIPCHK(hipStreamWaitEvent(e->cstream, e->ev_steps[b], 0));
-  hipLaunchKernelGGL(k_rows_interleave, dim3(nblocks(kept * n * (d + 1))), dim3(BLOCK), 0, e->cstream, sx, sl,
-                     e->sink_stage[b].p, kept * n, d);
-  HIPCHK(hipGetLastError());
-  if (e->tfn || e->run_sink_text) {  // the size of the block's text (its two counting passes); sink_deliver places and copies it
-    const size_t count = kept * n * (size_t)(d + 1), nwg = (count + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(k_text_sizes, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
-                       (const float *)nullptr, count, d, e->sink_text_wg[b].p);
-    hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, e->cstream, e->sink_text_wg[b].p, nwg);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(e->sink_text_total[b].p, e->sink_text_wg[b].p + nwg, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->cstream));
-  }
-  if (!e->tfn)
-    HIPCHK(hipMemcpyAsync(e->sink_pin[b].p, e->sink_stage[b].p, kept * n * (d + 1) * sizeof(float), hipMemcpyDeviceToHost, e->cstream));
-  HIPCHK(hipEventRecord(e->ev_copy[b], e->cstream));
-  // the ring: block seq + SINK_RING - 1 will overwrite the slot of block seq - 1, whose copy is already waited for
-  // two blocks from now at the latest; with SINK_RING = 4 the host-side wait above is the only synchronisation
-  return MCX_OK;
-}
-
-static int sink_drain(mcx_engine *e, int nblocks_done)
-{
-  for (int seq = std::max(0, nblocks_done - 2); seq < nblocks_done; ++seq) MCXCHK(sink_deliver(e, seq));
-  return MCX_OK;
-}
-
-extern "C" int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_steps)
-{
-  if (!e || (fn && block_steps < 1)) return fail(MCX_ERR_INVALID, "bad arguments");
-  e->sfn = fn;
-  e->tfn = nullptr;
-  e->sctx = ctx;
-  e->sink_block = fn ? block_steps : 0;
-  return MCX_OK;
-}
-
-extern "C" int mcx_sink_text(mcx_engine *e, const char **text, size_t *nbytes)
-{
-  if (!e || !text || !nbytes) return fail(MCX_ERR_INVALID, "bad arguments");
-  if (!e->cb_text) return fail(MCX_ERR_INVALID, "no block text: call it from a sink callback of a run with MCX_OPT_SINK_TEXT");
-  *text = e->cb_text;
-  *nbytes = e->cb_text_bytes;
-  return MCX_OK;
-}
-
-extern "C" int mcx_set_text_sink(mcx_engine *e, mcx_text_sink_fn fn, void *ctx, int block_steps)
-{
-  if (!e || (fn && block_steps < 1)) return fail(MCX_ERR_INVALID, "bad arguments");
-  e->tfn = fn;
-  e->sfn = nullptr;
-  e->sctx = ctx;
-  e->sink_block = fn ? block_steps : 0;
   return MCX_OK;
 }
 
@@ -2129,7 +1059,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     case MCX_PLAN_PUBLISH: MCXCHK(publish(e, isamp)); break;
     case MCX_PLAN_GATHER_BEGIN: MCXCHK(exchange_begin(e)); break;  // src/mcpar.cc:127-140
     case MCX_PLAN_GATHER_WAIT:
-      if (isamp == nsamp && e->xchg_pending && (e->opt_async_tail == 2 || (e->opt_async_tail == 1 && e->xfn == rccl_exchange)) &&
+      if (isamp == nsamp && e->xchg_pending && (e->opt_async_tail == 2 || (e->opt_async_tail == 1 && exchange_is_library_rccl(e))) &&
           pi + 2 == plan.size() && plan[pi + 1].kind == MCX_PLAN_PUBLISH) {
         e->tail_publish = nsamp;  // finish_tail: the run's last gather stays in flight
         ++pi;
@@ -2493,60 +1423,6 @@ extern "C" int mcx_samples_copy(mcx_engine *e, int first_step, int nsteps, float
   return rc;
 }
 
-// rows on the device -> their text (mcx_text.hpp); sl == null: sx holds whole rows of d + 1 columns
-static int text_of_rows(const float *sx, const float *sl, size_t count, int d, DevBuf<unsigned long long> &wg, DevBuf<char> &dev,
-                        hipStream_t st, char *text, size_t capacity, size_t *nbytes)
-{
-  *nbytes = 0;
-  if (count == 0) return MCX_OK;
-  const size_t nwg = (count + BLOCK - 1) / BLOCK;
-  if (nwg > 0x7fffffffu) return fail(MCX_ERR_INVALID, "too many rows for one call: ask for fewer at a time");
-  MCXCHK(wg.alloc(nwg + 1));
-  hipLaunchKernelGGL(k_text_sizes, dim3((unsigned)nwg), dim3(BLOCK), 0, st, sx, sl, count, d, wg.p);
-  hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, st, wg.p, nwg);
-  HIPCHK(hipGetLastError());
-  unsigned long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, wg.p + nwg, sizeof total, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  *nbytes = (size_t)total;
-  if (!text) return MCX_OK;  // (the size only)
-  if ((size_t)total > capacity) return fail(MCX_ERR_INVALID, "text buffer too small: %llu bytes needed, %zu given", total, capacity);
-  MCXCHK(dev.alloc((size_t)total));
-  hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, st, sx, sl, count, d, (const unsigned long long *)wg.p, dev.p);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(text, dev.p, (size_t)total, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  return MCX_OK;
-}
-
-// The same rows as text: what MCout::output prints for them (src/mcout.cc:41-45), formatted on the device.
-extern "C" int mcx_samples_text(mcx_engine *e, int first_step, int nsteps, char *text, size_t capacity, size_t *nbytes)
-{
-  MCXCHK(enter(e));
-  if (!e || !nbytes || first_step < 0 || nsteps < 0 || (!text && capacity)) return fail(MCX_ERR_INVALID, "bad arguments");
-  if (first_step + nsteps > e->samp_steps) return fail(MCX_ERR_INVALID, "steps [%d,%d) not in the sample store (%d steps)", first_step, first_step + nsteps, e->samp_steps);
-  const size_t n = (size_t)e->nchain, d = (size_t)e->nparam;
-  return text_of_rows(e->samp_x.p + (size_t)first_step * n * d, e->samp_ly.p + (size_t)first_step * n, (size_t)nsteps * n * (d + 1),
-                      (int)d, e->text_wg, e->text_dev, e->stream, text, capacity, nbytes);
-}
-
-// any rows on the host (ncol columns each), e.g. what a sink received: uploaded, formatted, the text copied back
-extern "C" int mcx_format_rows(const float *rows, size_t nrows, int ncol, char *text, size_t capacity, size_t *nbytes)
-{
-  if (!nbytes || ncol < 1 || (nrows && !rows) || (!text && capacity)) return fail(MCX_ERR_INVALID, "bad arguments");
-  MCXCHK(need_device());
-  DevBuf<float> dr;
-  DevBuf<unsigned long long> wg;
-  DevBuf<char> dev;
-  const size_t count = nrows * (size_t)ncol;
-  int rc = dr.alloc(count);
-  if (rc == MCX_OK && count && hipMemcpy(dr.p, rows, count * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-    rc = fail(MCX_ERR_HIP, "hipMemcpy failed");
-  if (rc == MCX_OK) rc = text_of_rows(dr.p, nullptr, count, ncol - 1, wg, dev, nullptr, text, capacity, nbytes);
-  dr.release(); wg.release(); dev.release();
-  return rc;
-}
-
 extern "C" int mcx_samples_maxlike(mcx_engine *e, float *lmax, float *params)
 {
   MCXCHK(enter(e));
@@ -2699,3 +1575,4 @@ extern "C" int mcx_debug_normals(uint32_t seed, uint32_t stream, uint32_t t, uin
   d.release();
   return rc;
 }
+

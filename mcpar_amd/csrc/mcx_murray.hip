@@ -1,0 +1,270 @@
+// mcx_murray.hip -- MCPar::genRemote (src/mcpar.cc:315-451) on device buffers: the schedule of draws, all-pairs sweeps and
+// decisions over the kernels of mcx_remote.hpp, with the two exact screens that let a sweep skip rows (boxes of four
+// coordinates: mcx_remote.hpp; one direction: mcx_cull_proj.hpp).  A translation unit of its own: its kernels are the
+// largest of the library after the step kernels.
+#include "mcx_engine_internal.hpp"
+#include "mcx_remote.hpp"
+#include "mcx_cull_proj.hpp"
+
+static_assert(NACT_CULL_CELLS == CULL_NCOUNT, "mcx_engine::nact is sized for the screens' counter cells");
+
+constexpr int SROW_UNMASKED_MAX_CHAINS = 8192;  // see launch_sweep_exact
+
+// the all-pairs sweep over chains whose np is a power of two (d == DMAX): one or two chains per lane (SWEEP_CPL).
+// Workgroups of 512 / 1024 threads (fewer copies of a block's Gaussians staged through LDS) were measured on the
+// two-chain kernels: C3 R-murray 39.2 ms with 256 threads, 40.0 with 512, 49.4 with 1024; the 32-D mixture 43.4 / 42.7
+// / 42.7 -- the staging is not what a sweep waits for.
+template <int DM, bool SUMS>
+static void launch_sweep_exact(const float *x, const int *list, int cnt, const float *qpar, float *psum, float *pmax,
+                               int N, int own0, const unsigned long long *excl, int ngroups, int S, hipStream_t st)
+{
+  constexpr int CPL = SWEEP_CPL(DM);
+  if constexpr (DM == 16) {
+    // masked, or few chains: every wavefront reads its own rows through the scalar cache (no LDS, no barriers);
+    // unmasked over many chains the rows are better staged once per 512 chains (4.3 GB through L2 otherwise)
+    if (excl || cnt <= SROW_UNMASKED_MAX_CHAINS) {
+      hipLaunchKernelGGL((k_remote_sweep_srow16<SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), S), dim3(BLOCK), 0, st,
+                         x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_remote_sweep<DM, SUMS, true, CPL>), dim3(nblocks(((size_t)cnt + CPL - 1) / CPL), S), dim3(BLOCK), 0, st, x,
+                     list, cnt, qpar, psum, pmax, DM, N, own0, excl, ngroups);
+}
+
+// Sort the active chains by their spatial key, box every group of CULL_W of them and test every (group, Q_i)
+// pair (mcx_remote.hpp, "Exact exclusion of far Gaussians").  Leaves the sorted list in e->cull_sorted and the
+// masks in e->cull_excl ([group][words]); the pairs kept are added to the device counter behind e->nact.
+constexpr int CULL_MIN_CHAINS = 4096, CULL_MIN_GAUSSIANS = 4096;
+
+template <int DMAX>
+static int cull_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, hipStream_t st)
+{
+  const int d = e->nparam, N = e->tchains;
+  const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64;
+  // (the sums and the histogram are zero here: zeroed when allocated, and again by every k_cull_boxes)
+  hipLaunchKernelGGL(k_cull_stats, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p);
+  hipLaunchKernelGGL(k_cull_keys, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p,
+                     e->cull_keys.p, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
+                     e->cull_sorted.p);
+  const dim3 gb((unsigned)((ng + BLOCK / 64 - 1) / (BLOCK / 64)));
+  if (sums)
+    hipLaunchKernelGGL((k_cull_boxes<DMAX, true>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
+                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p, e->cull_stats.p, e->cull_hist.p);
+  else
+    hipLaunchKernelGGL((k_cull_boxes<DMAX, false>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
+                       (const float *)e->winvall.p, own0, e->cull_box.p, e->cull_lim.p, e->cull_stats.p, e->cull_hist.p);
+  const int gchunk = 64;  // (every chunk re-reads the Gaussians' key dimensions: 74 us per 65 536 x 65 536 test with 16, 35 with 64)
+  hipLaunchKernelGGL((k_cull_test<DMAX>), dim3((unsigned)((nw + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)((ng + gchunk - 1) / gchunk)),
+                     dim3(BLOCK), 0, st, (const float *)e->winvall.p, N, (const float *)e->cull_box.p, (const float *)e->cull_lim.p, ng, nact,
+                     gchunk, e->cull_excl.p, nw, reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
+  HIPCHK(hipGetLastError());
+  e->cnt.kernel_launches += 6;
+  return MCX_OK;
+}
+
+// The same with the chains sorted along ONE direction and every (group, Q_i) row bounded by Cauchy-Schwarz along it
+// (mcx_cull_proj.hpp): for chain clouds no box of a few coordinates separates.
+template <int DMAX>
+static int cull_prepare_proj(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, hipStream_t st)
+{
+  const int N = e->tchains;
+  const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64;
+  double *acc0 = e->proj_acc.p, *acc1 = e->proj_acc.p + PROJ_ACC;
+  // (acc0 and the histogram are zero here: zeroed when allocated, and again by every k_proj_groups; acc1 is zeroed now)
+  HIPCHK(hipMemsetAsync(acc1, 0, PROJ_ACC * sizeof(double), st));
+  hipLaunchKernelGGL((k_proj_moments<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc0, 0, acc0);
+  hipLaunchKernelGGL((k_proj_moments<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc0, 1, acc1);
+  hipLaunchKernelGGL((k_proj_keys<DMAX>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, (const double *)acc1,
+                     e->proj_p.p, e->cull_keys.p, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
+                     e->cull_sorted.p);
+  const dim3 gb((unsigned)((ng + BLOCK / 64 - 1) / (BLOCK / 64)));
+  if (sums)
+    hipLaunchKernelGGL((k_proj_groups<DMAX, true>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
+                       (const float *)e->winvall.p, own0, (const double *)e->proj_p.p, e->proj_lohi.p, e->cull_lim.p, acc0, e->cull_hist.p);
+  else
+    hipLaunchKernelGGL((k_proj_groups<DMAX, false>), gb, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact,
+                       (const float *)e->winvall.p, own0, (const double *)e->proj_p.p, e->proj_lohi.p, e->cull_lim.p, acc0, e->cull_hist.p);
+  const int gchunk = 64;
+  hipLaunchKernelGGL((k_proj_test<DMAX>), dim3((unsigned)((nw + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)((ng + gchunk - 1) / gchunk)),
+                     dim3(BLOCK), 0, st, (const float *)e->winvall.p, N, (const double *)acc1, (const double *)e->proj_lohi.p,
+                     (const float *)e->cull_lim.p, ng, nact, gchunk, e->cull_excl.p, nw,
+                     reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
+  HIPCHK(hipGetLastError());
+  e->cnt.kernel_launches += 8;
+  return MCX_OK;
+}
+
+// MCPar::genRemote on device buffers (src/mcpar.cc:315-451)
+int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
+                         float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
+{
+  const int n = e->nchain, d = e->nparam, N = e->tchains, dm = d <= 64 ? dmax_for(d) : 64;
+  const bool big = d > 64;  // chain vector in registers up to np = 64, re-read from memory above
+  const int S = (N + QBLOCK - 1) / QBLOCK;
+  if (!big && S > 65535)  // blocks of Gaussians go in gridDim.y
+    return fail(MCX_ERR_UNSUPPORTED, "Murray proposals over %d chains in all: at most %d", N, 65535 * QBLOCK);
+  hipStream_t st = e->stream;
+  ProfScope ps(e, MCX_K_REMOTE, (uint64_t)n);
+  if (!big) {
+    MCXCHK(e->psum.alloc((size_t)n * S));
+    MCXCHK(e->pmax.alloc((size_t)n * S));
+    MCXCHK(e->racpt.alloc((size_t)n));
+  }
+  // exclusion of far Gaussians: the two-chains-per-lane sweeps (np = 16, 32) over enough chains and Gaussians to
+  // pay for the sort and the tests (or whenever possible: MCX_OPT_CULL = 1, for the tests)
+  const bool cull_can = !big && d == dm && SWEEP_CPL(dm) == 2 && e->opt_cull != 0;
+  auto cull_now = [&](int na) { return cull_can && (e->opt_cull > 0 || (na >= CULL_MIN_CHAINS && N >= CULL_MIN_GAUSSIANS)); };
+  if (cull_can) {
+    const size_t ngmax = ((size_t)n + CULL_W - 1) / CULL_W, nw = ((size_t)N + 63) / 64;
+    const bool fresh = !e->cull_hist.p || !e->cull_stats.p;
+    MCXCHK(e->cull_keys.alloc((size_t)n)); MCXCHK(e->cull_hist.alloc(CULL_BINS)); MCXCHK(e->cull_sorted.alloc((size_t)n));
+    MCXCHK(e->cull_stats.alloc(2 * CULL_KD));
+    if (fresh) {  // (k_cull_boxes leaves them zero for the next sort)
+      HIPCHK(hipMemsetAsync(e->cull_stats.p, 0, 2 * CULL_KD * sizeof(float), st));
+      HIPCHK(hipMemsetAsync(e->cull_hist.p, 0, CULL_BINS * sizeof(unsigned), st));
+    } MCXCHK(e->cull_box.alloc(ngmax * 2 * CULL_KD)); MCXCHK(e->cull_lim.alloc(ngmax));
+    MCXCHK(e->cull_excl.alloc(ngmax * nw));
+    const bool fresh_p = !e->proj_acc.p;
+    MCXCHK(e->proj_acc.alloc(2 * PROJ_ACC)); MCXCHK(e->proj_p.alloc((size_t)n)); MCXCHK(e->proj_lohi.alloc(2 * ngmax));
+    if (fresh_p) HIPCHK(hipMemsetAsync(e->proj_acc.p, 0, 2 * PROJ_ACC * sizeof(double), st));
+  }
+  // which exact screen: boxes of four coordinates (the narrow per-chain Gaussians of C3's shape) or one direction (np = 32:
+  // the mixture of C5, whose components lie on a line no coordinate axis is close to)
+  const bool proj = e->opt_cull == 2 || (e->opt_cull < 0 && dm == 32);
+  HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
+  uint64_t evaluated_host = 0;  // pairs of the sweeps that ran without an exclusion test
+  // auto mode gives the test up where it excludes too little to pay for itself (the 32-D mixture: per-chain
+  // Gaussians too broad for any 128-chain box), per kind of sweep, and tries again every eighth call
+  constexpr double CULL_USELESS = 0.85;
+  bool cull_min = true, cull_sums = true;
+  if (e->opt_cull < 0) {
+    if (e->cull_skip[0] > 0) { cull_min = false; e->cull_skip[0]--; }
+    if (e->cull_skip[1] > 0) { cull_sums = false; e->cull_skip[1]--; }
+  }
+  uint64_t tested_min = 0, tested_sums = 0;
+  hipLaunchKernelGGL(k_remote_prep, dim3(nblocks((size_t)N * d)), dim3(BLOCK), 0, st, musigall,
+                     e->winvall.p, (size_t)N * d);
+  const int own0 = e->rank * e->nchain;
+  if (big) {
+    hipLaunchKernelGGL(k_remote_cmax_big, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, pvals, e->winvall.p,
+                       e->cmax.p, n, d, N);
+    evaluated_host += (uint64_t)n * (uint64_t)N;
+  } else {
+    const bool cull = cull_now(n) && cull_min;
+    if (cull) tested_min = (uint64_t)n * (uint64_t)N;
+    const int *order = nullptr;
+    const unsigned long long *excl = nullptr;
+    if (cull) {
+      if (proj) {
+        DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
+      } else {
+        DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
+      }
+      order = e->cull_sorted.p;
+      excl = e->cull_excl.p;
+    } else {
+      evaluated_host += (uint64_t)n * (uint64_t)N;
+    }
+    {
+      ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)n * (uint64_t)N);
+      if (d == dm) {
+        DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, false>(pvals, order, n, e->winvall.p, (float *)nullptr, e->pmax.p,
+                                                           N, own0, excl, (n + CULL_W - 1) / CULL_W, S, st)));
+      } else {
+        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
+                                             0, st, pvals, (const int *)nullptr, n, e->winvall.p,
+                                             (float *)nullptr, e->pmax.p, d, N, own0, (const unsigned long long *)nullptr, 0));
+      }
+    }
+    hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S, order);
+  }
+  HIPCHK(hipGetLastError());
+  e->cnt.remote_pairs += (uint64_t)n * (uint64_t)N;
+  int nact = n, pass = 0;
+  int *ain = nullptr, *aout = e->active0.p;
+  unsigned long long kept_min = 0, kept_sums = 0;
+  MCXCHK(e->h_nact.alloc(1 + 2 * CULL_NCOUNT));  // pinned: the per-pass read-back queues behind the pass's last kernel
+  while (nact > 0) {
+    // two survivor counters in turn: a pass counts in one and zeroes the other for the next pass (the first pass's
+    // draw zeroes its own) -- no fill between the passes
+    int *const cnt_here = e->nact.p + (pass & 1);
+    if (big) HIPCHK(hipMemsetAsync(cnt_here, 0, sizeof(int), st));
+    RemoteArgs a;
+    a.active_in = ain; a.nact = nact; a.active_out = aout; a.nact_out = cnt_here;
+    a.nact_zero = big ? nullptr : e->nact.p + ((pass + 1) & 1);
+    a.musigall = musigall; a.winv = e->winvall.p; a.cmax = e->cmax.p;
+    a.ptrial = ptrial; a.mutrial = mutrial; a.sigtrial = sigtrial; a.cfac = cfac;
+    a.racpt = e->racpt.p; a.psum = e->psum.p; a.pmax = e->pmax.p;
+    a.n = n; a.d = d; a.N = N; a.pass = pass; a.S = S;
+    a.g0 = (uint32_t)(e->rank * e->nchain); a.t = t; a.seed = e->seed;
+    if (big) {
+      hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
+      evaluated_host += (uint64_t)nact * (uint64_t)N;
+    } else {
+      // (later passes: the k_remote_decide that rejected a chain has drawn its next proposal already)
+      if (pass == 0) DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
+      const bool cull = cull_now(nact) && cull_sums;
+      const int *list = ain;
+      const unsigned long long *excl = nullptr;
+      if (cull) {  // the proposals have just been drawn: sort, box and test them
+        if (proj) {
+          DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
+        } else {
+          DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
+        }
+        list = e->cull_sorted.p;
+        excl = e->cull_excl.p;
+        a.active_in = list;  // positions of psum / pmax are positions of the sorted list
+      } else {
+        evaluated_host += (uint64_t)nact * (uint64_t)N;
+      }
+      {
+      ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)nact * (uint64_t)N);
+      if (d == dm) {
+        DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, true>(ptrial, list, nact, e->winvall.p, e->psum.p, e->pmax.p, N,
+                                                          -1, excl, (nact + CULL_W - 1) / CULL_W, S, st)));
+      } else {
+        DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, false>), dim3(nblocks((size_t)nact), S), dim3(BLOCK),
+                                             0, st, ptrial, (const int *)ain, nact, e->winvall.p,
+                                             e->psum.p, e->pmax.p, d, N, -1, (const unsigned long long *)nullptr, 0));
+      }
+      }
+      hipLaunchKernelGGL(k_remote_decide, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    e->cnt.remote_pairs += (uint64_t)nact * (uint64_t)N;
+    unsigned long long *back = e->h_nact.p;  // survivors (low word), cells of the pairs kept by the min-arg / sum tests so far
+    HIPCHK(hipMemcpyAsync(back, e->nact.p, (cull_can ? 1 + 2 * CULL_NCOUNT : 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const unsigned long long before = kept_sums;
+    const uint64_t pairs_now = (uint64_t)nact * (uint64_t)N;
+    nact = (int)(unsigned)((pass & 1) ? back[0] >> 32 : back[0] & 0xffffffffull);
+    if (cull_can) {
+      kept_min = kept_sums = 0;
+      for (int c = 0; c < CULL_NCOUNT; ++c) { kept_min += back[1 + c]; kept_sums += back[1 + CULL_NCOUNT + c]; }
+    }
+    if (pairs_now && kept_sums > before) {  // this pass was tested
+      tested_sums += pairs_now;
+      if (e->opt_cull < 0 && (double)(kept_sums - before) > CULL_USELESS * (double)pairs_now) cull_sums = false;
+    }
+    ain = aout;
+    aout = (aout == e->active0.p) ? e->active1.p : e->active0.p;
+    e->cnt.kernel_launches += (big || pass > 0) ? 1 : 2;  // (+1: the sweep's own scope)
+    ++pass;
+  }
+  e->cnt.remote_pairs_evaluated += evaluated_host + (uint64_t)kept_min + (uint64_t)kept_sums;
+  if (e->opt_cull < 0) {
+    if (tested_min && (double)kept_min > CULL_USELESS * (double)tested_min) e->cull_skip[0] = 7;
+    if (tested_sums && (double)kept_sums > CULL_USELESS * (double)tested_sums) e->cull_skip[1] = 7;
+  }
+  hipLaunchKernelGGL(k_square, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, sigtrial, (size_t)e->ntot);
+  HIPCHK(hipGetLastError());
+  if (npass_out) *npass_out = pass;
+  return MCX_OK;
+}
+
