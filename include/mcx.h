@@ -198,9 +198,10 @@ enum {
   MCX_OPT_CULL = 13,       /* Murray sweeps: exclude, exactly, the Gaussians that are too far from all 128 chains of a
                               wavefront to matter (the chains are sorted spatially first; same bits).  Two screens: boxes
                               of four coordinates (chains sorted in Z-order), or one direction -- the chains' first
-                              principal axis -- with a Cauchy-Schwarz bound along it (chains sorted along it).  -1 auto
-                              [default: np = 16 boxes, np = 32 one direction, >= 4096 chains still rejected, >= 4096
-                              Gaussians], 0 off, 1 boxes whenever np allows, 2 one direction whenever np allows */
+                              principal axis -- with a Cauchy-Schwarz bound along it (chains sorted along it; for targets
+                              stretched along a line: on BASELINE's shapes it excludes less than the boxes).  -1 auto
+                              [default: boxes, with np = 16 or 32, >= 4096 chains still rejected, >= 4096 Gaussians],
+                              0 off, 1 boxes whenever np allows, 2 one direction whenever np allows */
   MCX_OPT_BLOCKS_PER_LANE = 14, /* hot-path kernel: consecutive 4-parameter blocks of a chain held by one lane -- 1: one
                               (np/4 lanes per chain), 2 or 4: fewer lanes per chain, the per-chain work (acceptance test,
                               selects, counters) paid once per 2 / 4 blocks (same bits).  0 auto [default] */

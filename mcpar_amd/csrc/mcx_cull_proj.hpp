@@ -1,9 +1,12 @@
-// mcx_cull_proj.hpp -- exact exclusion of far Gaussians along ONE direction (round 4), for chain clouds that no box of
-// a few coordinates separates: the 32-D mixture of BASELINE's C5, whose components lie on a line that is diagonal to
-// every coordinate axis.  tools/murray_pair_screen_probe.py measured what an exact screen could drop there: after 30
-// main-loop steps 96 % of the (128 neighbouring chains, Q_i) rows hold no pair with arg <= 176, after 50 steps 59 %,
-// after 70 steps 21 %, after 100 steps 6 % (37 % of all PAIRS are alive by then) -- with the chains sorted along that
-// line; the boxes of mcx_remote.hpp, four coordinates wide, see none of it (they kept 0.9995 of the rows).
+// mcx_cull_proj.hpp -- exact exclusion of far Gaussians along ONE direction (round 4; MCX_OPT_CULL = 2, never chosen
+// automatically), for chain clouds stretched along a line that is diagonal to every coordinate axis, where the boxes of
+// mcx_remote.hpp -- four coordinates wide -- see nothing.  Written for the 32-D mixture of BASELINE's C5 after
+// tools/murray_pair_screen_probe.py had shown how many (128 neighbouring chains, Q_i) rows hold no pair with arg <= 176
+// early in a run (96 % after 30 main-loop steps, 59 % after 50, 21 % after 70, 6 % after 100) -- and measured useless
+// there: it keeps 0.999 of the pairs, like the boxes.  Those rows are dead because each chain is ~20 sigma away from a
+// still-narrow Gaussian in the 31 directions ACROSS the mixture's axis; along the axis -- the only direction in which
+// 128 chains can be neighbours -- the components overlap.  On C3's Rosenbrock shape it keeps 0.58 of the pairs where the
+// boxes keep 0.41.  Kept as an option because it is exact, tested, and the right screen for a target that IS a line.
 //
 // The bound.  For any direction e, Cauchy-Schwarz on the sweep's own sum (src/mcpar.cc:367-373):
 //     (sum_k e_k (mu_k - x_k))^2  <=  (sum_k (mu_k - x_k)^2 w_k) (sum_k e_k^2 / w_k)     i.e.  arg >= (e.mu - e.x)^2 / s,

@@ -221,8 +221,8 @@ struct mcx_engine {
   DevBuf<float> cull_stats, cull_box, cull_lim;
   DevBuf<double> proj_acc, proj_p, proj_lohi;  // mcx_cull_proj.hpp: two power iterations' sums, e.x per chain, [lo, hi] per group
   DevBuf<unsigned long long> cull_excl;
-  int opt_cull = -1;  // -1 auto (many chains, many Gaussians; np = 16: boxes, np = 32: along one direction), 0 off,
-                      // 1 boxes whenever the kernels allow, 2 one direction whenever they allow
+  int opt_cull = -1;  // -1 auto (boxes: many chains, many Gaussians, np = 16 or 32), 0 off, 1 boxes whenever the kernels
+                      // allow, 2 one direction (mcx_cull_proj.hpp) whenever they allow
   int cull_skip[2] = {0, 0};  // auto mode: genRemote calls for which the min-arg / sum sweeps go without the test,
                               // because it excluded too little last time it was tried (then it is tried again)
   DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev, zpre, upre, trash;

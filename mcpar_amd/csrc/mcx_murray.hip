@@ -133,9 +133,11 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     MCXCHK(e->proj_acc.alloc(2 * PROJ_ACC)); MCXCHK(e->proj_p.alloc((size_t)n)); MCXCHK(e->proj_lohi.alloc(2 * ngmax));
     if (fresh_p) HIPCHK(hipMemsetAsync(e->proj_acc.p, 0, 2 * PROJ_ACC * sizeof(double), st));
   }
-  // which exact screen: boxes of four coordinates (the narrow per-chain Gaussians of C3's shape) or one direction (np = 32:
-  // the mixture of C5, whose components lie on a line no coordinate axis is close to)
-  const bool proj = e->opt_cull == 2 || (e->opt_cull < 0 && dm == 32);
+  // which exact screen: boxes of four coordinates, or -- on request only -- one direction (mcx_cull_proj.hpp).  Measured
+  // in round 4: on C3's shape the direction keeps 0.58 of the pairs where the boxes keep 0.41; on C5's mixture it keeps
+  // 0.999 like the boxes -- there a pair is dead because the chain is far from the Gaussian in the 31 directions ACROSS
+  // the mixture's axis (the per-chain Gaussians are still narrow), which no bound for 128 chains at once can see.
+  const bool proj = e->opt_cull == 2;
   HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
   uint64_t evaluated_host = 0;  // pairs of the sweeps that ran without an exclusion test
   // auto mode gives the test up where it excludes too little to pay for itself (the 32-D mixture: per-chain
