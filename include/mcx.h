@@ -208,8 +208,11 @@ enum {
   MCX_OPT_ASYNC_TAIL = 15,   /* sharded runs on the library's RCCL exchange: mcx_run returns while the run's LAST all-gather
                               (which nothing inside the run reads) is still in flight on its side stream; whatever looks
                               at the gathered slots next -- mcx_get_musigall, the next run's first gather or publish,
-                              mcx_synchronize, mcx_destroy -- waits for it.  1 [default], 0: mcx_run waits itself, 2: also with a
-                              caller's exchange hook (whose MCX_XCHG_WAIT call then comes after mcx_run has returned) */
+                              mcx_synchronize, mcx_destroy -- waits for it.  1 [default]: on a communicator the library made
+                              itself (mcx_exchange_rccl_init); not on an adopted one, where the caller's own collectives
+                              could overtake the pending gather on some ranks.  0: mcx_run always waits itself.  2: also with
+                              an adopted communicator or a caller's exchange hook (whose MCX_XCHG_WAIT call then comes after
+                              mcx_run has returned): call mcx_synchronize before anything else touches the communicator */
   MCX_OPT_SINK_TEXT = 16,    /* a row sink (mcx_set_sink) also gets every block as text: inside the callback, mcx_sink_text
                               returns the characters MCout::output would print for the block's rows [default 0] */
   MCX_OPT_MEET_UNDER_GATHER = 17 /* small-n mode, sharded runs: may a launch with tuner meetings -- whose workgroups must all

@@ -1059,7 +1059,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     case MCX_PLAN_PUBLISH: MCXCHK(publish(e, isamp)); break;
     case MCX_PLAN_GATHER_BEGIN: MCXCHK(exchange_begin(e)); break;  // src/mcpar.cc:127-140
     case MCX_PLAN_GATHER_WAIT:
-      if (isamp == nsamp && e->xchg_pending && (e->opt_async_tail == 2 || (e->opt_async_tail == 1 && exchange_is_library_rccl(e))) &&
+      if (isamp == nsamp && e->xchg_pending && exchange_tail_may_stay_in_flight(e) &&
           pi + 2 == plan.size() && plan[pi + 1].kind == MCX_PLAN_PUBLISH) {
         e->tail_publish = nsamp;  // finish_tail: the run's last gather stays in flight
         ++pi;

@@ -354,7 +354,7 @@ MCXI int exchange_wait(mcx_engine *e);
 MCXI void xwait_collect(mcx_engine *e);
 MCXI int publish(mcx_engine *e, int steps_done);
 MCXI int finish_tail(mcx_engine *e);
-MCXI bool exchange_is_library_rccl(const mcx_engine *e);
+MCXI bool exchange_tail_may_stay_in_flight(const mcx_engine *e);
 
 // mcx_sink.hip
 MCXI int sink_block_done(mcx_engine *e, int done, int nsteps, int seq);

@@ -276,4 +276,11 @@ extern "C" int mcx_debug_fill_slot(mcx_engine *e, float value)
 }
 
 
-bool exchange_is_library_rccl(const mcx_engine *e) { return e->xfn == rccl_exchange; }
+// May mcx_run return with the run's last gather still in flight (MCX_OPT_ASYNC_TAIL)?  2: with any exchange; 1 (default):
+// with the library's RCCL exchange on a communicator of its OWN -- on one the caller handed over (mcx_exchange_rccl_adopt)
+// the caller may issue collectives of its own next, and their order against a gather still pending here could differ
+// from rank to rank: there mcx_run waits, as with a hook.
+bool exchange_tail_may_stay_in_flight(const mcx_engine *e)
+{
+  return e->opt_async_tail == 2 || (e->opt_async_tail == 1 && e->xfn == rccl_exchange && e->xcomm_owned);
+}

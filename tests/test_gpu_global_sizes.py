@@ -18,26 +18,32 @@ from test_gpu_configs import THREADS, mix_params, run_sharded_async, same_bits
 pytestmark = pytest.mark.gpu
 
 
-def oracle_sharded(d, n, nshards, nburn, nsamp, pl, vo, samples_on=()):
+def oracle_sharded(d, n, nshards, nburn, nsamp, pl, vo, samples_on=(), stride=1):
     eos = [O.Engine(d, n, nshards=nshards, shard=s, pl=pl, threads=THREADS) for s in range(nshards)]
     for s, e in enumerate(eos):
-        e.set_record(samples=s in samples_on, mask=False)
+        e.set_record(samples=s in samples_on, mask=False, stride=stride)
     t0 = time.time()
     O.run_all(eos, nsamp, nburn, [O.default_pinit(d, n, g0=s * n) for s in range(nshards)], vo)
     return eos, time.time() - t0
 
 
-@pytest.mark.parametrize("eager", [0, 1], ids=["lazy", "eager"])
-def test_c4_global_size_bit_exact(eager):
-    """C4 as benchmarked (R-local: pl = 1, nburn 500) for 100 main-loop steps: every shard's state, moments
-    and the gathered musigall (all 8 slots, 64 MiB) against the oracle; samples kept on shard 0 only."""
+@pytest.mark.parametrize("nsamp,eager", [(100, 0), (100, 1), (1000, 0)], ids=["100-lazy", "100-eager", "as-benchmarked-1000-lazy"])
+def test_c4_global_size_bit_exact(nsamp, eager):
+    """C4 (R-local: pl = 1, nburn 500) for 100 main-loop steps under both exchange schedules and -- as benchmarked --
+    for all 1000 (786 M chain-steps; the oracle needs half a minute of 16 cores): every shard's state, moments and the
+    gathered musigall (all 8 slots, 64 MiB) against the oracle; samples kept on shard 0 only (every 111th step of the
+    long job)."""
     from mcpar_amd import engine as E
-    d, n, nshards, nburn, nsamp = 16, 65536, 8, 500, 100
+    d, n, nshards, nburn = 16, 65536, 8, 500
+    stride = 111 if nsamp > 100 else 1
     vo, k1 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
-    eos, dt = oracle_sharded(d, n, nshards, nburn, nsamp, 1.0, vo, samples_on=(0,))
-    print("oracle C4 global: %.1f s" % dt)
-    egs, nbegin = run_sharded_async(d, n, nshards, nburn, nsamp, 1.0, eager,
-                                    setup=lambda s, e: e.set_option(E.OPT_SAMPLES, 1 if s == 0 else 0))
+    eos, dt = oracle_sharded(d, n, nshards, nburn, nsamp, 1.0, vo, samples_on=(0,), stride=stride)
+    print("oracle C4 global, nsamp %d: %.1f s" % (nsamp, dt))
+
+    def setup(s, e):
+        e.set_option(E.OPT_SAMPLES, 1 if s == 0 else 0)
+        e.set_option(E.OPT_SAMPLE_STRIDE, stride)
+    egs, nbegin = run_sharded_async(d, n, nshards, nburn, nsamp, 1.0, eager, setup=setup)
     for s in range(nshards):
         eo, eg = eos[s], egs[s]
         c = eg.counters
