@@ -31,9 +31,9 @@
 // the CUs and leave two kernels waiting for each other.  That is a courtesy, not the guarantee: a CU mask, a
 // partitioned device or a foreign kernel holding LDS can still keep workgroups out, so a meeting that is not
 // complete after RunArgs::meet_timeout ticks of the 100 MHz wall clock is ABANDONED -- the waiting owner marks
-// the meeting word, every workgroup leaves its phase loop at the next barrier, the launch ends without writing
-// state back, ctr[5] tells the host, and mcx_run repeats the run on the per-segment kernels.  Launches of
-// main-loop steps only have no meetings.
+// the meeting's leaves, every owner that sees the mark goes on with a count of zero and skips the meetings that
+// follow, the launch runs to its end WITHOUT writing state back, ctr[5] tells the host, and mcx_run repeats the run on
+// the per-segment kernels.  Launches of main-loop steps only have no meetings.
 #pragma once
 #include "mcx_device.hpp"
 
@@ -497,15 +497,10 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   // iteration p: owners run phase p, recorders digest phase p - 1, everybody else fills phase p + 1
   for (int p = 0; p < nphase + (REC ? 1 : 0); ++p) {
     const int buf = p & 1;
-#if MCX_MEET_VARIANT != 0
-    // a tuner meeting was abandoned during the last phase: every wavefront of the workgroup reads the same flag
-    // (written before the barrier that ended that phase) and leaves here.  Meetings happen in burn-in steps only:
-    // phases that follow a phase without any need no look.
-    if (p > 0 && (p - 1) * K < a.nburn && __hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-      aborted = true;
-      break;
-    }
-#endif
+    // (After an abandoned tuner meeting nobody leaves early: the owners go on with counts of zero, the other wavefronts
+    // never learn of it, the launch runs to its end and writes nothing back -- an abandoned launch is rare and its time
+    // is the host's to lose.  A look at the flag at the top of every phase cost BASELINE's C2 6 % of its kernel time:
+    // round 4's A/B, 0.2708 -> 0.2541 ms.)
     if (owner) {
       if (working && p < nphase) {
         const int tau0 = p * K;
