@@ -12,7 +12,7 @@ expects (all optional, per configuration C in c2 c3 c5 c3-murray):
 and writes
   profiles/<rnd>_bench_C.json, profiles/<rnd>_C_kernel_stats.csv,
   profiles/<rnd>_C_pmc_counters.json  (per kernel: mean per dispatch of every collected counter, second job only),
-  profiles/<rnd>_C_fused_kernel_counters.json  (what bench.py falls back to when it cannot run rocprofv3 itself).
+  profiles/<rnd>_C_fused_kernel_counters.json  (the hot kernel's own figures: its name as traced, HBM bytes, VALU issue).
 """
 import collections
 import csv
@@ -64,7 +64,8 @@ for cfg in ("c3", "c2", "c5", "c3-murray", "c3-rosen2fixed"):
                          "by bench.py itself; FETCH_SIZE/WRITE_SIZE in KB" % cfg, "kernels": table},
               open(os.path.join(pr, "%s_%s_pmc_counters.json" % (rnd, cfg)), "w"), indent=1)
     d = line["config"]["nparam"] if line else 16
-    match = (line or {}).get("roofline", {}).get("kernel_match") or "k_fused_fast<%d, true" % lpc_for(d)
+    # the kernel the bench line names -- the one that ran, as its own child kernel trace called it
+    match = ((line or {}).get("roofline") or {}).get("kernel") or "k_fused_fast<%d, true" % lpc_for(d)
     main = [k for k in table if match in k]
     if not main:
         continue
@@ -75,7 +76,7 @@ for cfg in ("c3", "c2", "c5", "c3-murray", "c3-rosen2fixed"):
         res["traffic_formula"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM)"
     if line and line.get("roofline") and line["roofline"].get("frac") is not None:
         res["valu_busy_fraction"] = line["roofline"]["frac"]  # as bench.py computed it live from these counters
-        res["valu_formula"] = line["roofline"].get("formula")
+        res["valu_formula"] = "DESIGN.md section 6, 'the bench line': roofline.frac"
         res["SQ_INSTS_VALU"] = m.get("SQ_INSTS_VALU", {}).get("mean")
     json.dump(res, open(os.path.join(pr, "%s_%s_fused_kernel_counters.json" % (rnd, cfg)), "w"), indent=1)
     print(cfg, {k: v for k, v in res.items() if k in ("traffic_bytes_per_launch", "valu_busy_fraction")})

@@ -1,7 +1,7 @@
 # On the GPU box: the bench lines, live PMC passes and rocprofv3 kernel stats that tools/collect_profiles.py turns into
 # profiles/<round>_*.  usage: bash tools/refresh_profiles.sh r02
 set -o pipefail
-RND=${1:-r02}
+RND=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 G=$R/gpurun_out
