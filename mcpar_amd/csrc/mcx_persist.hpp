@@ -197,6 +197,9 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
 {
   static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX, "hot-path likelihoods only");
   static_assert(BPL == 1 || BPL == 2 || BPL == 4, "one, two or four blocks per lane");
+#ifdef MCX_PERSIST_TRACE
+  const unsigned long long trace_t_entry = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ __attribute__((aligned(16))) float lds_means[LIK == LIK_MIX ? 8 * MAXD_LDS : 4];
   __shared__ float lds_logw[8];
@@ -492,8 +495,15 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   };
 
   __syncthreads();
+#ifdef MCX_PERSIST_TRACE
+  const unsigned long long trace_t_ready = __builtin_amdgcn_s_memtime();  // state loaded, L(pinit) evaluated
+#endif
   if (!owner) fill(0, 0);  // (nobody has anything to record yet: the recorders fill too)
   __syncthreads();
+#ifdef MCX_PERSIST_TRACE
+  // (the last traced phase slot of wavefront 0 carries the launch's own milestones: entry / ready / first fill done / end)
+  const unsigned long long trace_t_filled = __builtin_amdgcn_s_memtime();
+#endif
   // iteration p: owners run phase p, recorders digest phase p - 1, everybody else fills phase p + 1
   for (int p = 0; p < nphase + (REC ? 1 : 0); ++p) {
     const int buf = p & 1;
@@ -685,6 +695,15 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
 #endif
   }
 
+#ifdef MCX_PERSIST_TRACE
+  if (a.trace_clk && blockIdx.x < PTRACE_WG && threadIdx.x == 0) {
+    unsigned long long *tc = a.trace_clk + ((((size_t)blockIdx.x * PWAVES + 15) * PTRACE_PH) + (PTRACE_PH - 2)) * 2;
+    tc[0] = trace_t_entry;
+    tc[1] = trace_t_ready;
+    tc[2] = trace_t_filled;
+    tc[3] = __builtin_amdgcn_s_memtime();  // the phase loop is over
+  }
+#endif
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // (every iteration ends with a barrier: a flag raised during the last phase is visible here)
   if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) aborted = true;

@@ -79,14 +79,20 @@ def test_sink_rows_equal_the_store(d, n, nburn, nsamp, pl, block, stride, persis
     assert same_bits(eng.samples, ref.samples)
 
 
-@pytest.mark.parametrize("d,n,nburn,nsamp,pl,block,stride", [
-    (16, 512, 120, 103, 0.85, 10, 1),    # one-launch kernel with Murray steps between its launches
-    (16, 20000, 55, 45, 0.9, 6, 3),      # hot-path fused kernel, thinned, more blocks than ring slots
-    (6, 100, 30, 25, 0.8, 1, 1),         # generic kernel
+@pytest.mark.parametrize("d,n,nburn,nsamp,pl,block,stride,persist", [
+    (16, 512, 120, 103, 0.85, 10, 1, -1),   # small-n one-launch kernel, Murray steps in between, ragged last block
+    (16, 512, 120, 103, 0.85, 10, 2, -1),   # thinned
+    (8, 4096, 60, 64, 1.0, 7, 1, 0),        # per-segment kernels (pre-generated normals)
+    (16, 20000, 55, 40, 1.0, 16, 1, -1),    # hot-path fused kernel, more blocks than ring slots
+    (16, 20000, 55, 45, 0.9, 6, 3, -1),
+    (6, 100, 30, 25, 0.8, 1, 1, -1),        # generic kernel (d % 4 != 0), one step per block
+    (16, 300, 0, 9, 1.0, 100, 1, -1),       # block longer than the run, no burn-in
+    (16, 8192, 110, 64, 1.0, 16, 1, -1),    # one-launch kernel without recorders (two owner wavefronts per workgroup)
 ])
-def test_sink_rows_equal_the_oracle(d, n, nburn, nsamp, pl, block, stride):
+def test_sink_rows_equal_the_oracle(d, n, nburn, nsamp, pl, block, stride, persist):
     """The streamed rows against the CPU oracle's own sample store (not against the HIP engine's): the rows MCout
-    would hold after src/mcpar.cc:176-182, and its running maximum (src/mcout.cc:140-144)."""
+    would hold after src/mcpar.cc:176-182, and its running maximum (src/mcout.cc:140-144) -- over the whole matrix of
+    kernel paths, block lengths and thinning that test_sink_rows_equal_the_store covers."""
     import mcpar_amd as M
     from mcpar_amd import engine as E
     p = O.default_pinit(d, n)
@@ -98,6 +104,7 @@ def test_sink_rows_equal_the_oracle(d, n, nburn, nsamp, pl, block, stride):
     vg, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eng = M.Engine(d, n, pl=pl)
     eng.set_option(E.OPT_SAMPLE_STRIDE, stride)
+    eng.set_option(E.OPT_PERSIST, persist)
     got = []
 
     def sink(first, nsteps, rows):

@@ -48,6 +48,10 @@ def main():
     t = np.fromfile(dump, dtype=np.uint64).reshape(4, 16, 128, 2).astype(np.int64)
     nph = int((t[0, 0, :, 1] > 0).sum())
     print("d=%d n=%d bpl=%d: %d phases traced, blocks per lane %d" % (d, n, bpl, nph, e.counters["small_n_blocks_per_lane"]))
+    ms = t[1, 15, 126:128, :].reshape(4)  # the launch's milestones (wavefront 15's last two slots)
+    if ms[0] > 0:
+        print("workgroup 1: entry -> state ready %d clocks, first fill %d, phase loop %d (%.1f per phase)"
+              % (ms[1] - ms[0], ms[2] - ms[1], ms[3] - ms[2], (ms[3] - ms[2]) / max(nph, 1)))
     wg = 1
     end = t[wg, :, :nph, 1]          # after the barrier (same for all waves up to skew)
     work_end = t[wg, :, :nph, 0]
