@@ -113,6 +113,28 @@ def test_facade_mcout_equals_reference_mcout_on_two_ranks(tmp_path):
     assert seen >= 2
 
 
+@pytest.mark.skipif(not os.path.exists(MPIEXEC), reason="no MPI launcher in this image")
+@pytest.mark.parametrize("nranks", [1, 3])
+def test_text_written_side_by_side_equals_the_funnel(tmp_path, nranks):
+    """MCout::write_text both ways (tests/cpp/textfile_check.cc): through rank 0's stream, and every rank writing its own
+    share of every block into one file at an MPI_Exscan'd offset (MCout::text_file) -- the same bytes, in dump order"""
+    r = subprocess.run(["make", "-C", DRV, "../libmcpar_mpi.so", "MPI=" + MPI], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("MPI build of the facade not available: " + r.stderr[-300:])
+    exe = str(tmp_path / "textfile_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-DMCX_WITH_MPI", "-DMPICH_SKIP_MPICXX", "-DOMPI_SKIP_MPICXX",
+                           "-I", os.path.join(ROOT, "include", "mcpar"), "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(MPI, "include"), os.path.join(ROOT, "tests", "cpp", "textfile_check.cc"),
+                           "-o", exe, "-L", os.path.join(ROOT, "mcpar_amd"), "-lmcpar_mpi", "-lmcx",
+                           os.path.join(MPI, "lib", "libmpi.so"), "-Wl,-rpath," + os.path.join(ROOT, "mcpar_amd"),
+                           "-Wl,-rpath,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath," + os.path.join(MPI, "lib")])
+    out = subprocess.run([MPIEXEC, "-n", str(nranks), exe, str(tmp_path / "side_by_side.txt")], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0] == "funnel in dump order" and lines[1].startswith("same ") and lines[1].endswith("%d ranks" % nranks), out.stdout
+
+
 def test_percent_g_is_the_reference_row_format():
     """tests/test_gpu_facade.py formats oracle rows with '%g  ' to build its expectations; the reference's own
     text for the golden rows says that this is the format of src/mcout.cc:41-45 (nan, -inf, -0, 1e-05, 1e+10, ...)."""
