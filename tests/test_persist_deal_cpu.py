@@ -62,3 +62,17 @@ def test_the_owners_simd_gets_less():
         per_simd[w % 4] += sum(2 if v >> 14 == 0 else (1 if v >> 14 == 3 else 0) for v in lst)
     assert per_simd[0] < per_simd[1] <= max(per_simd[2], per_simd[3]), per_simd
     assert sum(per_simd) == k * 2
+
+
+@pytest.mark.parametrize("lpc2,bpl,own,want_rec,want_k", [
+    (2, 1, 1, 1, 32),   # C2: one set of chains per workgroup -> recorders, 32-step phases
+    (4, 1, 1, 1, 32),   # 4096 x 16-D
+    (4, 1, 2, 0, 32),   # 8192 x 16-D, the strong-scaled shape: two owners, no recorders
+    (4, 1, 3, 0, 20),   # 12288 x 16-D
+    (2, 2, 2, 0, 16),   # 16384 x 16-D with two blocks per lane
+    (2, 2, 3, 0, 16),   # 24576 x 16-D
+])
+def test_configuration_table(lpc2, bpl, own, want_rec, want_k):
+    """the measured configuration rules of the one-launch kernel (EXPERIMENTS.md) as the library applies them"""
+    rec, k, tab = deal(lpc2, bpl, own)
+    assert (rec, k) == (want_rec, want_k)
