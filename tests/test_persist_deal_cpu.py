@@ -70,7 +70,7 @@ def test_the_owners_simd_gets_less():
     (4, 1, 2, 0, 32),   # 8192 x 16-D, the strong-scaled shape: two owners, no recorders
     (4, 1, 3, 0, 20),   # 12288 x 16-D
     (2, 2, 2, 0, 16),   # 16384 x 16-D with two blocks per lane
-    (2, 2, 3, 0, 16),   # 24576 x 16-D
+    (2, 2, 3, 0, 10),   # 24576 x 16-D: what the LDS double buffers hold
 ])
 def test_configuration_table(lpc2, bpl, own, want_rec, want_k):
     """the measured configuration rules of the one-launch kernel (EXPERIMENTS.md) as the library applies them"""
