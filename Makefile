@@ -19,7 +19,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 # what only one translation unit sees
-$(CSRC)/mcx_murray.o: $(CSRC)/mcx_remote.hpp $(CSRC)/mcx_cull_proj.hpp
+$(CSRC)/mcx_murray.o: $(CSRC)/mcx_remote.hpp $(CSRC)/mcx_cull_proj.hpp $(CSRC)/mcx_screen.hpp
 $(CSRC)/mcx_sink.o: $(CSRC)/mcx_text.hpp $(CSRC)/fmt_g6.hpp
 $(CSRC)/mcx_k_fastb.o: $(CSRC)/mcx_fastb.hpp
 

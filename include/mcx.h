@@ -196,12 +196,15 @@ enum {
                               keeps to the per-segment kernels for 16 runs, then tries again) [default 50: a healthy
                               launch is 0.3-1.3 ms long and its meetings wait microseconds] */
   MCX_OPT_CULL = 13,       /* Murray sweeps: exclude, exactly, the Gaussians that are too far from all 128 chains of a
-                              wavefront to matter (the chains are sorted spatially first; same bits).  Two screens: boxes
-                              of four coordinates (chains sorted in Z-order), or one direction -- the chains' first
-                              principal axis -- with a Cauchy-Schwarz bound along it (chains sorted along it; for targets
-                              stretched along a line: on BASELINE's shapes it excludes less than the boxes).  -1 auto
-                              [default: boxes, with np = 16 or 32, >= 4096 chains still rejected, >= 4096 Gaussians],
-                              0 off, 1 boxes whenever np allows, 2 one direction whenever np allows */
+                              wavefront to matter (the chains are sorted spatially first; same bits).  Three screens:
+                              (3) a lower bound of arg for every (chain, Gaussian) PAIR on the matrix cores -- a bf16
+                              product with its rounding bounded rigorously, reduced over the 128 chains
+                              (mcx_screen.hpp): leaves 6 % of C3-murray's pairs and 54 % of C5's; (1) boxes of four
+                              coordinates around the 128 chains (33 % / 100 %); (2) one direction -- the chains' first
+                              principal axis -- with a Cauchy-Schwarz bound along it (for targets stretched along a
+                              line; on BASELINE's shapes it excludes less than the boxes).  -1 auto [default: the
+                              per-pair bound, with np = 16 or 32, >= 4096 chains still rejected, >= 4096 Gaussians],
+                              0 off, 1 / 2 / 3: that screen whenever np allows */
   MCX_OPT_BLOCKS_PER_LANE = 14, /* hot-path kernel: consecutive 4-parameter blocks of a chain held by one lane -- 1: one
                               (np/4 lanes per chain), 2 or 4: fewer lanes per chain, the per-chain work (acceptance test,
                               selects, counters) paid once per 2 / 4 blocks (same bits).  0 auto [default] */

@@ -221,8 +221,10 @@ struct mcx_engine {
   DevBuf<float> cull_stats, cull_box, cull_lim;
   DevBuf<double> proj_acc, proj_p, proj_lohi;  // mcx_cull_proj.hpp: two power iterations' sums, e.x per chain, [lo, hi] per group
   DevBuf<unsigned long long> cull_excl;
-  int opt_cull = -1;  // -1 auto (boxes: many chains, many Gaussians, np = 16 or 32), 0 off, 1 boxes whenever the kernels
-                      // allow, 2 one direction (mcx_cull_proj.hpp) whenever they allow
+  DevBuf<unsigned short> scr_a, scr_b;  // mcx_screen.hpp: A' per position of the sorted list, B' per Gaussian (bf16)
+  DevBuf<float> scr_centre;
+  int opt_cull = -1;  // -1 auto (the per-pair bound: many chains, many Gaussians, np = 16 or 32), 0 off, whenever the kernels
+                      // allow: 1 boxes, 2 one direction (mcx_cull_proj.hpp), 3 the per-pair bound (mcx_screen.hpp)
   int cull_skip[2] = {0, 0};  // auto mode: genRemote calls for which the min-arg / sum sweeps go without the test,
                               // because it excluded too little last time it was tried (then it is tried again)
   DevBuf<float> samp_x, samp_ly, winv_tab, psum, pmax, racpt, pinit_dev, zpre, upre, trash;

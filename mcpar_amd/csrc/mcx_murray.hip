@@ -5,31 +5,42 @@
 #include "mcx_engine_internal.hpp"
 #include "mcx_remote.hpp"
 #include "mcx_cull_proj.hpp"
+#include "mcx_screen.hpp"
 
 static_assert(NACT_CULL_CELLS == CULL_NCOUNT, "mcx_engine::nact is sized for the screens' counter cells");
 
 constexpr int SROW_UNMASKED_MAX_CHAINS = 8192;  // see launch_sweep_exact
+constexpr int SROW_MAX_BLOCKS_PER_WAVE = 8;
 
 // the all-pairs sweep over chains whose np is a power of two (d == DMAX): one or two chains per lane (SWEEP_CPL).
 // Workgroups of 512 / 1024 threads (fewer copies of a block's Gaussians staged through LDS) were measured on the
 // two-chain kernels: C3 R-murray 39.2 ms with 256 threads, 40.0 with 512, 49.4 with 1024; the 32-D mixture 43.4 / 42.7
 // / 42.7 -- the staging is not what a sweep waits for.
+// Returns the number of entries per chain the sweep leaves in pmax for k_remote_cmax_combine (!SUMS): the blocks, or
+// fewer where a wavefront carries its minimum through several of them.
 template <int DM, bool SUMS>
-static void launch_sweep_exact(const float *x, const int *list, int cnt, const float *qpar, float *psum, float *pmax,
-                               int N, int own0, const unsigned long long *excl, int ngroups, int S, hipStream_t st)
+static int launch_sweep_exact(const float *x, const int *list, int cnt, const float *qpar, float *psum, float *pmax,
+                              int N, int own0, const unsigned long long *excl, int ngroups, int S, hipStream_t st)
 {
   constexpr int CPL = SWEEP_CPL(DM);
   if constexpr (DM == 16) {
     // masked, or few chains: every wavefront reads its own rows through the scalar cache (no LDS, no barriers);
     // unmasked over many chains the rows are better staged once per 512 chains (4.3 GB through L2 otherwise)
     if (excl || cnt <= SROW_UNMASKED_MAX_CHAINS) {
-      hipLaunchKernelGGL((k_remote_sweep_srow16<SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), S), dim3(BLOCK), 0, st,
-                         x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups);
-      return;
+      // masked min-arg sweep: several blocks per wavefront while 8192 wavefronts (eight per SIMD) remain -- 310 -> 72 us
+      // per 65 536 x 65 536 sweep at 1 % of the rows.  The sum sweep has no own-Gaussian args to redo per block and
+      // its surviving rows are many more in some groups than in others: eight blocks per wavefront 508 -> 600 us.
+      int bpw = (excl && !SUMS) ? (int)(((long long)ngroups * S) / 8192) : 1;
+      bpw = bpw < 1 ? 1 : (bpw > SROW_MAX_BLOCKS_PER_WAVE ? SROW_MAX_BLOCKS_PER_WAVE : bpw);
+      const int gy = (S + bpw - 1) / bpw;
+      hipLaunchKernelGGL((k_remote_sweep_srow16<SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), gy), dim3(BLOCK), 0, st,
+                         x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups, bpw);
+      return SUMS ? S : gy;
     }
   }
   hipLaunchKernelGGL((k_remote_sweep<DM, SUMS, true, CPL>), dim3(nblocks(((size_t)cnt + CPL - 1) / CPL), S), dim3(BLOCK), 0, st, x,
                      list, cnt, qpar, psum, pmax, DM, N, own0, excl, ngroups);
+  return S;
 }
 
 // Sort the active chains by their spatial key, box every group of CULL_W of them and test every (group, Q_i)
@@ -99,6 +110,45 @@ static int cull_prepare_proj(mcx_engine *e, const float *xrows, const int *ain, 
   return MCX_OK;
 }
 
+// The same sort, then the per-pair bound on the matrix cores (mcx_screen.hpp) in place of the boxes.  `fresh_q`: the
+// Gaussians' side (centre, B') has not been built for this genRemote call yet.
+template <int DMAX>
+static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, bool *fresh_q, hipStream_t st)
+{
+  const int d = e->nparam, N = e->tchains;
+  const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64, nblk = (N + SCR_BLK - 1) / SCR_BLK;
+  if (*fresh_q) {
+    hipLaunchKernelGGL(k_screen_centre, dim3(1), dim3(1024), 0, st, (const float *)e->winvall.p, N, d, e->scr_centre.p);
+    hipLaunchKernelGGL((k_screen_prep_q<DMAX>), dim3(nblocks((size_t)nblk * SCR_BLK)), dim3(BLOCK), 0, st, (const float *)e->winvall.p, N,
+                       nblk * SCR_BLK, (const float *)e->scr_centre.p, e->scr_b.p);
+    e->cnt.kernel_launches += 2;
+    *fresh_q = false;
+  }
+  hipLaunchKernelGGL(k_cull_stats, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p);
+  hipLaunchKernelGGL(k_cull_keys, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p,
+                     e->cull_keys.p, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
+  hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
+                     e->cull_sorted.p);
+  const dim3 gp(nblocks((size_t)ng * CULL_W));
+  if (sums)
+    hipLaunchKernelGGL((k_screen_prep_x<DMAX, true>), gp, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact, ng * CULL_W,
+                       (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p);
+  else
+    hipLaunchKernelGGL((k_screen_prep_x<DMAX, false>), gp, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact, ng * CULL_W,
+                       (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p);
+  // enough workgroups for every CU to hold several: the Gaussians' blocks are cut into chunks
+  const int gx = (ng + SCR_WAVES - 1) / SCR_WAVES;
+  int bchunk = (int)(((long long)gx * nblk + 4095) / 4096);
+  if (bchunk < 1) bchunk = 1;
+  hipLaunchKernelGGL((k_screen_gemm<DMAX>), dim3((unsigned)gx, (unsigned)((nblk + bchunk - 1) / bchunk)), dim3(SCR_WAVES * 64), 0, st,
+                     (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, nact, N, ng, bchunk, e->cull_excl.p, nw,
+                     reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
+  HIPCHK(hipGetLastError());
+  e->cnt.kernel_launches += 6;
+  return MCX_OK;
+}
+
 // MCPar::genRemote on device buffers (src/mcpar.cc:315-451)
 int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *musigall,
                          float *ptrial, float *cfac, float *mutrial, float *sigtrial, int *npass_out)
@@ -132,12 +182,16 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     const bool fresh_p = !e->proj_acc.p;
     MCXCHK(e->proj_acc.alloc(2 * PROJ_ACC)); MCXCHK(e->proj_p.alloc((size_t)n)); MCXCHK(e->proj_lohi.alloc(2 * ngmax));
     if (fresh_p) HIPCHK(hipMemsetAsync(e->proj_acc.p, 0, 2 * PROJ_ACC * sizeof(double), st));
+    MCXCHK(e->scr_centre.alloc(64)); MCXCHK(e->scr_a.alloc(ngmax * CULL_W * scr_k(dm)));
+    MCXCHK(e->scr_b.alloc((((size_t)N + SCR_BLK - 1) / SCR_BLK) * SCR_BLK * scr_k(dm)));
   }
   // which exact screen: boxes of four coordinates, or -- on request only -- one direction (mcx_cull_proj.hpp).  Measured
   // in round 4: on C3's shape the direction keeps 0.58 of the pairs where the boxes keep 0.41; on C5's mixture it keeps
   // 0.999 like the boxes -- there a pair is dead because the chain is far from the Gaussian in the 31 directions ACROSS
   // the mixture's axis (the per-chain Gaussians are still narrow), which no bound for 128 chains at once can see.
   const bool proj = e->opt_cull == 2;
+  const bool gemm = e->opt_cull == 3 || e->opt_cull < 0;
+  bool fresh_q = true;
   HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
   uint64_t evaluated_host = 0;  // pairs of the sweeps that ran without an exclusion test
   // auto mode gives the test up where it excludes too little to pay for itself (the 32-D mixture: per-chain
@@ -161,8 +215,11 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     if (cull) tested_min = (uint64_t)n * (uint64_t)N;
     const int *order = nullptr;
     const unsigned long long *excl = nullptr;
+    int S_min = S;  // entries per chain the min-arg sweep leaves for the combining kernel
     if (cull) {
-      if (proj) {
+      if (gemm) {
+        DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, &fresh_q, st))));
+      } else if (proj) {
         DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
       } else {
         DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
@@ -175,15 +232,15 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     {
       ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)n * (uint64_t)N);
       if (d == dm) {
-        DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, false>(pvals, order, n, e->winvall.p, (float *)nullptr, e->pmax.p,
-                                                           N, own0, excl, (n + CULL_W - 1) / CULL_W, S, st)));
+        DISPATCH_DMAX(dm, (S_min = launch_sweep_exact<DMAX_, false>(pvals, order, n, e->winvall.p, (float *)nullptr, e->pmax.p,
+                                                                   N, own0, excl, (n + CULL_W - 1) / CULL_W, S, st)));
       } else {
         DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, false, false>), dim3(nblocks((size_t)n), S), dim3(BLOCK),
                                              0, st, pvals, (const int *)nullptr, n, e->winvall.p,
                                              (float *)nullptr, e->pmax.p, d, N, own0, (const unsigned long long *)nullptr, 0));
       }
     }
-    hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S, order);
+    hipLaunchKernelGGL(k_remote_cmax_combine, dim3(nblocks((size_t)n)), dim3(BLOCK), 0, st, e->pmax.p, e->cmax.p, n, S_min, order);
   }
   HIPCHK(hipGetLastError());
   e->cnt.remote_pairs += (uint64_t)n * (uint64_t)N;
@@ -214,7 +271,9 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       const int *list = ain;
       const unsigned long long *excl = nullptr;
       if (cull) {  // the proposals have just been drawn: sort, box and test them
-        if (proj) {
+        if (gemm) {
+          DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, &fresh_q, st))));
+        } else if (proj) {
           DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
         } else {
           DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));

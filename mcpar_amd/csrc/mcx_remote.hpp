@@ -409,13 +409,19 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow16(const float *__re
                                                                int nact, const float *__restrict__ qpar,
                                                                float *__restrict__ psum, float *__restrict__ pmax, int N,
                                                                int own0, const unsigned long long *__restrict__ excl,
-                                                               int ngroups)
+                                                               int ngroups, int bpw)
 {
   constexpr int DMAX = 16, G = 4;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
   const int g = (int)blockIdx.x * (BLOCK / 64) + wv;
   if (g >= ngroups) return;  // (no barriers in this kernel)
-  const int sb = blockIdx.y;
+  // `bpw` consecutive blocks per wavefront: what a wavefront does before its first row -- its chains' vectors, their
+  // args against their own Gaussians -- is 1-2 GB through L2 per 65 536 x 65 536 sweep when every (group, block) pair
+  // does it anew, more than the rows the masks leave.  SUMS: one partial sum per block as ever (the summation order,
+  // DESIGN.md S3.5); !SUMS: the minimum runs on through the wavefront's blocks and is stored once, at "block"
+  // blockIdx.y (the combining kernel takes a minimum: fewer entries, the same result).
+  const int nsb = (N + QBLOCK - 1) / QBLOCK;
+  const int sb0 = (int)blockIdx.y * bpw, sb1 = sb0 + bpw < nsb ? sb0 + bpw : nsb;
   int pos[2], jj[2];
   bool valid[2];
 #pragma unroll
@@ -455,6 +461,8 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow16(const float *__re
       }
   }
   const unsigned long long everyone = __ballot(true), no_a = __ballot(!valid[0]), no_b = __ballot(!valid[1]);
+  for (int sb = sb0; sb < sb1; ++sb) {
+  if (SUMS) { part = f32x2{0.0f, 0.0f}; m = f32x2{0.0f, 0.0f}; }
   const int q0 = sb * QBLOCK;
   // the block's four mask words (bits beyond N are clear: k_cull_test), as scalars
   unsigned long long words[QBLOCK / 64];
@@ -549,17 +557,21 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow16(const float *__re
       if (r < 0) break;
     }
   }
+  if (SUMS) {
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
-    if (valid[c]) {
-      const size_t o = (size_t)sb * nact + pos[c];
-      if (SUMS) {
+    for (int c = 0; c < 2; ++c)
+      if (valid[c]) {
+        const size_t o = (size_t)sb * nact + pos[c];
         psum[o] = c == 0 ? part.x : part.y;
         pmax[o] = c == 0 ? m.x : m.y;
-      } else {
-        pmax[o] = c == 0 ? amin.x : amin.y;
       }
-    }
+  }
+  }
+  if (!SUMS) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (valid[c]) pmax[(size_t)blockIdx.y * nact + pos[c]] = c == 0 ? amin.x : amin.y;
+  }
 }
 
 // numerator of cfac: max_i Q_i(pvals_j) = exp(-min_i arg_i / 2) (src/mcpar.cc:421-437); does not depend on the pass

@@ -161,6 +161,10 @@ def test_own_gather_in_flight_and_a_launch_with_meetings(occupy, under):
     def make_hook(s):
         def hook(phase, ptr, slot, shard, ns, stream):
             if phase == E.XCHG_BEGIN:
+                # (both shards' earlier launches are over before the foreign kernel starts: the other shard's launch
+                # with meetings must not find it in its way by being a little behind -- it only waits for its OWN gather)
+                hip.hipDeviceSynchronize()
+                bar.wait(timeout=60)
                 if s == 0:  # (one foreign kernel per gather is enough: a quarter of the chip for 60 ms)
                     held[s] = start(occupy, ncu // 4, 60.0)
                 return 0

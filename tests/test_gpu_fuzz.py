@@ -48,7 +48,7 @@ def one_case(rng, idx):
     persist = int(rng.choice([-1, -1, 0, 1]))   # small-n mode: one launch per run / per-segment kernels
     split = int(rng.choice([-1, -1, 0, 1]))     # (persist off:) pre-generated normals or generated in the step kernel
     sink = int(rng.choice([0, 0, 1, 3, 10, 64]))  # > 0: samples streamed through the sink in blocks of that many steps
-    cull = int(rng.choice([-1, -1, 0, 1, 2]))   # exact exclusion of far Gaussians in the Murray sweeps: auto / off / boxes / one direction
+    cull = int(rng.choice([-1, -1, 0, 1, 2, 3]))   # exact exclusion of far Gaussians in the Murray sweeps: auto / off / boxes / one direction / per-pair bound
     bpl = int(rng.choice([0, 0, 1, 2, 4]))      # parameter blocks per lane of the hot-path kernel (0 = automatic)
     desc = dict(idx=idx, kind=kind, d=d, n=n, nburn=nburn, nsamp=nsamp, pl=pl, sync=sync, K=K, fullcov=incov is not None,
                 fuse=fuse, mask=mask, maxseg=maxseg, stride=stride, persist=persist, split=split, sink=sink, cull=cull, bpl=bpl)

@@ -1,6 +1,7 @@
 """Exact exclusion of far Gaussians in the Murray sweeps (mcx_remote.hpp, k_cull_*): sorting the active chains,
 boxing every wavefront's 128 chains and skipping the Q_i that are provably too far from all of them must not
-change a single bit -- with the exclusion forced on (MCX_OPT_CULL = 1: boxes; 2: one direction, mcx_cull_proj.hpp), off
+change a single bit -- with the exclusion forced on (MCX_OPT_CULL = 1: boxes; 2: one direction, mcx_cull_proj.hpp;
+3: the per-pair bound on the matrix cores, mcx_screen.hpp), off
 (0) and automatic (-1), against the
 oracle, which knows nothing of it -- and must actually exclude most pairs on BASELINE-shaped states."""
 import numpy as np
@@ -38,7 +39,7 @@ def test_gen_remote_same_bits_with_and_without_exclusion(d, n, nshards):
     pv[::7] = ms[own][::7, :, 0]
     eo = O.Engine(d, n, nshards=nshards, shard=shard, threads=THREADS)
     ro = eo.gen_remote(41, pv, ms)
-    for mode in (1, 2, 0, -1):  # boxes / one direction (mcx_cull_proj.hpp) / off / automatic
+    for mode in (1, 2, 3, 0, -1):  # boxes / one direction / per-pair bound (mcx_screen.hpp) / off / automatic
         eg = M.Engine(d, n, nshards=nshards, shard=shard)
         eg.set_option(E.OPT_CULL, mode)
         rg = eg.gen_remote(41, pv, ms)
@@ -67,7 +68,7 @@ def test_whole_murray_job_same_bits_and_most_pairs_excluded(cfg):
     assert eo.remote_steps >= 3
     vg, k2 = M.make_vlfunc(*spec_g)
     frac = {}
-    for mode in (1, 2, 0):
+    for mode in (1, 2, 3, 0):
         eg = M.Engine(d, n, pl=pl)
         eg.set_option(E.OPT_CULL, mode)
         eg.run(nsamp, nburn, p, vg)
@@ -79,10 +80,12 @@ def test_whole_murray_job_same_bits_and_most_pairs_excluded(cfg):
             assert same_bits(getattr(eg, name), getattr(eo, name)), (mode, name)
         frac[mode] = c["remote_pairs_evaluated"] / float(c["remote_pairs"])
         eg.close()
-    print("pairs left after the exclusion test: boxes %.3f, one direction %.3f of all (%s)" % (frac[1], frac[2], cfg))
+    print("pairs left after the exclusion test: boxes %.3f, one direction %.3f, per-pair bound %.3f of all (%s)"
+          % (frac[1], frac[2], frac[3], cfg))
     assert frac[0] == 1.0 and frac[1] <= 1.0 and frac[2] <= 1.0
-    if cfg == "rosen16":  # (the 32-D mixture: pairs are dead across the mixture's axis, which no bound for 128 chains sees)
-        assert frac[1] < 0.8 and frac[2] < 0.8
+    if cfg == "rosen16":  # (the 32-D mixture: pairs are dead across the mixture's axis, which no bound for 128 chains sees
+        assert frac[1] < 0.8 and frac[2] < 0.8  # -- the per-pair bound does)
+    assert frac[3] < 0.6
 
 
 def test_exclusion_keeps_nan_and_degenerate_inputs_identical():
@@ -98,7 +101,7 @@ def test_exclusion_keeps_nan_and_degenerate_inputs_identical():
     pv[200] = 50.0
     eo = O.Engine(d, n, threads=THREADS)
     ro = eo.gen_remote(3, pv, ms)
-    for mode in (1, 2, 0):
+    for mode in (1, 2, 3, 0):
         eg = M.Engine(d, n)
         eg.set_option(E.OPT_CULL, mode)
         rg = eg.gen_remote(3, pv, ms)
