@@ -344,6 +344,12 @@ int mcx_debug_copy_bandwidth(size_t bytes, int reps, double *gbps);
  * wavefronts per workgroup of lpc2 lanes per chain x bpl blocks per lane, and who generates what: tab[3][16][24] item
  * codes (0xffffffff ends a wavefront's list; kind << 14 | step pair << 4 | (owner, block)) */
 int mcx_debug_persist_deal(int lpc2, int bpl, int own, int *rec, int *ksteps, uint32_t *tab, int max_words);
+/* the per-pair screen of the Murray sweeps alone (mcx_screen.hpp; np = 16 or 32), for tests: nact chains x[nact][d], in
+ * groups of 128 as given, against N Gaussians musig[N][d][2] = (mu, sig2); sums != 0: the sum sweeps' bound (176), else
+ * the min-arg sweep's (chain j's own Gaussian is own0 + j).  masks[(N + 63) / 64][(nact + 127) / 128]: bit b of word w
+ * for group g set = Gaussian 64 w + b may matter to some chain of the group. */
+int mcx_debug_murray_screen(int d, int nact, int N, const float *x, const float *musig, int own0, int sums,
+                            unsigned long long *masks);
 /* device evaluation of the arithmetic primitives for bit-exactness tests:
  * what = 0 logf(bits), 1 expf(bits), 2 sin(2 pi w/2^32), 3 cos(...), 4 u24, 5 uopen,
  * 6 philox word 0 of ctr=(w,0,0,0) key=(0,0), 7 the kernels' lean sqrt, 8 IEEE sqrtf,

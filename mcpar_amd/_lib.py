@@ -111,6 +111,7 @@ def load():
         "mcx_debug_persist_deal": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), u32p, C.c_int],
         "mcx_debug_copy_bandwidth": [C.c_size_t, C.c_int, C.POINTER(C.c_double)],
         "mcx_debug_numerics": [C.c_int, C.c_int, u32p, u32p],
+        "mcx_debug_murray_screen": [C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_uint64)],
         "mcx_debug_normals": [C.c_uint32] * 6 + [C.c_int, fp],
         "mcx_debug_sqrt_sweep": [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), u32p],
     }

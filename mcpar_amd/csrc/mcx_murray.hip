@@ -329,3 +329,54 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
   return MCX_OK;
 }
 
+
+// The per-pair screen alone, for tests: masks[word][group] (mcx_screen.hpp's layout; group = 128 consecutive chains, in
+// the order given) of nact chains against N Gaussians given as (mu, sig2) pairs.
+extern "C" int mcx_debug_murray_screen(int d, int nact, int N, const float *x, const float *musig, int own0, int sums,
+                                       unsigned long long *masks)
+{
+  if ((d != 16 && d != 32) || nact < 1 || N < 1 || !x || !musig || !masks) return fail(MCX_ERR_INVALID, "mcx_debug_murray_screen: np = 16 or 32");
+  if (!sums && (own0 < 0 || own0 + nact > N)) return fail(MCX_ERR_INVALID, "mcx_debug_murray_screen: own Gaussians outside the N");
+  const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64, nblk = (N + SCR_BLK - 1) / SCR_BLK, K = scr_k(d);
+  DevBuf<float> dx, dms, q, centre, stats;
+  DevBuf<unsigned> hist;
+  DevBuf<unsigned short> A, B;
+  DevBuf<unsigned long long> excl, kept;
+  MCXCHK(dx.alloc((size_t)nact * d)); MCXCHK(dms.alloc((size_t)N * d * 2)); MCXCHK(q.alloc((size_t)N * d * 2));
+  MCXCHK(centre.alloc(64)); MCXCHK(stats.alloc(2 * CULL_KD)); MCXCHK(hist.alloc(CULL_BINS));
+  MCXCHK(A.alloc((size_t)ng * CULL_W * K)); MCXCHK(B.alloc((size_t)nblk * SCR_BLK * K));
+  MCXCHK(excl.alloc((size_t)ng * nw)); MCXCHK(kept.alloc(CULL_NCOUNT));
+  int rc = MCX_OK;
+  auto body = [&]() -> int {
+    HIPCHK(hipMemcpy(dx.p, x, (size_t)nact * d * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dms.p, musig, (size_t)N * d * 2 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(kept.p, 0, CULL_NCOUNT * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(excl.p, 0, (size_t)ng * nw * sizeof(unsigned long long)));
+    hipStream_t st = nullptr;
+    hipLaunchKernelGGL(k_remote_prep, dim3(nblocks((size_t)N * d)), dim3(BLOCK), 0, st, (const float *)dms.p, q.p, (size_t)N * d);
+    hipLaunchKernelGGL(k_screen_centre, dim3(1), dim3(1024), 0, st, (const float *)q.p, N, d, centre.p);
+    const dim3 gq(nblocks((size_t)nblk * SCR_BLK)), gp(nblocks((size_t)ng * CULL_W));
+    const int gx = (ng + SCR_WAVES - 1) / SCR_WAVES;
+    const dim3 gg((unsigned)gx, (unsigned)nblk);
+#define SCREEN_FOR(DM)                                                                                                          \
+    hipLaunchKernelGGL((k_screen_prep_q<DM>), gq, dim3(BLOCK), 0, st, (const float *)q.p, N, nblk * SCR_BLK, (const float *)centre.p, B.p); \
+    if (sums)                                                                                                                   \
+      hipLaunchKernelGGL((k_screen_prep_x<DM, true>), gp, dim3(BLOCK), 0, st, (const float *)dx.p, (const int *)nullptr, nact, ng * CULL_W, \
+                         (const float *)q.p, -1, (const float *)centre.p, A.p, stats.p, hist.p);                                 \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((k_screen_prep_x<DM, false>), gp, dim3(BLOCK), 0, st, (const float *)dx.p, (const int *)nullptr, nact, ng * CULL_W, \
+                         (const float *)q.p, own0, (const float *)centre.p, A.p, stats.p, hist.p);                               \
+    hipLaunchKernelGGL((k_screen_gemm<DM>), gg, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)A.p, (const unsigned short *)B.p, nact, N, \
+                       ng, 1, excl.p, nw, kept.p);
+    if (d == 16) { SCREEN_FOR(16) } else { SCREEN_FOR(32) }
+#undef SCREEN_FOR
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(masks, excl.p, (size_t)ng * nw * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MCX_OK;
+  };
+  rc = body();
+  dx.release(); dms.release(); q.release(); centre.release(); stats.release(); hist.release(); A.release(); B.release();
+  excl.release(); kept.release();
+  return rc;
+}

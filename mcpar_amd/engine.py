@@ -113,6 +113,19 @@ def debug_numerics(what, words):
     return out
 
 
+def debug_murray_screen(x, musig, own0=0, sums=True):
+    """the per-pair screen of the Murray sweeps alone (mcx_screen.hpp): masks[(N + 63) // 64, (n + 127) // 128] uint64 for
+    chains x[n, d] (groups of 128, in this order) against Gaussians musig[N, d, 2] = (mu, sig2)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    musig = np.ascontiguousarray(musig, dtype=np.float32)
+    n, d = x.shape
+    N = musig.shape[0]
+    masks = np.zeros(((N + 63) // 64, (n + 127) // 128), np.uint64)
+    check(load().mcx_debug_murray_screen(d, n, N, _fp(x), _fp(musig), int(own0), int(bool(sums)),
+                                         masks.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return masks
+
+
 def debug_normals(seed, stream, t, g0, a, q, n):
     out = np.empty((n, 4), np.float32)
     check(load().mcx_debug_normals(seed, stream, t, g0, a, q, n, _fp(out)))
