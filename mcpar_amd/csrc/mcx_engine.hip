@@ -745,6 +745,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   hipStream_t st = e->stream;
   MCXCHK(lik_setup(e->lik, L, d, st));
   MCXCHK(covar_install(e, incov, nullptr, false));  // src/mcpar.cc:20
+  e->cull_skip[0] = e->cull_skip[1] = 0;  // a new job starts from pinit: what the last one's Murray sweeps found useless is no guide
   // sample store: every chain, every main-loop step (src/mcpar.cc:31-40, 177-182), kept in HBM
   e->samp_steps = 0;
   const int nkeep = (nsamp + e->opt_stride - 1) / e->opt_stride;  // kept steps: isamp % stride == 0

@@ -23,17 +23,18 @@ static int launch_sweep_exact(const float *x, const int *list, int cnt, const fl
                               int N, int own0, const unsigned long long *excl, int ngroups, int S, hipStream_t st)
 {
   constexpr int CPL = SWEEP_CPL(DM);
-  if constexpr (DM == 16) {
-    // masked, or few chains: every wavefront reads its own rows through the scalar cache (no LDS, no barriers);
-    // unmasked over many chains the rows are better staged once per 512 chains (4.3 GB through L2 otherwise)
-    if (excl || cnt <= SROW_UNMASKED_MAX_CHAINS) {
+  if constexpr (DM == 16 || DM == 32) {
+    // 16-D masked, or over few chains: every wavefront reads its own rows through the scalar cache (no LDS, no
+    // barriers); unmasked over many chains the rows are better staged once per 512 chains (4.3 GB through L2 otherwise).
+    // 32-D: masked only (a row is two scalar fetches there).
+    if (excl || (DM == 16 && cnt <= SROW_UNMASKED_MAX_CHAINS)) {
       // masked min-arg sweep: several blocks per wavefront while 8192 wavefronts (eight per SIMD) remain -- 310 -> 72 us
       // per 65 536 x 65 536 sweep at 1 % of the rows.  The sum sweep has no own-Gaussian args to redo per block and
       // its surviving rows are many more in some groups than in others: eight blocks per wavefront 508 -> 600 us.
       int bpw = (excl && !SUMS) ? (int)(((long long)ngroups * S) / 8192) : 1;
       bpw = bpw < 1 ? 1 : (bpw > SROW_MAX_BLOCKS_PER_WAVE ? SROW_MAX_BLOCKS_PER_WAVE : bpw);
       const int gy = (S + bpw - 1) / bpw;
-      hipLaunchKernelGGL((k_remote_sweep_srow16<SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), gy), dim3(BLOCK), 0, st,
+      hipLaunchKernelGGL((k_remote_sweep_srow<DM, SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), gy), dim3(BLOCK), 0, st,
                          x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups, bpw);
       return SUMS ? S : gy;
     }
@@ -47,6 +48,10 @@ static int launch_sweep_exact(const float *x, const int *list, int cnt, const fl
 // pair (mcx_remote.hpp, "Exact exclusion of far Gaussians").  Leaves the sorted list in e->cull_sorted and the
 // masks in e->cull_excl ([group][words]); the pairs kept are added to the device counter behind e->nact.
 constexpr int CULL_MIN_CHAINS = 4096, CULL_MIN_GAUSSIANS = 4096;
+// the per-pair screen: any number of chains (a late rejection pass over a few hundred costs 60-160 us unscreened -- every
+// one of them against every Gaussian, on a fraction of the chip -- and has 20-30 of them per job), sorted only where there
+// are enough of them for neighbours to be near
+constexpr int SCREEN_MIN_CHAINS = 1, SCREEN_SORT_MIN_CHAINS = 2048;
 
 template <int DMAX>
 static int cull_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, hipStream_t st)
@@ -111,9 +116,11 @@ static int cull_prepare_proj(mcx_engine *e, const float *xrows, const int *ain, 
 }
 
 // The same sort, then the per-pair bound on the matrix cores (mcx_screen.hpp) in place of the boxes.  `fresh_q`: the
-// Gaussians' side (centre, B') has not been built for this genRemote call yet.
+// Gaussians' side (centre, B') has not been built for this genRemote call yet.  *order_out: the list the masks' groups
+// are cut from (the sorted list, or `ain` itself -- null = every chain in index order -- where nothing was sorted).
 template <int DMAX>
-static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, bool *fresh_q, hipStream_t st)
+static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, bool *fresh_q,
+                          const int **order_out, hipStream_t st)
 {
   const int d = e->nparam, N = e->tchains;
   const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64, nblk = (N + SCR_BLK - 1) / SCR_BLK;
@@ -124,18 +131,24 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
     e->cnt.kernel_launches += 2;
     *fresh_q = false;
   }
-  hipLaunchKernelGGL(k_cull_stats, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p);
-  hipLaunchKernelGGL(k_cull_keys, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p,
-                     e->cull_keys.p, e->cull_hist.p);
-  hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
-  hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
-                     e->cull_sorted.p);
+  const int *order = ain;  // (few chains: in the order they come)
+  if (nact >= SCREEN_SORT_MIN_CHAINS) {
+    hipLaunchKernelGGL(k_cull_stats, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p);
+    hipLaunchKernelGGL(k_cull_keys, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p,
+                       e->cull_keys.p, e->cull_hist.p);
+    hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, st, e->cull_hist.p);
+    hipLaunchKernelGGL(k_cull_scatter, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, ain, e->cull_keys.p, nact, e->cull_hist.p,
+                       e->cull_sorted.p);
+    order = e->cull_sorted.p;
+    e->cnt.kernel_launches += 4;
+  }
+  *order_out = order;
   const dim3 gp(nblocks((size_t)ng * CULL_W));
   if (sums)
-    hipLaunchKernelGGL((k_screen_prep_x<DMAX, true>), gp, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact, ng * CULL_W,
+    hipLaunchKernelGGL((k_screen_prep_x<DMAX, true>), gp, dim3(BLOCK), 0, st, xrows, order, nact, ng * CULL_W,
                        (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p);
   else
-    hipLaunchKernelGGL((k_screen_prep_x<DMAX, false>), gp, dim3(BLOCK), 0, st, xrows, (const int *)e->cull_sorted.p, nact, ng * CULL_W,
+    hipLaunchKernelGGL((k_screen_prep_x<DMAX, false>), gp, dim3(BLOCK), 0, st, xrows, order, nact, ng * CULL_W,
                        (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p);
   // enough workgroups for every CU to hold several: the Gaussians' blocks are cut into chunks
   const int gx = (ng + SCR_WAVES - 1) / SCR_WAVES;
@@ -145,7 +158,7 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
                      (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, nact, N, ng, bchunk, e->cull_excl.p, nw,
                      reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
   HIPCHK(hipGetLastError());
-  e->cnt.kernel_launches += 6;
+  e->cnt.kernel_launches += 2;
   return MCX_OK;
 }
 
@@ -168,7 +181,10 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
   // exclusion of far Gaussians: the two-chains-per-lane sweeps (np = 16, 32) over enough chains and Gaussians to
   // pay for the sort and the tests (or whenever possible: MCX_OPT_CULL = 1, for the tests)
   const bool cull_can = !big && d == dm && SWEEP_CPL(dm) == 2 && e->opt_cull != 0;
-  auto cull_now = [&](int na) { return cull_can && (e->opt_cull > 0 || (na >= CULL_MIN_CHAINS && N >= CULL_MIN_GAUSSIANS)); };
+  const bool gemm = e->opt_cull == 3 || e->opt_cull < 0;
+  auto cull_now = [&](int na) {
+    return cull_can && (e->opt_cull > 0 || (na >= (gemm ? SCREEN_MIN_CHAINS : CULL_MIN_CHAINS) && N >= CULL_MIN_GAUSSIANS));
+  };
   if (cull_can) {
     const size_t ngmax = ((size_t)n + CULL_W - 1) / CULL_W, nw = ((size_t)N + 63) / 64;
     const bool fresh = !e->cull_hist.p || !e->cull_stats.p;
@@ -190,7 +206,6 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
   // 0.999 like the boxes -- there a pair is dead because the chain is far from the Gaussian in the 31 directions ACROSS
   // the mixture's axis (the per-chain Gaussians are still narrow), which no bound for 128 chains at once can see.
   const bool proj = e->opt_cull == 2;
-  const bool gemm = e->opt_cull == 3 || e->opt_cull < 0;
   bool fresh_q = true;
   HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
   uint64_t evaluated_host = 0;  // pairs of the sweeps that ran without an exclusion test
@@ -217,14 +232,14 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     const unsigned long long *excl = nullptr;
     int S_min = S;  // entries per chain the min-arg sweep leaves for the combining kernel
     if (cull) {
+      order = e->cull_sorted.p;
       if (gemm) {
-        DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, &fresh_q, st))));
+        DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, &fresh_q, &order, st))));
       } else if (proj) {
         DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
       } else {
         DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
       }
-      order = e->cull_sorted.p;
       excl = e->cull_excl.p;
     } else {
       evaluated_host += (uint64_t)n * (uint64_t)N;
@@ -271,14 +286,14 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       const int *list = ain;
       const unsigned long long *excl = nullptr;
       if (cull) {  // the proposals have just been drawn: sort, box and test them
+        list = e->cull_sorted.p;
         if (gemm) {
-          DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, &fresh_q, st))));
+          DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, &fresh_q, &list, st))));
         } else if (proj) {
           DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
         } else {
           DISPATCH_DMAX(dm, MCXCHK((cull_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
         }
-        list = e->cull_sorted.p;
         excl = e->cull_excl.p;
         a.active_in = list;  // positions of psum / pmax are positions of the sorted list
       } else {

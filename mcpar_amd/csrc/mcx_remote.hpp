@@ -404,14 +404,17 @@ __global__ __launch_bounds__(NT, (DMAX == 32 && CPL == 2) ? 4 : 1) void k_remote
 // order as sweep_rows2, same early outs, hence the same bits.  excl == null sweeps every row: used for the late
 // rejection passes over a few thousand chains, where the LDS kernel's grid is too small to hide its barriers (VALU
 // issue 0.25) and the rows every wavefront then pulls through L2 are few.
-template <bool SUMS>
-__global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow16(const float *__restrict__ xrows, const int *__restrict__ active,
+// np = 32: the same with a row in two halves of 16 dimensions, each the 32 SGPRs a 16-D row takes -- the second half is
+// on its way while the first is swept and is swept only if the first left the row alive.
+template <int DMAX, bool SUMS>
+__global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow(const float *__restrict__ xrows, const int *__restrict__ active,
                                                                int nact, const float *__restrict__ qpar,
                                                                float *__restrict__ psum, float *__restrict__ pmax, int N,
                                                                int own0, const unsigned long long *__restrict__ excl,
                                                                int ngroups, int bpw)
 {
-  constexpr int DMAX = 16, G = 4;
+  static_assert(DMAX == 16 || DMAX == 32, "rows of one or two 16-dimension halves");
+  constexpr int H = 16, NH = DMAX / H, G = DMAX / 4;  // dimensions per half, halves, dimensions between two early-out tests
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
   const int g = (int)blockIdx.x * (BLOCK / 64) + wv;
   if (g >= ngroups) return;  // (no barriers in this kernel)
@@ -495,66 +498,85 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow16(const float *__re
   // one row = 32 floats read through the CONSTANT address space at a wave-uniform address: scalar loads
   // (s_load_dwordx4 .. x16 into SGPRs), waited for by the compiler's own s_waitcnt
   typedef float v4 __attribute__((ext_vector_type(4)));
-  struct Row { v4 v[DMAX / 2]; };
-  auto fetch = [&](int r, Row &row) {
+  struct Row { v4 v[H / 2]; };
+  auto fetch = [&](int r, int half, Row &row) {
     const __attribute__((address_space(4))) v4 *rp =
-        (const __attribute__((address_space(4))) v4 *)(qpar + 2 * (size_t)(q0 + r) * DMAX);
+        (const __attribute__((address_space(4))) v4 *)(qpar + 2 * ((size_t)(q0 + r) * DMAX + (size_t)half * H));
 #pragma unroll
-    for (int k = 0; k < DMAX / 2; ++k) row.v[k] = rp[k];
+    for (int k = 0; k < H / 2; ++k) row.v[k] = rp[k];
   };
-  auto sweep_one = [&](const Row &row) {
-    auto two_dims = [&](v4 v, int k, f32x2 arg) {  // (mu_k, w_k, mu_k+1, w_k+1)
-      const f32x2 xm0 = splat2(v.x) - xx[k];
-      arg = fma2(xm0 * xm0, splat2(v.y), arg);
-      const f32x2 xm1 = splat2(v.z) - xx[k + 1];
-      arg = fma2(xm1 * xm1, splat2(v.w), arg);
-      return arg;
-    };
-    const f32x2 b = SUMS ? splat2(ZERO_ARG)
-                         : f32x2{amin.x < ZERO_ARG ? amin.x : ZERO_ARG, amin.y < ZERO_ARG ? amin.y : ZERO_ARG};
+  auto two_dims = [&](v4 v, int k, f32x2 arg) {  // (mu_k, w_k, mu_k+1, w_k+1)
+    const f32x2 xm0 = splat2(v.x) - xx[k];
+    arg = fma2(xm0 * xm0, splat2(v.y), arg);
+    const f32x2 xm1 = splat2(v.z) - xx[k + 1];
+    arg = fma2(xm1 * xm1, splat2(v.w), arg);
+    return arg;
+  };
+  auto bound_now = [&]() {
+    return SUMS ? splat2(ZERO_ARG) : f32x2{amin.x < ZERO_ARG ? amin.x : ZERO_ARG, amin.y < ZERO_ARG ? amin.y : ZERO_ARG};
+  };
+  // dimensions half * H .. half * H + H - 1 of a row: false = every chain of the wavefront is past its bound
+  auto sweep_half = [&](const Row &row, int half, f32x2 &arg, const f32x2 b) {
+#pragma unroll
+    for (int c = 0; c < H; c += G) {
+#pragma unroll
+      for (int k = 0; k < G / 2; ++k) arg = two_dims(row.v[c / 2 + k], half * H + c + 2 * k, arg);
+      if (((__ballot(arg.x > b.x) | no_a) & (__ballot(arg.y > b.y) | no_b)) == everyone) return false;
+    }
+    return true;
+  };
+  auto consume = [&](const f32x2 arg) {
+    if (SUMS) {
+      const f32x2 gv = expf_v2x2(splat2(-0.5f) * arg);
+      part = part + gv;
+      m.x = gv.x > m.x ? gv.x : m.x;
+      m.y = gv.y > m.y ? gv.y : m.y;
+    } else {
+      amin.x = arg.x < amin.x ? arg.x : amin.x;
+      amin.y = arg.y < amin.y ? arg.y : amin.y;
+    }
+  };
+  auto sweep_one = [&](const Row &row) {  // (a whole 16-D row)
     f32x2 arg = {0.0f, 0.0f};
-    bool live = true;
-#pragma unroll
-    for (int c = 0; c < DMAX; c += G) {
-#pragma unroll
-      for (int k = 0; k < G / 2; ++k) arg = two_dims(row.v[c / 2 + k], c + 2 * k, arg);
-      if (((__ballot(arg.x > b.x) | no_a) & (__ballot(arg.y > b.y) | no_b)) == everyone) {
-        live = false;
-        break;
-      }
-    }
-    if (live) {
-      if (SUMS) {
-        const f32x2 gv = expf_v2x2(splat2(-0.5f) * arg);
-        part = part + gv;
-        m.x = gv.x > m.x ? gv.x : m.x;
-        m.y = gv.y > m.y ? gv.y : m.y;
-      } else {
-        amin.x = arg.x < amin.x ? arg.x : amin.x;
-        amin.y = arg.y < amin.y ? arg.y : amin.y;
-      }
-    }
+    if (sweep_half(row, 0, arg, bound_now())) consume(arg);
   };
   // Two row buffers in turn: the next surviving row is requested before this one is swept.  Scalar loads return
   // out of order, so the only wait there is is "all of them": the wait for THIS row must come before the request
   // for the next one, or it would wait for that too -- `landed` is a use of the row's first and last number that the
   // compiler has to satisfy at that point.
-  auto landed = [&](const Row &row) { asm volatile("" ::"s"(row.v[0].x), "s"(row.v[DMAX / 2 - 1].w)); };
+  auto landed = [&](const Row &row) { asm volatile("" ::"s"(row.v[0].x), "s"(row.v[H / 2 - 1].w)); };
   Row ra, rb;
   int r = next_row();
   if (r >= 0) {
-    fetch(r, ra);
-    for (;;) {
-      landed(ra);
-      r = next_row();
-      if (r >= 0) fetch(r, rb);
-      sweep_one(ra);
-      if (r < 0) break;
-      landed(rb);
-      r = next_row();
-      if (r >= 0) fetch(r, ra);
-      sweep_one(rb);
-      if (r < 0) break;
+    fetch(r, 0, ra);
+    if constexpr (NH == 1) {
+      for (;;) {
+        landed(ra);
+        r = next_row();
+        if (r >= 0) fetch(r, 0, rb);
+        sweep_one(ra);
+        if (r < 0) break;
+        landed(rb);
+        r = next_row();
+        if (r >= 0) fetch(r, 0, ra);
+        sweep_one(rb);
+        if (r < 0) break;
+      }
+    } else {
+      for (;;) {
+        landed(ra);
+        fetch(r, 1, rb);
+        f32x2 arg = {0.0f, 0.0f};
+        const f32x2 b = bound_now();
+        bool live = sweep_half(ra, 0, arg, b);
+        landed(rb);
+        const int rn = next_row();
+        if (rn >= 0) fetch(rn, 0, ra);
+        if (live) live = sweep_half(rb, 1, arg, b);
+        if (live) consume(arg);
+        if (rn < 0) break;
+        r = rn;
+      }
     }
   }
   if (SUMS) {
