@@ -45,6 +45,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 PORT_OVER_REFERENCE = 2.2  # the oracle port's speed over the compiled reference per set of cores
 HBM_PEAK = 8.0e12       # B/s, MI355X_MICROARCH.md chip table
 FP32_VALU_PEAK = 157.3e12  # flop/s, MI355X_MICROARCH.md "Peak FP32 (vector)"
+BF16_MFMA_PEAK = 2.5e15    # flop/s dense, MI355X_MICROARCH.md (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD)
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 
 # SURVEY §8d.  lik: 1 = Rosenbrock1, 5 = K-component unit-variance Gaussian mixture
@@ -551,11 +552,26 @@ def main():
         dd = c["d"]
         flops = sw["chain_steps"] * (3 * dd + 4)
         ach = flops / (sw["ms"] * 1e-3)
-        return dict(bound="valu", kernel="k_remote_sweep*", achieved=ach / 1e12, peak=FP32_VALU_PEAK / 1e12,
-                    unit="TFLOP/s", frac=ach / FP32_VALU_PEAK, pairs=sw["chain_steps"], flop_per_pair=3 * dd + 4,
-                    launches=sw["launches"], total_ms=sw["ms"], remote_steps=cn["remote_steps"], passes=cn["remote_passes"],
-                    whole_genremote_ms=pr["remote"]["ms"], pairs_evaluated=cn.get("remote_pairs_evaluated"),
-                    pairs_evaluated_frac=(cn.get("remote_pairs_evaluated", 0) / float(cn["remote_pairs"]) if cn.get("remote_pairs") else None))
+        kept = (cn.get("remote_pairs_evaluated", 0) / float(cn["remote_pairs"]) if cn.get("remote_pairs") else None)
+        out = dict(bound="valu", kernel="k_remote_sweep*", achieved=ach / 1e12, peak=FP32_VALU_PEAK / 1e12,
+                   unit="TFLOP/s", frac=ach / FP32_VALU_PEAK, pairs=sw["chain_steps"], flop_per_pair=3 * dd + 4,
+                   launches=sw["launches"], total_ms=sw["ms"], remote_steps=cn["remote_steps"], passes=cn["remote_passes"],
+                   whole_genremote_ms=pr["remote"]["ms"], pairs_evaluated=cn.get("remote_pairs_evaluated"),
+                   pairs_evaluated_frac=kept)
+        if kept is not None:
+            # `achieved` counts the algorithm's pairs, skipped or not (with the screens it passes the vector peak: the
+            # point of them); this is the rate on the pairs the sweeps actually swept
+            out["achieved_on_evaluated_pairs"] = ach * kept / 1e12
+            out["frac_on_evaluated_pairs"] = ach * kept / FP32_VALU_PEAK
+        sc = pr.get("remote_screen")
+        if sc and sc["launches"] > 0 and sc["ms"] > 0:
+            # the per-pair screen (mcx_screen.hpp): one bf16 product row of K = 2 np + 16 per pair on the matrix cores
+            kk = 2 * dd + 16
+            sf = sc["chain_steps"] * 2.0 * kk / (sc["ms"] * 1e-3)
+            out["screen"] = dict(bound="mfma", kernel="k_screen_gemm<%d>" % dd, achieved=sf / 1e12, peak=BF16_MFMA_PEAK / 1e12,
+                                 unit="TFLOP/s", frac=sf / BF16_MFMA_PEAK, pairs=sc["chain_steps"], flop_per_pair=2 * kk,
+                                 launches=sc["launches"], total_ms=sc["ms"])
+        return out
 
     roofline = murray = cpu = end_to_end = claims = host_cb = None
     others = {}

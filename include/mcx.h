@@ -314,6 +314,7 @@ enum { MCX_K_FUSED_BURN = 0, MCX_K_FUSED_MAIN, MCX_K_PROPOSE, MCX_K_EVAL, MCX_K_
        MCX_K_REMOTE_SWEEP, /* the all-pairs sweep kernels alone (inside MCX_K_REMOTE); chain_steps = pairs */
        MCX_K_GEN_NORMALS,  /* small-n mode: the random-number generator kernel (inside MCX_K_FUSED_*) */
        MCX_K_RUN_SMALL,    /* small-n mode: k_run_small, burn-in and main-loop steps of one launch together */
+       MCX_K_REMOTE_SCREEN,/* the per-pair screen's matrix-core kernel alone (inside MCX_K_REMOTE); chain_steps = pairs */
        MCX_K_COUNT = 12 };
 typedef struct mcx_profile {
   double ms[MCX_K_COUNT];

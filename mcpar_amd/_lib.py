@@ -32,7 +32,7 @@ class Counters(C.Structure):
 
 
 K_NAMES = ("fused_burn", "fused_main", "propose", "eval", "accept", "remote", "tuner", "misc", "remote_sweep",
-           "gen_normals", "run_small", "reserved11")
+           "gen_normals", "run_small", "remote_screen")
 
 
 class PlanItem(C.Structure):

@@ -26,7 +26,8 @@ static int launch_sweep_exact(const float *x, const int *list, int cnt, const fl
   if constexpr (DM == 16 || DM == 32) {
     // 16-D masked, or over few chains: every wavefront reads its own rows through the scalar cache (no LDS, no
     // barriers); unmasked over many chains the rows are better staged once per 512 chains (4.3 GB through L2 otherwise).
-    // 32-D: masked only (a row is two scalar fetches there).
+    // 32-D: masked only (a row is two scalar fetches there) -- and then whatever share of the rows the masks leave: C5 25.5 ms
+    // per job so, 26.0-26.8 with the LDS kernel taking over from 15 / 30 / 50 % of the rows kept or everywhere.
     if (excl || (DM == 16 && cnt <= SROW_UNMASKED_MAX_CHAINS)) {
       // masked min-arg sweep: several blocks per wavefront while 8192 wavefronts (eight per SIMD) remain -- 310 -> 72 us
       // per 65 536 x 65 536 sweep at 1 % of the rows.  The sum sweep has no own-Gaussian args to redo per block and
@@ -154,11 +155,14 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
   const int gx = (ng + SCR_WAVES - 1) / SCR_WAVES;
   int bchunk = (int)(((long long)gx * nblk + 4095) / 4096);
   if (bchunk < 1) bchunk = 1;
-  hipLaunchKernelGGL((k_screen_gemm<DMAX>), dim3((unsigned)gx, (unsigned)((nblk + bchunk - 1) / bchunk)), dim3(SCR_WAVES * 64), 0, st,
-                     (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, nact, N, ng, bchunk, e->cull_excl.p, nw,
-                     reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
+  {
+    ProfScope sg(e, MCX_K_REMOTE_SCREEN, (uint64_t)nact * (uint64_t)N);
+    hipLaunchKernelGGL((k_screen_gemm<DMAX>), dim3((unsigned)gx, (unsigned)((nblk + bchunk - 1) / bchunk)), dim3(SCR_WAVES * 64), 0, st,
+                       (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, nact, N, ng, bchunk, e->cull_excl.p, nw,
+                       reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
+  }
   HIPCHK(hipGetLastError());
-  e->cnt.kernel_launches += 2;
+  e->cnt.kernel_launches += 1;  // (+1: the screen's own scope)
   return MCX_OK;
 }
 

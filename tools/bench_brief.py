@@ -17,4 +17,8 @@ mr = line.get("murray_roofline") or {}
 if mr:
     print("   sweeps: %.2f ms of %.2f ms in genRemote over %s remote steps, pairs evaluated %.4f" % (
         mr.get("total_ms", 0), mr.get("whole_genremote_ms", 0), mr.get("remote_steps"), mr.get("pairs_evaluated_frac", 0)))
+    sc = mr.get("screen")
+    if sc:
+        print("   screen: %s %.2f ms in %d launches, %.0f TFLOP/s bf16 = %.2f of the dense peak" % (
+            sc["kernel"], sc["total_ms"], sc["launches"], sc["achieved"], sc["frac"]))
 print("   " + json.dumps({k: v for k, v in line["summary"].items() if v is not None}))
