@@ -237,7 +237,7 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     int S_min = S;  // entries per chain the min-arg sweep leaves for the combining kernel
     if (cull) {
       order = e->cull_sorted.p;
-      if (gemm) {
+      if (gemm) {  // (boxes here and the per-pair bound for the sums only: C3-murray 18.1 -> 25.6 ms, C5 26.0 -> 38.8)
         DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, &fresh_q, &order, st))));
       } else if (proj) {
         DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
