@@ -1,6 +1,8 @@
 """Randomised configurations (fixed seed): every combination of dimension, chain count, loop lengths,
 sync period, proposal mix, likelihood, covariance, fusion mode, launch cap and thinning must match the
 oracle bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -50,6 +52,8 @@ def one_case(rng, idx):
     sink = int(rng.choice([0, 0, 1, 3, 10, 64]))  # > 0: samples streamed through the sink in blocks of that many steps
     cull = int(rng.choice([-1, -1, 0, 1, 2, 3]))   # exact exclusion of far Gaussians in the Murray sweeps: auto / off / boxes / one direction / per-pair bound
     bpl = int(rng.choice([0, 0, 1, 2, 4]))      # parameter blocks per lane of the hot-path kernel (0 = automatic)
+    if os.environ.get("MCX_FUZZ_CULL"):         # a soak of one screen: every case with it
+        cull = int(os.environ["MCX_FUZZ_CULL"])
     desc = dict(idx=idx, kind=kind, d=d, n=n, nburn=nburn, nsamp=nsamp, pl=pl, sync=sync, K=K, fullcov=incov is not None,
                 fuse=fuse, mask=mask, maxseg=maxseg, stride=stride, persist=persist, split=split, sink=sink, cull=cull, bpl=bpl)
     p = (rng.normal(0, 0.7, (n, d))).astype(np.float32)
