@@ -158,7 +158,10 @@ def pmc_child(cfg, n):
     eng.close()
 
 
-def collect_pmc(config_name, n, keep_dir=None, budget_s=150.0):
+PMC_PASS_MFMA = ("SQ_VALU_MFMA_BUSY_CYCLES",)  # Murray configurations: the screen's matrix-core kernel (cycles, not quad-cycles)
+
+
+def collect_pmc(config_name, n, keep_dir=None, budget_s=150.0, extra_passes=()):
     """-> ({kernel: {counter: mean per dispatch}}, {kernel: mean duration ns under the profiler}, note).
     Each counter group is its own `rocprofv3 --pmc ... --kernel-trace` run of `bench.py --pmc-child`."""
     exe = shutil.which("rocprofv3")
@@ -170,7 +173,7 @@ def collect_pmc(config_name, n, keep_dir=None, budget_s=150.0):
         os.makedirs(tmp, exist_ok=True)
     else:
         tmp = tempfile.mkdtemp(prefix="mcx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    for group in PMC_PASSES:
+    for group in tuple(PMC_PASSES) + tuple(extra_passes):
         if time.time() - t_start > budget_s:
             return out or None, dur, "time budget exhausted before " + ",".join(group)
         ddir = os.path.join(tmp, "_".join(group))
@@ -751,7 +754,8 @@ def main():
             pmc = pdur = None
             note = "--no-pmc"
             if not args.no_pmc:
-                pmc, pdur, note = collect_pmc(args.config, n, keep_dir=args.keep_pmc or None)
+                pmc, pdur, note = collect_pmc(args.config, n, keep_dir=args.keep_pmc or None,
+                                              extra_passes=(PMC_PASS_MFMA,) if cfg["pl"] < 1.0 else ())
             # the kernel that RAN: the one of the family the child job spent the most time in, under the name its kernel
             # trace gives it (k_fused_fastb<LPC2, BPL, ...> when the engine chose several blocks per lane, ...)
             dom = dominant_kernel(pmc, pdur, roofline["kernel_family"])
@@ -834,6 +838,15 @@ def main():
                         frac_at_measured_issue_intervals=(2.7 * plain + 4.7 * packed) / (N_SIMD * cyc2))
                 if vi:
                     murray["valu_issue"] = dict(kernels=vi)
+                # the screen's kernel: cycles its SIMDs' matrix cores were busy (32 per v_mfma_f32_32x32x16_bf16) of the
+                # cycles the kernel ran, from the same kind of child pass
+                kg = find_kernel(pmc, "k_screen_gemm")
+                if kg and murray.get("screen") and "SQ_VALU_MFMA_BUSY_CYCLES" in pmc[kg] and "GRBM_GUI_ACTIVE" in pmc[kg]:
+                    cyc3 = pmc[kg]["GRBM_GUI_ACTIVE"] / 8.0
+                    murray["screen"]["mfma_busy"] = dict(SQ_VALU_MFMA_BUSY_CYCLES=pmc[kg]["SQ_VALU_MFMA_BUSY_CYCLES"],
+                                                         GRBM_GUI_ACTIVE=pmc[kg]["GRBM_GUI_ACTIVE"],
+                                                         frac_of_simd_cycles=pmc[kg]["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * cyc3),
+                                                         note="mean over the dispatches of the measured child job (all pass sizes)")
         if not args.no_extras and args.config == "c3" and not args.chains and args.dim == 0:
             claims = claims_under_the_clock(M, E, dt / args.steps * 1e3, n, nburn, nsamp)
             host_cb = host_callback_leg(M, E, cfg, n)
@@ -857,6 +870,8 @@ def main():
             "other_configs_meet_timeouts": sum(v["stats"]["meet_timeouts"] for v in others.values()) if others else None,
             "c5_pairs_evaluated_frac": pick(others.get("c5"), "sweep", "pairs_evaluated_frac"),
             "c3_murray_pairs_evaluated_frac": pick(others.get("c3-murray"), "sweep", "pairs_evaluated_frac"),
+            "c5_screen_mfma_frac": pick(others.get("c5"), "sweep", "screen", "frac") or pick(murray, "screen", "frac"),
+            "c3_murray_screen_mfma_frac": pick(others.get("c3-murray"), "sweep", "screen", "frac"),
             "full_cov_ratio": {k: round(v["ratio"], 3) for k, v in ((claims or {}).get("full_cov") or {}).items() if isinstance(v, dict)} or None,
             "strong_proxy_ms": pick(sp, "ms_per_job"), "strong_proxy_speedup": pick(sp, "speedup_vs_headline_job"),
             "strong_proxy_meet_timeouts": pick(sp, "stats", "meet_timeouts"),

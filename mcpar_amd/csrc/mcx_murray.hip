@@ -151,9 +151,18 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
   else
     hipLaunchKernelGGL((k_screen_prep_x<DMAX, false>), gp, dim3(BLOCK), 0, st, xrows, order, nact, ng * CULL_W,
                        (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p);
-  // enough workgroups for every CU to hold several: the Gaussians' blocks are cut into chunks
+  // The Gaussians' blocks are cut into chunks so that the grid is two chipfuls of workgroups (the kernel's own occupancy
+  // x the CUs; one to four chipfuls, or 4096 workgroups whatever the chip holds: the same time within 2 %)
+  constexpr int rounds = 2;
+  static int resident = 0;  // (per instantiation: a function-local static of the template)
+  if (!resident) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_screen_gemm<DMAX>, SCR_WAVES * 64, 0) != hipSuccess || nb < 1) nb = 2;
+    resident = nb * (e->ncu > 0 ? e->ncu : 256);
+  }
   const int gx = (ng + SCR_WAVES - 1) / SCR_WAVES;
-  int bchunk = (int)(((long long)gx * nblk + 4095) / 4096);
+  const int gy_want = std::max(1, (rounds * resident) / gx);
+  int bchunk = (nblk + gy_want - 1) / gy_want;
   if (bchunk < 1) bchunk = 1;
   {
     ProfScope sg(e, MCX_K_REMOTE_SCREEN, (uint64_t)nact * (uint64_t)N);

@@ -265,13 +265,7 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigne
       for (int s = 0; s < KS; ++s)
         bf[s] = *reinterpret_cast<const scr_bf16x8 *>(blds + (ct * 32 + r) * LROW + (s * 16 + h * 8) * 2);
       float mn = __builtin_inff();
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        scr_f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][s], bf[s], acc, 0, 0, 0);
-        // (two wavefronts per SIMD asked for above: with at most 256 registers the accumulators are plain VGPRs and
-        // this minimum reads them directly -- from AGPRs every one of them costs a v_accvgpr_read first)
+      auto tile_min = [](const scr_f32x16 &acc) {
         const float m0 = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
         const float m1 = __builtin_fminf(__builtin_fminf(acc[3], acc[4]), acc[5]);
         const float m2 = __builtin_fminf(__builtin_fminf(acc[6], acc[7]), acc[8]);
@@ -279,7 +273,19 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigne
         const float m4 = __builtin_fminf(__builtin_fminf(acc[12], acc[13]), acc[14]);
         const float m5 = __builtin_fminf(__builtin_fminf(m0, m1), acc[15]);
         const float m6 = __builtin_fminf(__builtin_fminf(m2, m3), m4);
-        mn = __builtin_fminf(__builtin_fminf(mn, m5), m6);
+        return __builtin_fminf(m5, m6);
+      };
+      // (at most 256 registers asked for above: the accumulators are plain VGPRs and the minimum reads them directly --
+      // from AGPRs every one of them costs a v_accvgpr_read first.  Measured and not faster: two row tiles at a time on
+      // two accumulators (32-D +3 %, 16-D spills at five wavefronts per SIMD), s_setprio around the products, five
+      // wavefronts per SIMD instead of four, grids of exactly one to four chipfuls of workgroups: the matrix cores stay
+      // 65 % busy, SQ_VALU_MFMA_BUSY_CYCLES)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        scr_f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][s], bf[s], acc, 0, 0, 0);
+        mn = __builtin_fminf(mn, tile_min(acc));
       }
       const bool col_ok = b * SCR_BLK + ct * 32 + r < N;
       const unsigned long long bal = __ballot(col_ok && !(mn > 0.0f));  // both halves hold the same 32 Gaussians
