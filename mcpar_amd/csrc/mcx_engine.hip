@@ -329,7 +329,8 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   A(e->tun_cells.alloc(TUN_CELLS + 1));
   if (st == MCX_OK && hipMemset(e->tun_cells.p, 0, (TUN_CELLS + 1) * sizeof(unsigned long long)) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipMemset failed");
-  A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->nact.alloc(2 * (1 + 2 * NACT_CULL_CELLS))); A(e->ntrace.alloc(1));
+  A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->ntrace.alloc(1));
+  A(e->nact.alloc(2 * (1 + 2 * NACT_CULL_CELLS) + 2));  // (+ the word k_remote_decide counts its workgroups in)
   if (st == MCX_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipStreamCreate failed");
   if (st != MCX_OK) { mcx_destroy(e); return st; }

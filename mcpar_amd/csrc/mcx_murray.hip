@@ -220,7 +220,8 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
   // the mixture's axis (the per-chain Gaussians are still narrow), which no bound for 128 chains at once can see.
   const bool proj = e->opt_cull == 2;
   bool fresh_q = true;
-  HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long), st));
+  // (the screens' cells and, right behind them, the word k_remote_decide counts its workgroups in)
+  HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long) + 2 * sizeof(int), st));
   uint64_t evaluated_host = 0;  // pairs of the sweeps that ran without an exclusion test
   // auto mode gives the test up where it excludes too little to pay for itself (the 32-D mixture: per-chain
   // Gaussians too broad for any 128-chain box), per kind of sweep, and tries again every eighth call
@@ -289,6 +290,10 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     a.racpt = e->racpt.p; a.psum = e->psum.p; a.pmax = e->pmax.p;
     a.n = n; a.d = d; a.N = N; a.pass = pass; a.S = S;
     a.g0 = (uint32_t)(e->rank * e->nchain); a.t = t; a.seed = e->seed;
+    a.counts = reinterpret_cast<const unsigned long long *>(e->nact.p);
+    a.counts_host = big ? nullptr : e->h_nact.p;  // (np > 64: no k_remote_decide; the copy below)
+    a.done = reinterpret_cast<unsigned *>(e->nact.p) + 2 * (1 + 2 * NACT_CULL_CELLS);
+    a.ncounts = cull_can ? 1 + 2 * CULL_NCOUNT : 1;
     if (big) {
       hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
       evaluated_host += (uint64_t)nact * (uint64_t)N;
@@ -328,7 +333,7 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     HIPCHK(hipGetLastError());
     e->cnt.remote_pairs += (uint64_t)nact * (uint64_t)N;
     unsigned long long *back = e->h_nact.p;  // survivors (low word), cells of the pairs kept by the min-arg / sum tests so far
-    HIPCHK(hipMemcpyAsync(back, e->nact.p, (cull_can ? 1 + 2 * CULL_NCOUNT : 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (big) HIPCHK(hipMemcpyAsync(back, e->nact.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));  // (else: k_remote_decide has written them)
     HIPCHK(hipStreamSynchronize(st));
     const unsigned long long before = kept_sums;
     const uint64_t pairs_now = (uint64_t)nact * (uint64_t)N;

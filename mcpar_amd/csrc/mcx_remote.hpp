@@ -166,6 +166,13 @@ struct RemoteArgs {
   float *psum, *pmax;  // [S][nact] per-block partial sums / maxima, by position in the active list
   int n, d, N, pass, S;
   uint32_t g0, t, seed;
+  // k_remote_decide's last workgroup hands the pass's counters to the host itself (no copy kernel behind it): `ncounts`
+  // 64-bit words from `counts` (the two survivor counters, then the screens' cells) to `counts_host` (pinned, mapped);
+  // `done` counts the workgroups that are through and is left zero.  counts_host null: nothing of the kind.
+  const unsigned long long *counts;
+  unsigned long long *counts_host;
+  unsigned *done;
+  int ncounts;
 };
 
 // Murray draw for every still-rejected chain (src/mcpar.cc:337-352): pick a component, draw from
@@ -414,7 +421,9 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow(const float *__rest
                                                                int ngroups, int bpw)
 {
   static_assert(DMAX == 16 || DMAX == 32, "rows of one or two 16-dimension halves");
-  constexpr int H = 16, NH = DMAX / H, G = DMAX / 4;  // dimensions per half, halves, dimensions between two early-out tests
+  // dimensions per half-row, halves, dimensions between two early-out tests (two tests per row: behind the per-pair
+  // screen few rows leave early, and four tests cost 1.5 % of both Murray jobs more than two or one)
+  constexpr int H = 16, NH = DMAX / H, G = DMAX / 2;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
   const int g = (int)blockIdx.x * (BLOCK / 64) + wv;
   if (g >= ngroups) return;  // (no barriers in this kernel)
@@ -637,40 +646,56 @@ __device__ __forceinline__ int wave_slot(int *counter)
 static __global__ void k_remote_decide(const RemoteArgs a)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.nact) return;
-  const int j = a.active_in ? a.active_in[i] : i;
-  float qs = FPEPS, qm = FPEPS;  // src/mcpar.cc:355-365
-  // The partials are added in block order (the arithmetic contract), but they are REQUESTED 16 blocks at a time:
-  // a 65 536-chain pass reads 134 MB here with one wavefront per SIMD, so the loads in flight per lane are its speed
-  // (66 -> 14 us).
-  constexpr int U = 16;
-  const float *ps = a.psum + i, *pm = a.pmax + i;
-  int sb = 0;
-  for (; sb + U <= a.S; sb += U) {
-    float s[U], v[U];
+  if (i < a.nact) {
+    const int j = a.active_in ? a.active_in[i] : i;
+    float qs = FPEPS, qm = FPEPS;  // src/mcpar.cc:355-365
+    // The partials are added in block order (the arithmetic contract), but they are REQUESTED 16 blocks at a time:
+    // a 65 536-chain pass reads 134 MB here with one wavefront per SIMD, so the loads in flight per lane are its speed
+    // (66 -> 14 us).
+    constexpr int U = 16;
+    const float *ps = a.psum + i, *pm = a.pmax + i;
+    int sb = 0;
+    for (; sb + U <= a.S; sb += U) {
+      float s[U], v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      s[u] = ps[(size_t)(sb + u) * a.nact];
-      v[u] = pm[(size_t)(sb + u) * a.nact];
+      for (int u = 0; u < U; ++u) {
+        s[u] = ps[(size_t)(sb + u) * a.nact];
+        v[u] = pm[(size_t)(sb + u) * a.nact];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        qs = qs + s[u];
+        qm = v[u] > qm ? v[u] : qm;
+      }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      qs = qs + s[u];
-      qm = v[u] > qm ? v[u] : qm;
+    for (; sb < a.S; ++sb) {
+      qs = qs + ps[(size_t)sb * a.nact];
+      const float v = pm[(size_t)sb * a.nact];
+      qm = v > qm ? v : qm;
+    }
+    const float pacpt = qm / qs;
+    if (i == 0 && a.nact_zero) *a.nact_zero = 0;  // the next pass's counter (this pass counts in the other one)
+    if (a.racpt[j] < pacpt) {
+      a.cfac[j] = a.cmax[j] / qm;
+    } else {
+      a.active_out[wave_slot(a.nact_out)] = j;
+      remote_draw_one(a, j, a.pass + 1);  // rejected: its next proposal, now (src/mcpar.cc:337-352 of the next pass)
     }
   }
-  for (; sb < a.S; ++sb) {
-    qs = qs + ps[(size_t)sb * a.nact];
-    const float v = pm[(size_t)sb * a.nact];
-    qm = v > qm ? v : qm;
+  if (!a.counts_host) return;
+  // the last workgroup through copies the counters out: what the host waits for is this kernel, not a copy behind it
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(a.done, 1u) == gridDim.x - 1u;
   }
-  const float pacpt = qm / qs;
-  if (i == 0 && a.nact_zero) *a.nact_zero = 0;  // the next pass's counter (this pass counts in the other one)
-  if (a.racpt[j] < pacpt) {
-    a.cfac[j] = a.cmax[j] / qm;
-  } else {
-    a.active_out[wave_slot(a.nact_out)] = j;
-    remote_draw_one(a, j, a.pass + 1);  // rejected: its next proposal, now (src/mcpar.cc:337-352 of the next pass)
+  __syncthreads();
+  if (last) {
+    for (int k = (int)threadIdx.x; k < a.ncounts; k += (int)blockDim.x)
+      a.counts_host[k] = __hip_atomic_load(a.counts + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) *a.done = 0u;
+    __threadfence_system();
   }
 }
 
