@@ -68,9 +68,9 @@ __device__ __forceinline__ float scr_val(unsigned short h) { return __uint_as_fl
 // small.  One workgroup; d a power of two <= 64 (thread t: dimension t % d of the rows t / d, t / d + 1024 / d, ...).
 static __global__ __launch_bounds__(1024) void k_screen_centre(const float *__restrict__ qpar, int N, int d, float *__restrict__ centre)
 {
-  __shared__ float sum[64], cnt[64];
-  if (threadIdx.x < 64) { sum[threadIdx.x] = 0.0f; cnt[threadIdx.x] = 0.0f; }
-  __syncthreads();
+  __shared__ float sum[1024], cnt[1024];  // [slice][dimension]: added up in a fixed order (the groups the masks are made
+                                          // for still depend on the counting sort's atomics: the count of pairs left
+                                          // varies by a few in ten thousand from run to run, the results by nothing)
   const int stride = N > 2048 ? N / 2048 : 1;
   const int rows = (N + stride - 1) / stride;
   const int k = (int)threadIdx.x % d, per = 1024 / d;
@@ -79,11 +79,13 @@ static __global__ __launch_bounds__(1024) void k_screen_centre(const float *__re
     const float v = qpar[2 * ((size_t)r * stride * d + k)];
     if (v - v == 0.0f) { s += v; c += 1.0f; }
   }
-  atomicAdd(&sum[k], s);
-  atomicAdd(&cnt[k], c);
+  sum[threadIdx.x] = s;
+  cnt[threadIdx.x] = c;
   __syncthreads();
   if ((int)threadIdx.x < d) {
-    const float mean = cnt[threadIdx.x] > 0.0f ? sum[threadIdx.x] / cnt[threadIdx.x] : 0.0f;
+    float ts = 0.0f, tc = 0.0f;
+    for (int u = 0; u < per; ++u) { ts += sum[u * d + k]; tc += cnt[u * d + k]; }
+    const float mean = tc > 0.0f ? ts / tc : 0.0f;
     centre[threadIdx.x] = (mean - mean == 0.0f) ? mean : 0.0f;
   }
 }

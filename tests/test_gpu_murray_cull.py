@@ -109,3 +109,4 @@ def test_exclusion_keeps_nan_and_degenerate_inputs_identical():
         for a, b, name in zip(rg[:4], ro[:4], ("ptrial", "cfac", "mutrial", "sigtrial")):
             assert same_bits(a, b), (mode, name)
         eg.close()
+
