@@ -233,6 +233,7 @@ struct mcx_engine {
   // host staging
   PinBuf<float> h_ptrial, h_lytrial;
   PinBuf<unsigned long long> h_ctr;  // the run's counters, read back once at its end
+  unsigned long long remote_serial = 0;  // Murray passes so far (what k_remote_decide signs its counters with)
   PinBuf<unsigned long long> h_nact;  // a Murray pass's survivor count (and the exclusion tests' counters)
   std::vector<float> h_cov, h_cov_dev, h_winv;  // h_cov_dev = what cov0 holds
   bool cov_pending = false;  // cov has not been reset to cov0 for the current run yet

@@ -168,11 +168,14 @@ struct RemoteArgs {
   uint32_t g0, t, seed;
   // k_remote_decide's last workgroup hands the pass's counters to the host itself (no copy kernel behind it): `ncounts`
   // 64-bit words from `counts` (the two survivor counters, then the screens' cells) to `counts_host` (pinned, mapped);
-  // `done` counts the workgroups that are through and is left zero.  counts_host null: nothing of the kind.
+  // `done` counts the workgroups that are through and is left zero; then `serial` goes to counts_host[nflag].
+  // counts_host null: nothing of the kind.
   const unsigned long long *counts;
   unsigned long long *counts_host;
   unsigned *done;
   int ncounts;
+  int nflag;                  // counts_host[nflag] takes ...
+  unsigned long long serial;  // ... the pass's serial number after the counters: what the host polls for
 };
 
 // Murray draw for every still-rejected chain (src/mcpar.cc:337-352): pick a component, draw from
@@ -696,6 +699,10 @@ static __global__ void k_remote_decide(const RemoteArgs a)
       a.counts_host[k] = __hip_atomic_load(a.counts + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) *a.done = 0u;
     __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {  // the counters are on their way: now the pass's serial number, which the host spins on
+      __hip_atomic_store(a.counts_host + a.nflag, a.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
