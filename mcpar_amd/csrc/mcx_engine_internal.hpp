@@ -274,7 +274,11 @@ struct mcx_engine {
   mcx_text_sink_fn tfn = nullptr;  // mcx_set_text_sink: the blocks as text instead of rows (one of the two at most)
   DevBuf<unsigned long long> sink_text_wg[2];  // per staging buffer: the text kernels' byte counts / offsets
   PinBuf<unsigned long long> sink_text_total[2];
-  PinBuf<char> sink_text_pin;
+  DevBuf<char> sink_text_dev[2];   // per staging buffer: the block's text on the device ...
+  PinBuf<char> sink_text_pin[2];   // ... and where it lands on the host (copied on tstream, under the next block's formatting)
+  size_t sink_text_bytes[2] = {0, 0};
+  bool sink_text_ok[2] = {false, false};
+  int sink_text_issued = 0;        // blocks of this run whose text has been sent off
   bool run_sink_text = false;        // this run's row sink also gets every block's text (MCX_OPT_SINK_TEXT)
   const char *cb_text = nullptr;     // valid while a sink callback runs: mcx_sink_text
   size_t cb_text_bytes = 0;
@@ -285,6 +289,8 @@ struct mcx_engine {
   int run_sblock = 0, run_kb = 0;  // its block length in steps / in kept steps
   hipStream_t cstream = nullptr;
   hipEvent_t ev_steps[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
+  hipStream_t tstream = nullptr;   // the text's copies to the host
+  hipEvent_t ev_write[2] = {nullptr, nullptr}, ev_text[2] = {nullptr, nullptr};
   DevBuf<float> sink_stage[2];
   PinBuf<float> sink_pin[2];
   DevBuf<float> best_row;            // running maximum-likelihood sample: [0] = log-likelihood, [1..np] = parameters

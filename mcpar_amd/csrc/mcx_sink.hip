@@ -12,6 +12,35 @@
 // waits for THAT copy only; the device ring holds SINK_RING = 4 blocks, so steps are never held up by a slot
 // that is still being read as long as the consumer keeps up).
 // ---------------------------------------------------------------------------------------------
+// Text of block seq: its byte count has arrived (ev_copy), so the fields are formatted once more into place
+// (mcx_text.hpp) on the copy stream and the text leaves on a stream of its own -- the copy of one block (PCIe, 5-6 ms for
+// C3's 287 MB) under the formatting of the next instead of in a row with it.  The staging buffer still holds the rows:
+// the block that reuses it is queued two blocks later, behind this kernel on the same stream.
+static int sink_text_issue(mcx_engine *e, int seq)
+{
+  const int b = seq & 1;
+  HIPCHK(hipEventSynchronize(e->ev_copy[b]));
+  const int first = seq * e->run_kb;
+  const int kept = std::min(e->run_kb, (e->last_sink_total - first));
+  const size_t total = (size_t)e->sink_text_total[b].p[0];
+  const size_t count = (size_t)kept * e->nchain * (size_t)(e->nparam + 1), nwg = (count + BLOCK - 1) / BLOCK;
+  e->sink_text_bytes[b] = total;
+  e->sink_text_ok[b] = false;
+  e->sink_text_issued = seq + 1;
+  int arc = e->sink_text_dev[b].alloc(total + total / 8);
+  if (arc == MCX_OK && total > e->sink_text_pin[b].n) arc = e->sink_text_pin[b].alloc(total + total / 8);
+  if (arc != MCX_OK) return e->tfn ? arc : MCX_OK;  // (a row sink whose block's text found no memory gets its rows all the same)
+  hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
+                     (const float *)nullptr, count, e->nparam, (const unsigned long long *)e->sink_text_wg[b].p, e->sink_text_dev[b].p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev_write[b], e->cstream));
+  HIPCHK(hipStreamWaitEvent(e->tstream, e->ev_write[b], 0));
+  HIPCHK(hipMemcpyAsync(e->sink_text_pin[b].p, e->sink_text_dev[b].p, total, hipMemcpyDeviceToHost, e->tstream));
+  HIPCHK(hipEventRecord(e->ev_text[b], e->tstream));
+  e->sink_text_ok[b] = true;
+  return MCX_OK;
+}
+
 static int sink_deliver(mcx_engine *e, int seq)
 {
   MCXCHK(meet_release(e, false));  // (the consumer may take its time)
@@ -20,26 +49,15 @@ static int sink_deliver(mcx_engine *e, int seq)
   const int first = seq * e->run_kb;  // kept steps before this block
   const int kept = std::min(e->run_kb, (e->last_sink_total - first));
   if (e->tfn || e->run_sink_text) {
-    // text sink: the block's byte count has arrived with the event; now that its size is known, the fields are
-    // formatted once more into place (mcx_text.hpp) and copied out -- the staging buffer still holds the rows (the block
-    // that reuses it is queued only after this call)
-    const size_t total = (size_t)e->sink_text_total[b].p[0];
-    const size_t count = (size_t)kept * e->nchain * (size_t)(e->nparam + 1), nwg = (count + BLOCK - 1) / BLOCK;
-    int arc = e->text_dev.alloc(total);
-    if (arc == MCX_OK && total > e->sink_text_pin.n) arc = e->sink_text_pin.alloc(total + total / 8);
-    if (arc != MCX_OK && e->tfn) return arc;
-    if (arc == MCX_OK) {
-      hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
-                         (const float *)nullptr, count, e->nparam, (const unsigned long long *)e->sink_text_wg[b].p, e->text_dev.p);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(e->sink_text_pin.p, e->text_dev.p, total, hipMemcpyDeviceToHost, e->cstream));
-      HIPCHK(hipStreamSynchronize(e->cstream));
+    if (seq >= e->sink_text_issued) MCXCHK(sink_text_issue(e, seq));  // (the run's last blocks: nothing came after them)
+    if (e->sink_text_ok[b]) {
+      HIPCHK(hipEventSynchronize(e->ev_text[b]));
       if (e->tfn) {
-        if (e->tfn(e->sctx, first, kept, e->sink_text_pin.p, total) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
+        if (e->tfn(e->sctx, first, kept, e->sink_text_pin[b].p, e->sink_text_bytes[b]) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
         return MCX_OK;
       }
-      e->cb_text = e->sink_text_pin.p;  // (row sink with MCX_OPT_SINK_TEXT: the callback asks mcx_sink_text for it)
-      e->cb_text_bytes = total;
+      e->cb_text = e->sink_text_pin[b].p;  // (row sink with MCX_OPT_SINK_TEXT: the callback asks mcx_sink_text for it)
+      e->cb_text_bytes = e->sink_text_bytes[b];
     }
     // (a row sink whose block's text found no memory gets its rows all the same: mcx_sink_text then says so)
   }
@@ -59,18 +77,22 @@ int sink_block_done(mcx_engine *e, int done, int nsteps, int seq)
   const size_t row0 = (size_t)(first_step / e->opt_stride);
   const size_t kept = (size_t)((done + e->opt_stride - 1) / e->opt_stride) - row0;
   const float *sx = vx + row0 * e->ntot, *sl = vl + row0 * n;
-  e->last_sink_total = (int)(row0 + kept);
+  const bool texts = e->tfn || e->run_sink_text;
+  if (seq == 0) e->sink_text_issued = 0;
   // running maximum (src/mcout.cc:140-144), on the step stream: cheap, and ordered before the slot's reuse
   hipLaunchKernelGGL(k_argmax_first, dim3(std::min<unsigned>(nblocks(kept * n), 1024u)), dim3(BLOCK), 0, e->stream, sl, kept * n, e->best_key.p);
   hipLaunchKernelGGL(k_best_update, dim3(1), dim3(BLOCK), 0, e->stream, e->best_key.p, sl, sx, d, e->best_row.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev_steps[b], e->stream));
+  // the previous block's text: formatted and sent off now that its size is known (last_sink_total still counts up to it)
+  if (texts && seq >= 1 && e->sink_text_issued < seq) MCXCHK(sink_text_issue(e, seq - 1));
+  e->last_sink_total = (int)(row0 + kept);
   if (seq >= 2) MCXCHK(sink_deliver(e, seq - 2));  // frees staging buffer b
   HIPCHK(hipStreamWaitEvent(e->cstream, e->ev_steps[b], 0));
   hipLaunchKernelGGL(k_rows_interleave, dim3(nblocks(kept * n * (d + 1))), dim3(BLOCK), 0, e->cstream, sx, sl,
                      e->sink_stage[b].p, kept * n, d);
   HIPCHK(hipGetLastError());
-  if (e->tfn || e->run_sink_text) {  // the size of the block's text (its two counting passes); sink_deliver places and copies it
+  if (texts) {  // the size of the block's text (its two counting passes); sink_text_issue places and copies it
     const size_t count = kept * n * (size_t)(d + 1), nwg = (count + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(k_text_sizes, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
                        (const float *)nullptr, count, d, e->sink_text_wg[b].p);
