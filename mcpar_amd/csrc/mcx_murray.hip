@@ -2,6 +2,8 @@
 // decisions over the kernels of mcx_remote.hpp, with the two exact screens that let a sweep skip rows (boxes of four
 // coordinates: mcx_remote.hpp; one direction: mcx_cull_proj.hpp).  A translation unit of its own: its kernels are the
 // largest of the library after the step kernels.
+#include <atomic>
+
 #include "mcx_engine_internal.hpp"
 #include "mcx_remote.hpp"
 #include "mcx_cull_proj.hpp"
@@ -154,12 +156,13 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
   // The Gaussians' blocks are cut into chunks so that the grid is two chipfuls of workgroups (the kernel's own occupancy
   // x the CUs; one to four chipfuls, or 4096 workgroups whatever the chip holds: the same time within 2 %)
   constexpr int rounds = 2;
-  static int resident = 0;  // (per instantiation: a function-local static of the template)
-  if (!resident) {
-    int nb = 0;
+  static std::atomic<int> blocks_per_cu{0};  // (per instantiation; engines on several threads may ask at once: the same answer)
+  int nb = blocks_per_cu.load(std::memory_order_relaxed);
+  if (!nb) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_screen_gemm<DMAX>, SCR_WAVES * 64, 0) != hipSuccess || nb < 1) nb = 2;
-    resident = nb * (e->ncu > 0 ? e->ncu : 256);
+    blocks_per_cu.store(nb, std::memory_order_relaxed);
   }
+  const int resident = nb * (e->ncu > 0 ? e->ncu : 256);
   const int gx = (ng + SCR_WAVES - 1) / SCR_WAVES;
   const int gy_want = std::max(1, (rounds * resident) / gx);
   int bchunk = (nblk + gy_want - 1) / gy_want;
