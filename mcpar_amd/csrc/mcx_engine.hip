@@ -382,9 +382,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
     if (e->ev_steps[b]) (void)hipEventDestroy(e->ev_steps[b]);
     if (e->ev_copy[b]) (void)hipEventDestroy(e->ev_copy[b]);
     if (e->ev_write[b]) (void)hipEventDestroy(e->ev_write[b]);
-    if (e->ev_text[b]) (void)hipEventDestroy(e->ev_text[b]);
     e->sink_text_dev[b].release();
-    e->sink_text_pin[b].release();
   }
   e->best_row.release(); e->best_key.release(); e->cov0.release();
   for (auto &pr : e->xw_pool) {
@@ -394,6 +392,8 @@ extern "C" int mcx_destroy(mcx_engine *e)
   if (e->meet_fd >= 0) (void)close(e->meet_fd);
   if (e->cstream) (void)hipStreamDestroy(e->cstream);
   if (e->tstream) (void)hipStreamDestroy(e->tstream);
+  if (e->ev_text) (void)hipEventDestroy(e->ev_text);
+  e->sink_text_pin.release();
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MCX_OK;
@@ -779,10 +779,10 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
       if (!e->ev_steps[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_steps[b], hipEventDisableTiming));
       if (!e->ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_copy[b], hipEventDisableTiming));
       if (!e->ev_write[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_write[b], hipEventDisableTiming));
-      if (!e->ev_text[b]) HIPCHK(hipEventCreateWithFlags(&e->ev_text[b], hipEventDisableTiming));
     }
     if (!e->cstream) HIPCHK(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
     if (!e->tstream) HIPCHK(hipStreamCreateWithFlags(&e->tstream, hipStreamNonBlocking));
+    if (!e->ev_text) HIPCHK(hipEventCreateWithFlags(&e->ev_text, hipEventDisableTiming));
   }
   MCXCHK(e->best_row.alloc((size_t)d + 1));
   MCXCHK(e->best_key.alloc(1));

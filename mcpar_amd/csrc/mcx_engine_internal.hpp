@@ -275,10 +275,10 @@ struct mcx_engine {
   DevBuf<unsigned long long> sink_text_wg[2];  // per staging buffer: the text kernels' byte counts / offsets
   PinBuf<unsigned long long> sink_text_total[2];
   DevBuf<char> sink_text_dev[2];   // per staging buffer: the block's text on the device ...
-  PinBuf<char> sink_text_pin[2];   // ... and where it lands on the host (copied on tstream, under the next block's formatting)
+  PinBuf<char> sink_text_pin;      // ... and where it lands on the host (copied on tstream, under the next block's formatting)
   size_t sink_text_bytes[2] = {0, 0};
   bool sink_text_ok[2] = {false, false};
-  int sink_text_issued = 0;        // blocks of this run whose text has been sent off
+  int sink_text_written = 0, sink_text_copied = 0;  // blocks of this run whose text has been formatted / sent off
   bool run_sink_text = false;        // this run's row sink also gets every block's text (MCX_OPT_SINK_TEXT)
   const char *cb_text = nullptr;     // valid while a sink callback runs: mcx_sink_text
   size_t cb_text_bytes = 0;
@@ -290,7 +290,7 @@ struct mcx_engine {
   hipStream_t cstream = nullptr;
   hipEvent_t ev_steps[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
   hipStream_t tstream = nullptr;   // the text's copies to the host
-  hipEvent_t ev_write[2] = {nullptr, nullptr}, ev_text[2] = {nullptr, nullptr};
+  hipEvent_t ev_write[2] = {nullptr, nullptr}, ev_text = nullptr;
   DevBuf<float> sink_stage[2];
   PinBuf<float> sink_pin[2];
   DevBuf<float> best_row;            // running maximum-likelihood sample: [0] = log-likelihood, [1..np] = parameters

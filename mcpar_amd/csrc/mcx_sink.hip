@@ -12,11 +12,13 @@
 // waits for THAT copy only; the device ring holds SINK_RING = 4 blocks, so steps are never held up by a slot
 // that is still being read as long as the consumer keeps up).
 // ---------------------------------------------------------------------------------------------
-// Text of block seq: its byte count has arrived (ev_copy), so the fields are formatted once more into place
-// (mcx_text.hpp) on the copy stream and the text leaves on a stream of its own -- the copy of one block (PCIe, 5-6 ms for
-// C3's 287 MB) under the formatting of the next instead of in a row with it.  The staging buffer still holds the rows:
-// the block that reuses it is queued two blocks later, behind this kernel on the same stream.
-static int sink_text_issue(mcx_engine *e, int seq)
+// Text of block seq, in two moves.  (1) Its byte count has arrived (ev_copy), so the fields are formatted once more into
+// place (mcx_text.hpp) on the copy stream -- one block after its rows were staged, while the block before it is still on
+// its way to the host.  The staging buffer still holds the rows: the block that reuses it is queued two blocks later,
+// behind this kernel on the same stream.  (2) The text leaves on a stream of its own as soon as the consumer has
+// returned the one pinned buffer (pinning a second gigabyte costs a one-shot driver more than the overlap saves it):
+// the copy of a block (PCIe, 5-6 ms for C3's 287 MB) runs under the formatting of the next.
+static int sink_text_write(mcx_engine *e, int seq)
 {
   const int b = seq & 1;
   HIPCHK(hipEventSynchronize(e->ev_copy[b]));
@@ -26,18 +28,33 @@ static int sink_text_issue(mcx_engine *e, int seq)
   const size_t count = (size_t)kept * e->nchain * (size_t)(e->nparam + 1), nwg = (count + BLOCK - 1) / BLOCK;
   e->sink_text_bytes[b] = total;
   e->sink_text_ok[b] = false;
-  e->sink_text_issued = seq + 1;
-  int arc = e->sink_text_dev[b].alloc(total + total / 8);
-  if (arc == MCX_OK && total > e->sink_text_pin[b].n) arc = e->sink_text_pin[b].alloc(total + total / 8);
+  e->sink_text_written = seq + 1;
+  const int arc = e->sink_text_dev[b].alloc(total + total / 8);
   if (arc != MCX_OK) return e->tfn ? arc : MCX_OK;  // (a row sink whose block's text found no memory gets its rows all the same)
   hipLaunchKernelGGL(k_text_write, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
                      (const float *)nullptr, count, e->nparam, (const unsigned long long *)e->sink_text_wg[b].p, e->sink_text_dev[b].p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev_write[b], e->cstream));
-  HIPCHK(hipStreamWaitEvent(e->tstream, e->ev_write[b], 0));
-  HIPCHK(hipMemcpyAsync(e->sink_text_pin[b].p, e->sink_text_dev[b].p, total, hipMemcpyDeviceToHost, e->tstream));
-  HIPCHK(hipEventRecord(e->ev_text[b], e->tstream));
   e->sink_text_ok[b] = true;
+  return MCX_OK;
+}
+
+static int sink_text_copy(mcx_engine *e, int seq)
+{
+  const int b = seq & 1;
+  e->sink_text_copied = seq + 1;
+  if (!e->sink_text_ok[b]) return MCX_OK;
+  const size_t total = e->sink_text_bytes[b];
+  if (total > e->sink_text_pin.n) {
+    const int arc = e->sink_text_pin.alloc(total + total / 8);
+    if (arc != MCX_OK) {
+      e->sink_text_ok[b] = false;
+      return e->tfn ? arc : MCX_OK;
+    }
+  }
+  HIPCHK(hipStreamWaitEvent(e->tstream, e->ev_write[b], 0));
+  HIPCHK(hipMemcpyAsync(e->sink_text_pin.p, e->sink_text_dev[b].p, total, hipMemcpyDeviceToHost, e->tstream));
+  HIPCHK(hipEventRecord(e->ev_text, e->tstream));
   return MCX_OK;
 }
 
@@ -48,22 +65,29 @@ static int sink_deliver(mcx_engine *e, int seq)
   HIPCHK(hipEventSynchronize(e->ev_copy[b]));
   const int first = seq * e->run_kb;  // kept steps before this block
   const int kept = std::min(e->run_kb, (e->last_sink_total - first));
-  if (e->tfn || e->run_sink_text) {
-    if (seq >= e->sink_text_issued) MCXCHK(sink_text_issue(e, seq));  // (the run's last blocks: nothing came after them)
+  const bool texts = e->tfn || e->run_sink_text;
+  if (texts) {
+    if (seq >= e->sink_text_written) MCXCHK(sink_text_write(e, seq));  // (the run's last blocks: nothing came after them)
+    if (seq >= e->sink_text_copied) MCXCHK(sink_text_copy(e, seq));
     if (e->sink_text_ok[b]) {
-      HIPCHK(hipEventSynchronize(e->ev_text[b]));
+      HIPCHK(hipEventSynchronize(e->ev_text));
       if (e->tfn) {
-        if (e->tfn(e->sctx, first, kept, e->sink_text_pin[b].p, e->sink_text_bytes[b]) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
-        return MCX_OK;
+        if (e->tfn(e->sctx, first, kept, e->sink_text_pin.p, e->sink_text_bytes[b]) != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
+      } else {
+        e->cb_text = e->sink_text_pin.p;  // (row sink with MCX_OPT_SINK_TEXT: the callback asks mcx_sink_text for it)
+        e->cb_text_bytes = e->sink_text_bytes[b];
       }
-      e->cb_text = e->sink_text_pin[b].p;  // (row sink with MCX_OPT_SINK_TEXT: the callback asks mcx_sink_text for it)
-      e->cb_text_bytes = e->sink_text_bytes[b];
     }
     // (a row sink whose block's text found no memory gets its rows all the same: mcx_sink_text then says so)
   }
-  const int rc = e->sfn(e->sctx, first, kept, e->sink_pin[b].p);
-  e->cb_text = nullptr;
-  e->cb_text_bytes = 0;
+  int rc = 0;
+  if (!e->tfn) {
+    rc = e->sfn(e->sctx, first, kept, e->sink_pin[b].p);
+    e->cb_text = nullptr;
+    e->cb_text_bytes = 0;
+  }
+  // the pinned buffer is free again: the next block's text, formatted by now, may follow
+  if (texts && rc == 0 && seq + 1 < e->sink_text_written && seq + 1 >= e->sink_text_copied) MCXCHK(sink_text_copy(e, seq + 1));
   if (rc != 0) return fail(MCX_ERR_INVALID, "sample sink failed");
   return MCX_OK;
 }
@@ -78,21 +102,22 @@ int sink_block_done(mcx_engine *e, int done, int nsteps, int seq)
   const size_t kept = (size_t)((done + e->opt_stride - 1) / e->opt_stride) - row0;
   const float *sx = vx + row0 * e->ntot, *sl = vl + row0 * n;
   const bool texts = e->tfn || e->run_sink_text;
-  if (seq == 0) e->sink_text_issued = 0;
+  if (seq == 0) e->sink_text_written = e->sink_text_copied = 0;
   // running maximum (src/mcout.cc:140-144), on the step stream: cheap, and ordered before the slot's reuse
   hipLaunchKernelGGL(k_argmax_first, dim3(std::min<unsigned>(nblocks(kept * n), 1024u)), dim3(BLOCK), 0, e->stream, sl, kept * n, e->best_key.p);
   hipLaunchKernelGGL(k_best_update, dim3(1), dim3(BLOCK), 0, e->stream, e->best_key.p, sl, sx, d, e->best_row.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev_steps[b], e->stream));
   // the previous block's text: formatted and sent off now that its size is known (last_sink_total still counts up to it)
-  if (texts && seq >= 1 && e->sink_text_issued < seq) MCXCHK(sink_text_issue(e, seq - 1));
+  if (texts && seq >= 1 && e->sink_text_written < seq) MCXCHK(sink_text_write(e, seq - 1));
+  if (texts && seq == 1) MCXCHK(sink_text_copy(e, 0));  // (the first block's: nobody holds the pinned buffer yet)
   e->last_sink_total = (int)(row0 + kept);
   if (seq >= 2) MCXCHK(sink_deliver(e, seq - 2));  // frees staging buffer b
   HIPCHK(hipStreamWaitEvent(e->cstream, e->ev_steps[b], 0));
   hipLaunchKernelGGL(k_rows_interleave, dim3(nblocks(kept * n * (d + 1))), dim3(BLOCK), 0, e->cstream, sx, sl,
                      e->sink_stage[b].p, kept * n, d);
   HIPCHK(hipGetLastError());
-  if (texts) {  // the size of the block's text (its two counting passes); sink_text_issue places and copies it
+  if (texts) {  // the size of the block's text (its two counting passes); sink_text_write / _copy place and send it
     const size_t count = kept * n * (size_t)(d + 1), nwg = (count + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(k_text_sizes, dim3((unsigned)nwg), dim3(BLOCK), 0, e->cstream, (const float *)e->sink_stage[b].p,
                        (const float *)nullptr, count, d, e->sink_text_wg[b].p);
