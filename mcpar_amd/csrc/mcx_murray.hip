@@ -351,6 +351,9 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       // stream now and then, so that a launch that failed or a device that is gone ends the wait
       volatile unsigned long long *const flag = back + a.nflag;
       for (unsigned spins = 0; __atomic_load_n(const_cast<unsigned long long *>(flag), __ATOMIC_ACQUIRE) != a.serial; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();  // (the sibling hyperthread and the other engines' threads get the core's issue slots)
+#endif
         if ((spins & 0xfffu) == 0xfffu) {
           const hipError_t q = hipStreamQuery(st);
           if (q == hipSuccess) break;  // the stream is empty: the word is there (or never will be: checked below)
