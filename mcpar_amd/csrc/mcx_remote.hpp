@@ -654,7 +654,7 @@ static __global__ void k_remote_decide(const RemoteArgs a)
     float qs = FPEPS, qm = FPEPS;  // src/mcpar.cc:355-365
     // The partials are added in block order (the arithmetic contract), but they are REQUESTED 16 blocks at a time:
     // a 65 536-chain pass reads 134 MB here with one wavefront per SIMD, so the loads in flight per lane are its speed
-    // (66 -> 14 us).
+    // (66 -> 14 us; 64 at a time for the late passes over a few hundred chains: 13 -> 18 us, no).
     constexpr int U = 16;
     const float *ps = a.psum + i, *pm = a.pmax + i;
     int sb = 0;
