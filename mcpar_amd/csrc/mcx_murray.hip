@@ -348,7 +348,8 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       // k_remote_decide's last workgroup writes the counters, then the pass's serial number: spinning on that word
       // instead of a copy kernel and a wait for the stream (once per pass, 30-50 passes per job; against the copy and
       // the wait on one box: C3-murray 16.2 -> 16.1 ms, C5 23.6 -> 23.4: the counters' way over PCIe is 6-11 us of the
-      // kernel now, what the copy kernel and its launch were) -- with a look at the stream now and then, so that a launch that failed or a device that is gone ends the wait
+      // kernel now, what the copy kernel and its launch were) -- with a look at the stream now and then, so that a
+      // launch that failed or a device that is gone ends the wait
       volatile unsigned long long *const flag = back + a.nflag;
       for (unsigned spins = 0; __atomic_load_n(const_cast<unsigned long long *>(flag), __ATOMIC_ACQUIRE) != a.serial; ++spins) {
 #if defined(__x86_64__) || defined(__i386__)
