@@ -238,9 +238,12 @@ typedef struct mcx_counters {
   uint64_t remote_pairs; /* (chain, Q_i) pairs of the Murray sweeps as the reference loops over them: sum over
                             passes of n_active * N, plus n * N per genRemote call for the cfac numerator
                             (src/mcpar.cc:367-395, 421-437) */
-  uint64_t remote_pairs_evaluated; /* of those, the pairs whose arg the sweep kernels actually started to
-                            accumulate: the rest were excluded by an exact bound (their Q_i is exactly 0, or
-                            cannot lower the running minimum) before any per-pair work */
+  uint64_t remote_pairs_evaluated; /* the pairs whose arg the sweep kernels actually started to accumulate: the
+                            rest were excluded by an exact bound (their Q_i is exactly 0, or cannot lower the running
+                            minimum) before any per-pair work.  The late passes over a few hundred chains sweep the
+                            next four passes' proposals at once (same results, same pass count): proposals a chain
+                            then did not need are counted here and not in remote_pairs, so without a screen the
+                            ratio of the two is a little above 1 */
   uint64_t meet_timeouts; /* runs repeated on the per-segment kernels because a tuner meeting of the one-launch
                             small-n kernel was abandoned (MCX_OPT_MEET_TIMEOUT_MS) */
   /* ABI 4 */

@@ -330,7 +330,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   if (st == MCX_OK && hipMemset(e->tun_cells.p, 0, (TUN_CELLS + 1) * sizeof(unsigned long long)) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipMemset failed");
   A(e->active0.alloc(n)); A(e->active1.alloc(n)); A(e->ntrace.alloc(1));
-  A(e->nact.alloc(2 * (1 + 2 * NACT_CULL_CELLS) + 2));  // (+ the word k_remote_decide counts its workgroups in)
+  A(e->nact.alloc(2 * (1 + 2 * NACT_CULL_CELLS) + 2 + 8));  // (+ the word k_remote_decide counts its workgroups in, + its tried[])
   if (st == MCX_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     st = fail(MCX_ERR_HIP, "hipStreamCreate failed");
   if (st != MCX_OK) { mcx_destroy(e); return st; }
@@ -371,7 +371,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->cull_keys.release(); e->cull_hist.release(); e->cull_sorted.release(); e->cull_stats.release(); e->cull_box.release();
-  e->cull_lim.release(); e->cull_excl.release(); e->scr_a.release(); e->scr_b.release(); e->scr_centre.release(); e->proj_acc.release(); e->proj_p.release(); e->proj_lohi.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
+  e->cull_lim.release(); e->cull_excl.release(); e->scr_a.release(); e->scr_b.release(); e->scr_centre.release(); e->cand.release(); e->proj_acc.release(); e->proj_p.release(); e->proj_lohi.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
   e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release(); e->deal_tab.release(); e->trace_clk.release();
   for (int b = 0; b < 2; ++b) {

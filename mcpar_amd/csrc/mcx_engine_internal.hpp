@@ -223,6 +223,7 @@ struct mcx_engine {
   DevBuf<unsigned long long> cull_excl;
   DevBuf<unsigned short> scr_a, scr_b;  // mcx_screen.hpp: A' per position of the sorted list, B' per Gaussian (bf16)
   DevBuf<float> scr_centre;
+  DevBuf<float> cand;  // Murray passes over few chains: the next passes' proposals (p, mu, sig per candidate, then racpt)
   int opt_cull = -1;  // -1 auto (the per-pair bound: many chains, many Gaussians, np = 16 or 32), 0 off, whenever the kernels
                       // allow: 1 boxes, 2 one direction (mcx_cull_proj.hpp), 3 the per-pair bound (mcx_screen.hpp)
   int cull_skip[2] = {0, 0};  // auto mode: genRemote calls for which the min-arg / sum sweeps go without the test,

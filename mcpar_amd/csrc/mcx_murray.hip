@@ -13,6 +13,14 @@ static_assert(NACT_CULL_CELLS == CULL_NCOUNT, "mcx_engine::nact is sized for the
 
 constexpr int SROW_UNMASKED_MAX_CHAINS = 8192;  // see launch_sweep_exact
 constexpr int SROW_MAX_BLOCKS_PER_WAVE = 8;
+// Few chains left (the late rejection passes: a few hundred chains, then tens, then a handful -- three or four passes per
+// Murray step that cost 60-75 us each whatever they sweep, launches and one wait for the host): MULTI_K passes at once.
+// The proposal and the test of pass p for chain j are functions of (step, j, p) and of sums over all Gaussians, not of
+// what other chains or earlier passes did, so the next MULTI_K proposals of every remaining chain are drawn, swept and
+// tested together and each chain takes the first that passes: same proposals, same tests, same order -- same bits, and
+// the pass count the reference would have reached.
+constexpr int MULTI_MAX_CHAINS = 1024, MULTI_K = 4;  // (from 128 / 448 / 1024 / 2048 chains: C3-murray 15.66 / 15.47 / 15.45 /
+                                                     // 15.47 ms, C5 23.10 / 22.15 / 21.93 / 22.12; never: 16.7 / 23.9)
 
 // the all-pairs sweep over chains whose np is a power of two (d == DMAX): one or two chains per lane (SWEEP_CPL).
 // Workgroups of 512 / 1024 threads (fewer copies of a block's Gaussians staged through LDS) were measured on the
@@ -123,7 +131,7 @@ static int cull_prepare_proj(mcx_engine *e, const float *xrows, const int *ain, 
 // are cut from (the sorted list, or `ain` itself -- null = every chain in index order -- where nothing was sorted).
 template <int DMAX>
 static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, bool *fresh_q,
-                          const int **order_out, hipStream_t st)
+                          const int **order_out, hipStream_t st, bool may_sort = true)
 {
   const int d = e->nparam, N = e->tchains;
   const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64, nblk = (N + SCR_BLK - 1) / SCR_BLK;
@@ -135,7 +143,7 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
     *fresh_q = false;
   }
   const int *order = ain;  // (few chains: in the order they come)
-  if (nact >= SCREEN_SORT_MIN_CHAINS) {
+  if (may_sort && nact >= SCREEN_SORT_MIN_CHAINS) {
     hipLaunchKernelGGL(k_cull_stats, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p);
     hipLaunchKernelGGL(k_cull_keys, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, xrows, ain, nact, d, e->cull_stats.p,
                        e->cull_keys.p, e->cull_hist.p);
@@ -189,10 +197,12 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     return fail(MCX_ERR_UNSUPPORTED, "Murray proposals over %d chains in all: at most %d", N, 65535 * QBLOCK);
   hipStream_t st = e->stream;
   ProfScope ps(e, MCX_K_REMOTE, (uint64_t)n);
+  const size_t rows_max = std::max<size_t>((size_t)n, (size_t)MULTI_MAX_CHAINS * MULTI_K);  // chains, or candidates of few chains
   if (!big) {
-    MCXCHK(e->psum.alloc((size_t)n * S));
-    MCXCHK(e->pmax.alloc((size_t)n * S));
+    MCXCHK(e->psum.alloc(rows_max * S));
+    MCXCHK(e->pmax.alloc(rows_max * S));
     MCXCHK(e->racpt.alloc((size_t)n));
+    MCXCHK(e->cand.alloc((size_t)MULTI_MAX_CHAINS * MULTI_K * (3 * (size_t)d + 1)));
   }
   // exclusion of far Gaussians: the two-chains-per-lane sweeps (np = 16, 32) over enough chains and Gaussians to
   // pay for the sort and the tests (or whenever possible: MCX_OPT_CULL = 1, for the tests)
@@ -202,9 +212,9 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     return cull_can && (e->opt_cull > 0 || (na >= (gemm ? SCREEN_MIN_CHAINS : CULL_MIN_CHAINS) && N >= CULL_MIN_GAUSSIANS));
   };
   if (cull_can) {
-    const size_t ngmax = ((size_t)n + CULL_W - 1) / CULL_W, nw = ((size_t)N + 63) / 64;
+    const size_t ngmax = (rows_max + CULL_W - 1) / CULL_W, nw = ((size_t)N + 63) / 64;
     const bool fresh = !e->cull_hist.p || !e->cull_stats.p;
-    MCXCHK(e->cull_keys.alloc((size_t)n)); MCXCHK(e->cull_hist.alloc(CULL_BINS)); MCXCHK(e->cull_sorted.alloc((size_t)n));
+    MCXCHK(e->cull_keys.alloc(rows_max)); MCXCHK(e->cull_hist.alloc(CULL_BINS)); MCXCHK(e->cull_sorted.alloc(rows_max));
     MCXCHK(e->cull_stats.alloc(2 * CULL_KD));
     if (fresh) {  // (k_cull_boxes leaves them zero for the next sort)
       HIPCHK(hipMemsetAsync(e->cull_stats.p, 0, 2 * CULL_KD * sizeof(float), st));
@@ -212,7 +222,7 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     } MCXCHK(e->cull_box.alloc(ngmax * 2 * CULL_KD)); MCXCHK(e->cull_lim.alloc(ngmax));
     MCXCHK(e->cull_excl.alloc(ngmax * nw));
     const bool fresh_p = !e->proj_acc.p;
-    MCXCHK(e->proj_acc.alloc(2 * PROJ_ACC)); MCXCHK(e->proj_p.alloc((size_t)n)); MCXCHK(e->proj_lohi.alloc(2 * ngmax));
+    MCXCHK(e->proj_acc.alloc(2 * PROJ_ACC)); MCXCHK(e->proj_p.alloc(rows_max)); MCXCHK(e->proj_lohi.alloc(2 * ngmax));
     if (fresh_p) HIPCHK(hipMemsetAsync(e->proj_acc.p, 0, 2 * PROJ_ACC * sizeof(double), st));
     MCXCHK(e->scr_centre.alloc(64)); MCXCHK(e->scr_a.alloc(ngmax * CULL_W * scr_k(dm)));
     MCXCHK(e->scr_b.alloc((((size_t)N + SCR_BLK - 1) / SCR_BLK) * SCR_BLK * scr_k(dm)));
@@ -279,18 +289,21 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
   int nact = n, pass = 0;
   int *ain = nullptr, *aout = e->active0.p;
   unsigned long long kept_min = 0, kept_sums = 0;
+  constexpr int NCOUNTS_ALL = 1 + 2 * CULL_NCOUNT + 1 + MULTI_K / 2;  // survivors, the screens' cells, `done`, tried[MULTI_K]
   if (!e->h_nact.p) {  // pinned and mapped: k_remote_decide writes the pass's counters and serial there
-    MCXCHK(e->h_nact.alloc(2 + 2 * CULL_NCOUNT));
-    memset(e->h_nact.p, 0, (2 + 2 * CULL_NCOUNT) * sizeof(unsigned long long));
+    MCXCHK(e->h_nact.alloc(NCOUNTS_ALL + 1));
+    memset(e->h_nact.p, 0, (NCOUNTS_ALL + 1) * sizeof(unsigned long long));
   }
+  int it = 0;  // kernels' turns (a turn over candidates stands for several passes)
   while (nact > 0) {
+    const bool multi = !big && pass > 0 && nact <= MULTI_MAX_CHAINS;
     // two survivor counters in turn: a pass counts in one and zeroes the other for the next pass (the first pass's
     // draw zeroes its own) -- no fill between the passes
-    int *const cnt_here = e->nact.p + (pass & 1);
+    int *const cnt_here = e->nact.p + (it & 1);
     if (big) HIPCHK(hipMemsetAsync(cnt_here, 0, sizeof(int), st));
     RemoteArgs a;
     a.active_in = ain; a.nact = nact; a.active_out = aout; a.nact_out = cnt_here;
-    a.nact_zero = big ? nullptr : e->nact.p + ((pass + 1) & 1);
+    a.nact_zero = big ? nullptr : e->nact.p + ((it + 1) & 1);
     a.musigall = musigall; a.winv = e->winvall.p; a.cmax = e->cmax.p;
     a.ptrial = ptrial; a.mutrial = mutrial; a.sigtrial = sigtrial; a.cfac = cfac;
     a.racpt = e->racpt.p; a.psum = e->psum.p; a.pmax = e->pmax.p;
@@ -299,12 +312,43 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     a.counts = reinterpret_cast<const unsigned long long *>(e->nact.p);
     a.counts_host = big ? nullptr : e->h_nact.p;  // (np > 64: no k_remote_decide; the copy below)
     a.done = reinterpret_cast<unsigned *>(e->nact.p) + 2 * (1 + 2 * NACT_CULL_CELLS);
-    a.ncounts = cull_can ? 1 + 2 * CULL_NCOUNT : 1;
-    a.nflag = 1 + 2 * CULL_NCOUNT;  // (a word of its own whatever ncounts is: serial numbers only ever grow there)
+    a.ncounts = multi ? NCOUNTS_ALL : (cull_can ? 1 + 2 * CULL_NCOUNT : 1);
+    a.nflag = NCOUNTS_ALL;  // (a word of its own whatever ncounts is: serial numbers only ever grow there)
     a.serial = ++e->remote_serial;
+    a.ncand = MULTI_K;
+    a.cand_p = e->cand.p;
+    a.cand_mu = a.cand_p + (size_t)MULTI_MAX_CHAINS * MULTI_K * d;
+    a.cand_sig = a.cand_mu + (size_t)MULTI_MAX_CHAINS * MULTI_K * d;
+    a.cand_racpt = a.cand_sig + (size_t)MULTI_MAX_CHAINS * MULTI_K * d;
+    a.tried = e->nact.p + 2 * (1 + 2 * NACT_CULL_CELLS) + 2;
     if (big) {
       hipLaunchKernelGGL(k_remote_pass_big, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
       evaluated_host += (uint64_t)nact * (uint64_t)N;
+    } else if (multi) {
+      const int nv = nact * MULTI_K;
+      hipLaunchKernelGGL(k_remote_draw_multi, dim3(nblocks((size_t)nv)), dim3(BLOCK), 0, st, a);
+      const bool cull = gemm && cull_now(nv) && cull_sums;  // (the other screens sort, and the candidates keep their rows)
+      const int *list = nullptr;
+      const unsigned long long *excl = nullptr;
+      if (cull) {
+        DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, a.cand_p, nullptr, nv, true, -1, &fresh_q, &list, st, false))));
+        excl = e->cull_excl.p;
+      } else {
+        evaluated_host += (uint64_t)nv * (uint64_t)N;
+      }
+      {
+        ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)nv * (uint64_t)N);
+        if (d == dm) {
+          DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, true>(a.cand_p, list, nv, e->winvall.p, e->psum.p, e->pmax.p, N,
+                                                            -1, excl, (nv + CULL_W - 1) / CULL_W, S, st)));
+        } else {
+          DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_sweep<DMAX_, true, false>), dim3(nblocks((size_t)nv), S), dim3(BLOCK),
+                                               0, st, (const float *)a.cand_p, (const int *)nullptr, nv, e->winvall.p,
+                                               e->psum.p, e->pmax.p, d, N, -1, (const unsigned long long *)nullptr, 0));
+        }
+      }
+      static_assert(MULTI_K == 4, "k_remote_decide_multi: a chain's candidates are a quad of lanes");
+      hipLaunchKernelGGL(k_remote_decide_multi, dim3(nblocks((size_t)nv)), dim3(BLOCK), 0, st, a);
     } else {
       // (later passes: the k_remote_decide that rejected a chain has drawn its next proposal already)
       if (pass == 0) DISPATCH_DMAX(dm, hipLaunchKernelGGL((k_remote_draw<DMAX_>), dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a));
@@ -339,7 +383,7 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       hipLaunchKernelGGL(k_remote_decide, dim3(nblocks((size_t)nact)), dim3(BLOCK), 0, st, a);
     }
     HIPCHK(hipGetLastError());
-    e->cnt.remote_pairs += (uint64_t)nact * (uint64_t)N;
+    if (!multi) e->cnt.remote_pairs += (uint64_t)nact * (uint64_t)N;  // (candidates: what the passes would have swept, below)
     unsigned long long *back = e->h_nact.p;  // survivors (low word), cells of the pairs kept by the min-arg / sum tests so far
     if (big) {
       HIPCHK(hipMemcpyAsync(back, e->nact.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -368,8 +412,20 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       }
     }
     const unsigned long long before = kept_sums;
-    const uint64_t pairs_now = (uint64_t)nact * (uint64_t)N;
-    nact = (int)(unsigned)((pass & 1) ? back[0] >> 32 : back[0] & 0xffffffffull);
+    const uint64_t pairs_now = (uint64_t)nact * (uint64_t)N * (multi ? MULTI_K : 1);
+    nact = (int)(unsigned)((it & 1) ? back[0] >> 32 : back[0] & 0xffffffffull);
+    int passes_now = 1;
+    if (multi) {
+      // tried[c] chains came as far as candidate c: pass + c would have swept them.  Survivors tried them all.
+      const unsigned *tried = reinterpret_cast<const unsigned *>(back + 1 + 2 * CULL_NCOUNT + 1);
+      passes_now = 0;
+      for (int c = 0; c < MULTI_K; ++c)
+        if (tried[c]) {
+          passes_now = c + 1;
+          e->cnt.remote_pairs += (uint64_t)tried[c] * (uint64_t)N;
+        }
+      if (nact > 0) passes_now = MULTI_K;
+    }
     if (cull_can) {
       kept_min = kept_sums = 0;
       for (int c = 0; c < CULL_NCOUNT; ++c) { kept_min += back[1 + c]; kept_sums += back[1 + CULL_NCOUNT + c]; }
@@ -381,7 +437,8 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     ain = aout;
     aout = (aout == e->active0.p) ? e->active1.p : e->active0.p;
     e->cnt.kernel_launches += (big || pass > 0) ? 1 : 2;  // (+1: the sweep's own scope)
-    ++pass;
+    pass += passes_now;
+    ++it;
   }
   e->cnt.remote_pairs_evaluated += evaluated_host + (uint64_t)kept_min + (uint64_t)kept_sums;
   if (e->opt_cull < 0) {

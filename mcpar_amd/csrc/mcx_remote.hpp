@@ -176,11 +176,17 @@ struct RemoteArgs {
   int ncounts;
   int nflag;                  // counts_host[nflag] takes ...
   unsigned long long serial;  // ... the pass's serial number after the counters: what the host polls for
+  // Several passes at once over few chains (k_remote_draw_multi / k_remote_decide_multi): candidate c of the chain at
+  // position i of the active list is the proposal pass + c would draw for it, kept in row i * ncand + c of these
+  float *cand_p, *cand_mu, *cand_sig, *cand_racpt;
+  int *tried;  // [ncand]: chains that came as far as candidate c (what pass + c would have had to sweep)
+  int ncand;
 };
 
 // Murray draw for every still-rejected chain (src/mcpar.cc:337-352): pick a component, draw from
 // its diagonal Gaussian, keep (mutrial, sigtrial); one lane per chain.
-__device__ __forceinline__ void remote_draw_one(const RemoteArgs &a, int j, int pass)
+__device__ __forceinline__ void remote_draw_row(const RemoteArgs &a, int j, int pass, float *__restrict__ p, float *__restrict__ mu,
+                                                float *__restrict__ sig, float *__restrict__ racpt)
 {
   const int d = a.d;
   const uint32_t g = a.g0 + (uint32_t)j;
@@ -195,13 +201,18 @@ __device__ __forceinline__ void remote_draw_one(const RemoteArgs &a, int j, int 
       if (k < d) {  // src/mcpar.cc:339-352
         const float m = a.musigall[2 * ((size_t)sel * d + k)];
         const float sg = __builtin_sqrtf(a.musigall[2 * ((size_t)sel * d + k) + 1]);
-        a.mutrial[(size_t)j * d + k] = m;
-        a.sigtrial[(size_t)j * d + k] = sg;
-        a.ptrial[(size_t)j * d + k] = __builtin_fmaf(sg, z[c], m);
+        mu[k] = m;
+        sig[k] = sg;
+        p[k] = __builtin_fmaf(sg, z[c], m);
       }
     }
   }
-  a.racpt[j] = u24(w.y);  // src/mcpar.cc:401
+  *racpt = u24(w.y);  // src/mcpar.cc:401
+}
+__device__ __forceinline__ void remote_draw_one(const RemoteArgs &a, int j, int pass)
+{
+  const size_t o = (size_t)j * a.d;
+  remote_draw_row(a, j, pass, a.ptrial + o, a.mutrial + o, a.sigtrial + o, a.racpt + j);
 }
 
 // the first pass of a Murray step draws for every chain; later passes are drawn by the k_remote_decide that rejected them
@@ -212,6 +223,18 @@ __global__ __launch_bounds__(BLOCK) void k_remote_draw(const RemoteArgs a)
   if (i == 0) *a.nact_out = 0;  // (this pass's decide counts its survivors there)
   if (i >= a.nact) return;
   remote_draw_one(a, a.active_in ? a.active_in[i] : i, a.pass);
+}
+
+// Few chains left: the proposals of this pass AND of the ncand - 1 passes behind it, for every still-rejected chain --
+// they depend on (step, chain, pass) only, not on what the passes before them decided.  One lane per candidate.
+static __global__ __launch_bounds__(BLOCK) void k_remote_draw_multi(const RemoteArgs a)
+{
+  const int v = blockIdx.x * BLOCK + threadIdx.x;
+  if (v < a.ncand) a.tried[v] = 0;
+  if (v >= a.nact * a.ncand) return;
+  const int i = v / a.ncand, c = v - i * a.ncand;
+  const size_t o = (size_t)v * a.d;
+  remote_draw_row(a, a.active_in ? a.active_in[i] : i, a.pass + c, a.cand_p + o, a.cand_mu + o, a.cand_sig + o, a.cand_racpt + v);
 }
 
 // The all-pairs sweep (src/mcpar.cc:367-395 for ptrial, :421-437 for pvals): lanes = chains (vector
@@ -645,6 +668,30 @@ __device__ __forceinline__ int wave_slot(int *counter)
   return base + (int)__popcll(callers & ((1ull << lane) - 1ull));
 }
 
+// the last workgroup of a deciding kernel copies the pass's counters out: what the host waits for is this kernel, not a
+// copy behind it
+__device__ __forceinline__ void decide_hand_over(const RemoteArgs &a)
+{
+  if (!a.counts_host) return;
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(a.done, 1u) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  if (last) {
+    for (int k = (int)threadIdx.x; k < a.ncounts; k += (int)blockDim.x)
+      a.counts_host[k] = __hip_atomic_load(a.counts + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) *a.done = 0u;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {  // the counters are on their way: now the pass's serial number, which the host spins on
+      __hip_atomic_store(a.counts_host + a.nflag, a.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // rejection test of the pass (src/mcpar.cc:397-441); survivors are compacted for the next pass
 static __global__ void k_remote_decide(const RemoteArgs a)
 {
@@ -685,25 +732,69 @@ static __global__ void k_remote_decide(const RemoteArgs a)
       remote_draw_one(a, j, a.pass + 1);  // rejected: its next proposal, now (src/mcpar.cc:337-352 of the next pass)
     }
   }
-  if (!a.counts_host) return;
-  // the last workgroup through copies the counters out: what the host waits for is this kernel, not a copy behind it
-  __shared__ int last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last = atomicAdd(a.done, 1u) == gridDim.x - 1u;
+  decide_hand_over(a);
+}
+
+// The same over candidates (k_remote_draw_multi): a chain takes the first of its ncand proposals that passes its test --
+// what ncand passes one after the other would have done, every test being a function of (step, chain, pass) and of the
+// sums over ALL Gaussians only -- and is a survivor if none does.  tried[c] counts the chains that got as far as
+// candidate c: the chains pass + c would have swept.  One lane per CANDIDATE (the four of a chain are a quad of lanes:
+// their sums are read side by side, not one after the other), ncand == 4.
+static __global__ __launch_bounds__(BLOCK) void k_remote_decide_multi(const RemoteArgs a)
+{
+  const int v = blockIdx.x * BLOCK + threadIdx.x;  // row i * 4 + c
+  const int nv = a.nact * 4;
+  const bool have = v < nv;
+  const int i = v >> 2, c = v & 3;
+  const int j = have ? (a.active_in ? a.active_in[i] : i) : 0;
+  bool ok = false;
+  float qm = FPEPS;
+  if (have) {
+    float qs = FPEPS;  // src/mcpar.cc:355-365
+    constexpr int U = 16;
+    const float *ps = a.psum + v, *pm = a.pmax + v;
+    int sb = 0;
+    for (; sb + U <= a.S; sb += U) {
+      float s[U], x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        s[u] = ps[(size_t)(sb + u) * nv];
+        x[u] = pm[(size_t)(sb + u) * nv];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        qs = qs + s[u];
+        qm = x[u] > qm ? x[u] : qm;
+      }
+    }
+    for (; sb < a.S; ++sb) {
+      qs = qs + ps[(size_t)sb * nv];
+      const float x = pm[(size_t)sb * nv];
+      qm = x > qm ? x : qm;
+    }
+    ok = a.cand_racpt[v] < qm / qs;
   }
-  __syncthreads();
-  if (last) {
-    for (int k = (int)threadIdx.x; k < a.ncounts; k += (int)blockDim.x)
-      a.counts_host[k] = __hip_atomic_load(a.counts + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 0) *a.done = 0u;
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {  // the counters are on their way: now the pass's serial number, which the host spins on
-      __hip_atomic_store(a.counts_host + a.nflag, a.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // the chain's quad: which of its candidates pass, and the first of them
+  const unsigned long long pass_mask = __ballot(ok);
+  const unsigned quad = (unsigned)(pass_mask >> ((threadIdx.x & 63u) & ~3u)) & 0xfu;
+  const int first = quad ? __builtin_ctz(quad) : 4;
+  if (v == 0 && a.nact_zero) *a.nact_zero = 0;
+  if (have && c == first) {  // this one becomes the chain's proposal
+    a.cfac[j] = a.cmax[j] / qm;
+    for (int k = 0; k < a.d; ++k) {
+      a.ptrial[(size_t)j * a.d + k] = a.cand_p[(size_t)v * a.d + k];
+      a.mutrial[(size_t)j * a.d + k] = a.cand_mu[(size_t)v * a.d + k];
+      a.sigtrial[(size_t)j * a.d + k] = a.cand_sig[(size_t)v * a.d + k];
     }
   }
+  if (have && c == 0 && first == 4) a.active_out[wave_slot(a.nact_out)] = j;
+  const int ntried = (have && c == 0) ? (first < 4 ? first + 1 : 4) : 0;  // (counted once per chain)
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {  // (every lane is here: whole-wavefront ballots)
+    const int cnt = (int)__popcll(__ballot(ntried > cc));
+    if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(a.tried + cc, cnt);
+  }
+  decide_hand_over(a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -82,7 +82,8 @@ def test_whole_murray_job_same_bits_and_most_pairs_excluded(cfg):
         eg.close()
     print("pairs left after the exclusion test: boxes %.3f, one direction %.3f, per-pair bound %.3f of all (%s)"
           % (frac[1], frac[2], frac[3], cfg))
-    assert frac[0] == 1.0 and frac[1] <= 1.0 and frac[2] <= 1.0
+    # (no screen: every pair the reference loops over, plus the proposals the late passes swept ahead of their turn)
+    assert 1.0 <= frac[0] < 1.1 and frac[1] <= 1.05 and frac[2] <= 1.05
     if cfg == "rosen16":  # (the 32-D mixture: pairs are dead across the mixture's axis, which no bound for 128 chains sees
         assert frac[1] < 0.8 and frac[2] < 0.8  # -- the per-pair bound does)
     assert frac[3] < 0.6
