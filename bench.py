@@ -325,6 +325,158 @@ class Job:
         self.eng.close()
 
 
+# ---------------------------------------------------------------------------------------------
+# N > 1 without a launcher: this process starts the N ranks itself
+# ---------------------------------------------------------------------------------------------
+EXIT_TOO_FEW_DEVICES = 66   # a rank found fewer GPUs than ranks (and no --one-device)
+EXIT_RCCL_TIMEOUT = 75      # the RCCL communicator / its first gather did not come up within --rccl-timeout
+EXIT_WATCHDOG = 124         # the parent saw no JSON line within --launch-timeout
+
+
+def launch_ranks(n_ranks, argv, timeout_s):
+    """`python bench.py --gpus N` called directly (WORLD_SIZE unset): start N fresh rank processes of this same script
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would), relay rank 0's one
+    JSON line, return the exit status.  This parent never loads libmcx, torch or anything else that touches the GPU,
+    and nothing that has touched the GPU re-execs: the ranks are children, started before any HIP call.
+    A rank that dies takes the others with it; no line within `timeout_s` kills them all (exit 124).  Ranks that give
+    up on RCCL (exit 75) are started ONCE more on the host-staged exchange, and the line then says why."""
+    import signal
+    import socket
+    import threading
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        p = s.getsockname()[1]
+        s.close()
+        return p
+
+    def attempt(extra, budget_s):
+        port = free_port()
+        procs, lines = [], []
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MCX_BENCH_LAUNCHED="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + extra, env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+
+        def reader():
+            for ln in procs[0].stdout:
+                lines.append(ln)
+        th = threading.Thread(target=reader, daemon=True)
+        th.start()
+
+        def kill_all():
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, signal.SIGTERM)
+                    except OSError:
+                        pass
+            t_end = time.time() + 5.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    p.wait()
+        t0 = time.time()
+        rc = 0
+        try:
+            while True:
+                codes = [p.poll() for p in procs]
+                bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+                if bad:
+                    rc = bad[0][1] if bad[0][1] > 0 else 128 - bad[0][1]
+                    for special in (EXIT_RCCL_TIMEOUT, EXIT_TOO_FEW_DEVICES):
+                        if any(c == special for _r, c in bad):
+                            rc = special
+                    print("bench: rank %d exited with status %d; stopping the other ranks" % bad[0], file=sys.stderr)
+                    kill_all()
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                if time.time() - t0 > budget_s:
+                    print("bench: no result after %.0f s (--launch-timeout): killing the %d ranks" % (budget_s, n_ranks), file=sys.stderr)
+                    kill_all()
+                    rc = EXIT_WATCHDOG
+                    break
+                time.sleep(0.05)
+        except BaseException:
+            kill_all()
+            raise
+        th.join(timeout=5.0)
+        return rc, lines, time.time() - t0
+
+    t_start = time.time()
+    rc, lines, took = attempt([], timeout_s)
+    if rc == EXIT_RCCL_TIMEOUT and "--exchange" not in argv:
+        left = timeout_s - (time.time() - t_start)
+        print("bench: the RCCL exchange did not come up; one more attempt on the host-staged all-gather (%.0f s left)" % left, file=sys.stderr)
+        if left > 30:
+            rc, lines, took = attempt(["--exchange", "staged", "--exchange-fallback-reason",
+                                       "fallback because the RCCL communicator or its first all-gather did not complete in time"], left)
+    if rc != 0:
+        return rc
+    good = []
+    for ln in lines:
+        try:
+            o = json.loads(ln.decode("utf-8", "replace"))
+        except ValueError:
+            continue
+        if isinstance(o, dict) and ("metric" in o or o.get("dry_launch")):
+            good.append((ln, o))
+    if len(good) != 1:
+        print("bench: expected ONE JSON line from rank 0, got %d" % len(good), file=sys.stderr)
+        return 1
+    ln, o = good[0]
+    if o.get("n_gpus") != n_ranks:
+        print("bench: rank 0 reports n_gpus = %r, launched %d ranks" % (o.get("n_gpus"), n_ranks), file=sys.stderr)
+        return 1
+    c = o.get("config") or {}
+    if "metric" in o and not (c.get("rccl_comm_ranks") == n_ranks or "fallback because" in str(c.get("exchange_backend"))
+                              or "requested" in str(c.get("exchange_backend"))):
+        print("bench: the line names neither an RCCL communicator of %d ranks nor the reason for another exchange: %r / %r"
+              % (n_ranks, c.get("rccl_comm_ranks"), c.get("exchange_backend")), file=sys.stderr)
+        return 1
+    o["launcher"] = dict(kind="bench.py's own (WORLD_SIZE was unset)", ranks=n_ranks, wall_s=time.time() - t_start)
+    if "summary" in o:  # keep `summary` the LAST key
+        o["summary"] = o.pop("summary")
+    sys.stdout.write(json.dumps(o) + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def dry_launch():
+    """--dry-launch: prove that the ranks this script was started as (by its own launcher or by torch.distributed.run)
+    find each other: rendezvous on gloo, one all-gather of the ranks, one line from rank 0.  No GPU, no libmcx."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    seen = [rank]
+    # the launcher's two failure paths, for tests/test_bench_launcher_cpu.py: a rank that never arrives, a rank that dies
+    if os.environ.get("MCX_BENCH_DEBUG_HANG_RANK") == str(rank):
+        time.sleep(3600)
+    if os.environ.get("MCX_BENCH_DEBUG_DIE_RANK") == str(rank):
+        sys.exit(7)
+    if world > 1:
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "0")), os.getpid()))
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        assert int(t.item()) == world * (world + 1) // 2
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(dry_launch=True, n_gpus=world, ranks=seen,
+                              launched_by="bench.py" if os.environ.get("MCX_BENCH_LAUNCHED") else "external launcher")), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,7 +504,22 @@ def main():
     ap.add_argument("--cull", type=int, default=-1, choices=(-1, 0, 1), help="MCX_OPT_CULL of the measured job (Murray sweeps: exact "
                     "exclusion of far Gaussians): -1 auto (default), 0 off, 1 on")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-launch", action="store_true", help="only prove that the N ranks start and rendezvous (no GPU work)")
+    ap.add_argument("--launch-timeout", type=float, default=540.0, help="--gpus N > 1 started directly: seconds the parent waits "
+                    "for rank 0's line before it kills the ranks and exits 124")
+    ap.add_argument("--rccl-timeout", type=float, default=90.0, help="seconds a rank waits for the RCCL communicator and its first "
+                    "all-gather before it gives up (exit 75; bench.py's own launcher then retries on the staged exchange)")
+    ap.add_argument("--extras-budget", type=float, default=240.0, help="N > 1: seconds after start beyond which no further extra "
+                    "leg (reference schedule, Murray configuration, strong scaling) is begun")
+    ap.add_argument("--exchange-fallback-reason", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        # called the way the driver calls it (`python3 bench.py --gpus 8 ...`, no launcher): be the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
+    if args.dry_launch:
+        dry_launch()
+        return
 
     cfg = dict(CONFIGS[args.config])
     if args.dim > 0:
@@ -368,11 +535,25 @@ def main():
         pmc_child(cfg, args.chains or cfg["n"])
         return
 
+    t_process_start = time.time()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    if world > 1 and not args.one_device:
+        # fewer GPUs than ranks is an error, never a quiet N = 1 (or N ranks on one device): every rank checks before
+        # the rendezvous, so all of them leave with the same status
+        from mcpar_amd import engine as _E
+        try:
+            ndev = _E.device_count()
+        except Exception as ex:  # noqa: BLE001
+            print("bench: rank %d: %s" % (rank, ex), file=sys.stderr)
+            ndev = 0
+        if ndev < world:
+            print("bench: rank %d: --gpus %d but this node shows %d GPU(s) to libmcx (mcx_device_count); refusing to run "
+                  "(rehearsals on one GPU: add --one-device)" % (rank, world, ndev), file=sys.stderr)
+            sys.exit(EXIT_TOO_FEW_DEVICES)
     # stdout carries exactly ONE line, the JSON.  gloo announces its connections and RCCL prints its version banner
     # on the C-level stdout whenever a communicator is made (also the later ones: the Murray and strong-scaling
     # jobs), child profilers chatter too: file descriptor 1 points at stderr from here to the end of the run and
@@ -406,7 +587,7 @@ def main():
     emit = not args.no_samples
 
     # ---- inter-shard exchange -------------------------------------------------------------------
-    state = {"backend": None, "rccl_ranks": None}
+    state = {"backend": None, "rccl_ranks": None, "rccl_bring_up_s": None}
     pci = None
     try:
         buf = C.create_string_buffer(64)
@@ -460,18 +641,35 @@ def main():
             return Job(M, E, c, nn, 0, 1, emit_, args.max_segment)
         uid = new_rccl_id() if args.exchange == "rccl" else None
         j = Job(M, E, c, nn, rank, world, emit_, args.max_segment)
-        why = "requested" if args.exchange == "staged" else "fallback: RCCL not loadable on every rank"
+        why = (args.exchange_fallback_reason or "requested") if args.exchange == "staged" else "fallback because RCCL is not loadable on every rank"
         if uid is not None:
             # communicator + one gather now: a broken fabric shows here, not inside the timed region.  Every rank
             # learns whether ALL ranks succeeded, so the fallback is taken by all of them or by none.
-            err = ""
-            try:
-                j.eng.rccl_init(uid)
-                # one real gather with known contents: every slot must arrive, whole, at every rank
-                if not j.eng.exchange_self_check():
-                    err = "RCCL all-gather self-check failed: a slot did not arrive as sent"
-            except Exception as ex:  # MCX_ERR_EXCHANGE with the RCCL error string
-                err = str(ex)
+            # ncclCommInitRank / the first gather can hang on a broken fabric and cannot be cancelled: they run in a
+            # thread (ctypes drops the GIL), and a rank that is still waiting after --rccl-timeout leaves with status 75
+            import threading
+            res = {"err": "", "t": None}
+
+            def bring_up():
+                t0 = time.time()
+                try:
+                    j.eng.rccl_init(uid)
+                    # one real gather with known contents: every slot must arrive, whole, at every rank
+                    if not j.eng.exchange_self_check():
+                        res["err"] = "RCCL all-gather self-check failed: a slot did not arrive as sent"
+                except Exception as ex:  # MCX_ERR_EXCHANGE with the RCCL error string
+                    res["err"] = str(ex)
+                res["t"] = time.time() - t0
+            th = threading.Thread(target=bring_up, daemon=True)
+            th.start()
+            th.join(args.rccl_timeout)
+            if th.is_alive():
+                print("bench: rank %d: the RCCL communicator / its first all-gather is not up after %.0f s (--rccl-timeout); "
+                      "giving up (exit %d)" % (rank, args.rccl_timeout, EXIT_RCCL_TIMEOUT), file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(EXIT_RCCL_TIMEOUT)
+            err = res["err"]
+            state["rccl_bring_up_s"] = res["t"]
             flag = torch.tensor([1 if err else 0], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()):
@@ -480,7 +678,7 @@ def main():
                 except Exception:
                     pass
                 uid = None
-                why = "fallback: " + (err or "RCCL failed on another rank")
+                why = "fallback because " + (err or "RCCL failed on another rank")
                 print("bench: rank %d: RCCL exchange unavailable (%s); using the host-staged all-gather" % (rank, why), file=sys.stderr)
         if uid is None:
             staged_exchange(j.eng)
@@ -510,6 +708,20 @@ def main():
             dt = float(tt.item())
         return dt
 
+    skipped = []
+
+    def within_budget(what):
+        """N > 1: the extra legs are begun only while the slowest rank is inside --extras-budget (collective: all ranks
+        take the same decision); what is left out is named in config.extras_skipped"""
+        if world == 1:
+            return True
+        tt = torch.tensor([time.time() - t_process_start], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if float(tt.item()) < args.extras_budget:
+            return True
+        skipped.append(what)
+        return False
+
     job = make_job(cfg, n, emit)
     eng = job.eng
     if args.cull != -1:
@@ -526,7 +738,7 @@ def main():
     # src/mcpar.cc:127-140, overlapped with the next segment) next to the default, which gathers only the
     # snapshots a Murray step or the end of the run reads (bit-identical results: tests/test_gpu_multishard.py)
     ref_sched = None
-    if world > 1:
+    if world > 1 and not args.no_extras and within_budget("reference_schedule"):
         eng.set_option(E.OPT_EAGER_EXCHANGE, 1)
         job.run()
         ke = max(1, args.steps // 2)
@@ -606,7 +818,7 @@ def main():
 
     # ---- N > 1: a Murray (pl < 1) configuration over the same ranks, first-class next to the R-local number ----
     murray_multi = None
-    if world > 1 and cfg["pl"] >= 1.0 and not args.no_extras:
+    if world > 1 and cfg["pl"] >= 1.0 and not args.no_extras and within_budget("murray"):
         job.close()
         c5 = dict(CONFIGS["c5"])
         j5 = make_job(c5, c5["n"], True)
@@ -625,7 +837,10 @@ def main():
 
     # ---- N > 1: the same total job split over the ranks (strong scaling; `value` above is weak scaling) ----------
     strong_multi = None
-    if world > 1 and not args.strong and not args.no_extras and total % world == 0:
+    if world > 1 and not args.strong and not args.no_extras and total % world == 0 and within_budget("strong_scaling"):
+        if job is not None:
+            job.close()
+            job = None
         cs = dict(cfg)
         ns_ = total // world
         cs["n"] = ns_
@@ -899,6 +1114,8 @@ def main():
                        "parallelism": ("chains sharded x%d (contiguous blocks, g = shard*n + j), in-place all-gather of the "
                                        "(mu, sig^2) slots" % world) if world > 1 else "single GPU",
                        "exchange_backend": state["backend"], "rccl_comm_ranks": state["rccl_ranks"],
+                       "rccl_bring_up_s": state["rccl_bring_up_s"], "extras_skipped": skipped or None,
+                       "rank0_wall_s": time.time() - t_process_start,
                        "pci_bus_ids": pci_ids,
                        "stats": headline_stats,
                        "reference_schedule": ref_sched,

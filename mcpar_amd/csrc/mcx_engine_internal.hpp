@@ -34,6 +34,7 @@ typedef enum { ncclFloat = 7 } ncclDataType_t;
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>

@@ -111,10 +111,22 @@ bool rccl_load()
   // if another RCCL is already in the process (e.g. the one PyTorch-ROCm ships) the soname resolves to it
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
+  // MCX_RCCL_LIB: this library and no other (a site's own RCCL build; tests/cpp/rccl_stub.hip) -- no quiet fallback to
+  // the system's when it does not load
+  const char *forced = std::getenv("MCX_RCCL_LIB");
+  if (forced && *forced) {
+    h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      const char *de = dlerror();
+      g_rccl.why = std::string("MCX_RCCL_LIB=") + forced + " not loadable: " + (de ? de : "?");
+      return false;
+    }
+  }
   for (const char *n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (h || (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
   if (!h) {
-    g_rccl.why = std::string("librccl.so.1 not loadable: ") + (dlerror() ? dlerror() : "?");
+    const char *de = dlerror();
+    g_rccl.why = std::string("librccl.so.1 not loadable: ") + (de ? de : "?");
     return false;
   }
   bool ok = true;
