@@ -788,7 +788,7 @@ def main():
                                  launches=sc["launches"], total_ms=sc["ms"])
         return out
 
-    roofline = murray = cpu = end_to_end = claims = host_cb = None
+    roofline = murray = cpu = end_to_end = claims = host_cb = device_vl = None
     others = {}
     if rank == 0:
         fm, fb, rs = prof["fused_main"], prof["fused_burn"], prof["run_small"]
@@ -1065,6 +1065,7 @@ def main():
         if not args.no_extras and args.config == "c3" and not args.chains and args.dim == 0:
             claims = claims_under_the_clock(M, E, dt / args.steps * 1e3, n, nburn, nsamp)
             host_cb = host_callback_leg(M, E, cfg, n)
+            device_vl = device_vlfunc_leg(M, E, cfg, n, dt / args.steps * 1e3, emit)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg)
 
@@ -1093,6 +1094,9 @@ def main():
             "end_to_end_rows_ms": pick(end_to_end, "ms_per_step"),
             "end_to_end_text_ms": pick(end_to_end, "text", "whole_job_through_the_text_sink", "ms_per_step"),
             "host_callback_ms_per_step": pick(host_cb, "ms_per_step"), "host_callback_path_ms_per_step": pick(host_cb, "path_ms_per_step"),
+            "device_vlfunc_source_fraction_of_builtin": (pick(device_vl, "source_block_form", "fraction_of_builtin"),
+                                                         pick(device_vl, "source_whole_vector_form", "fraction_of_builtin")),
+            "device_vlfunc_kernel_ms_per_step": pick(device_vl, "kernel", "ms_per_step"),
             "cpu_baseline": pick(cpu, "value"),
             "weak_reference_schedule_ms": pick(ref_sched, "ms_per_step"),
             "murray_multi_ms": pick(murray_multi, "ms_per_step"), "murray_multi_meet_timeouts": pick(murray_multi, "stats", "meet_timeouts"),
@@ -1127,7 +1131,7 @@ def main():
                        "other_configs": others or None,
                        "full_cov": (claims or {}).get("full_cov"), "strong_proxy": sp,
                        "accept_rate_reference_shape": (claims or {}).get("accept_rate_reference_shape")},
-            "end_to_end": end_to_end, "host_callback": host_cb, "murray_roofline": murray, "cpu_baseline": cpu, "roofline": roofline,
+            "end_to_end": end_to_end, "host_callback": host_cb, "device_vlfunc": device_vl, "murray_roofline": murray, "cpu_baseline": cpu, "roofline": roofline,
             "summary": summary,  # LAST: whoever keeps only the tail of this line still has every headline number
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -1177,6 +1181,80 @@ def host_callback_leg(M, E, cfg, n):
                 ms_per_step=dt / steps * 1e3, value=n * steps / dt, unit="chain-steps/s", functor_calls=calls,
                 functor_ms_per_step=inside[0] / steps * 1e3, path_ms_per_step=path * 1e3,
                 pcie_bytes_per_step=bytes_per_step, pcie_GBps_over_path_time=bytes_per_step / path / 1e9)
+
+
+USER_KERNEL_TEMPLATE = r"""
+// Rosenbrock1(%(d)d) as a user's own KERNEL (MCX_VL_DEVICE: the VLFunc contract of src/vlfunc.hh:9-12 on device memory),
+// one thread per parameter set, sums in the engine's order (blocks of four, xor-butterfly over the blocks)
+extern "C" __global__ void user_rosenbrock(int npset, const float *x, float *y)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npset) return;
+  const float4 *p = reinterpret_cast<const float4 *>(x + (size_t)j * %(d)d);
+  float part[%(nb)d];
+  for (int q = 0; q < %(nb)d; ++q) {
+    const float4 v = p[q];
+    const float a1 = 1.0f - v.x, a2 = __builtin_fmaf(-v.x, v.x, v.y);
+    const float b1 = 1.0f - v.z, b2 = __builtin_fmaf(-v.z, v.z, v.w);
+    part[q] = (0.0f + __builtin_fmaf(100.0f * a2, a2, a1 * a1)) + __builtin_fmaf(100.0f * b2, b2, b1 * b1);
+  }
+  for (int s = 1; s < %(nb)d; s <<= 1)
+    for (int q = 0; q < %(nb)d; q += 2 * s)
+      for (int r = 0; r < s; ++r) part[q + r] = part[q + r] + part[q + r + s];
+  y[j] = 0.0f - part[0];
+}
+"""
+
+
+def device_vlfunc_leg(M, E, cfg, n, headline_ms, emit):
+    """A user's OWN likelihood on the GPU, both ways the C ABI offers (src/vlfunc.hh:9-12, called at src/mcpar.cc:60,160):
+    `kernel` = MCX_VL_DEVICE, the user's separately compiled kernel between the engine's propose and accept kernels --
+    three launches per step, the chain state round-tripping HBM every step, so SURVEY 8d's 392 (+68) B per chain-step
+    apply literally; `source` = MCX_VL_SOURCE, the user's device functions compiled INTO the fused step kernels (hiprtc):
+    the whole job, launch for launch like the built-in.  Both restate Rosenbrock1 so that the work is the headline's."""
+    d, nburn, nsamp = cfg["d"], cfg["nburn"], cfg["nsamp"]
+    out = {}
+    p = pinit_for(d, n, 0)
+    ex = os.path.join(ROOT, "mcpar_amd", "examples")
+    for key, fname, par in (("source_block_form", "user_rosenbrock1_blocks.hip", None),
+                            ("source_whole_vector_form", "user_rosenbrock1_whole.hip", [1.0])):
+        try:
+            t0 = time.perf_counter()
+            vl, _keep = M.make_vlfunc(M.VL_SOURCE, d, params=par, source=open(os.path.join(ex, fname)).read())
+            eng = M.Engine(d, n, pl=cfg["pl"])
+            eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
+            eng.stage_pinit(p)
+            eng.run(nsamp, nburn, None, vl)  # includes the one-off hiprtc build of this text
+            first = time.perf_counter() - t0
+            t = time_job(eng, vl, p, nsamp, nburn, reps=7)
+            st = job_stats(eng)
+            acc = eng.counters["naccept_main"] / float(n * nsamp)
+            eng.close()
+            out[key] = dict(workload="C3's job with Rosenbrock1(%d) given as HIP source (%s), fused into the step kernels" % (d, fname),
+                            ms_per_job=t * 1e3, value=n * (nburn + nsamp) / t, unit="chain-steps/s",
+                            builtin_ms_per_job=headline_ms, fraction_of_builtin=headline_ms / (t * 1e3),
+                            first_run_s_including_the_build=first, accept_rate_main=acc, stats=st)
+        except Exception as ex_:  # noqa: BLE001
+            out[key] = dict(error=repr(ex_))
+    try:
+        fn = E.compile_user_kernel(USER_KERNEL_TEMPLATE % dict(d=d, nb=d // 4), "user_rosenbrock")
+        vl, _keep = M.make_vlfunc(M.VL_DEVICE, d, device_fn=fn)
+        kb, ks = 60, 40  # like host_callback: enough steps to time a per-step path
+        eng = M.Engine(d, n, pl=1.0)
+        eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
+        t = time_job(eng, vl, p, ks, kb, reps=5)
+        st = job_stats(eng)
+        eng.close()
+        abytes = float(n) * (kb * alg_bytes_per_chain_step(d, False, False) + ks * alg_bytes_per_chain_step(d, True, emit))
+        out["kernel"] = dict(workload="Rosenbrock1(%d) as the user's own kernel (MCX_VL_DEVICE) x %d chains, nburn %d + nsamp %d: "
+                                      "propose / user kernel / accept, three launches per step" % (d, n, kb, ks),
+                             ms_per_step=t / (kb + ks) * 1e3, value=n * (kb + ks) / t, unit="chain-steps/s",
+                             hbm_alg=dict(achieved=abytes / t / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=abytes / t / HBM_PEAK,
+                                          note="SURVEY 8d bytes per chain-step; on this path the state does round-trip HBM every step"),
+                             stats=st)
+    except Exception as ex_:  # noqa: BLE001
+        out["kernel"] = dict(error=repr(ex_))
+    return out
 
 
 def fm_unavoidable(d, n, chain_steps_per_launch, emit):

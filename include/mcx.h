@@ -50,8 +50,37 @@ enum {
                              log L unbounded above) and the loop kept inside each parameter set:
                              - sum_{k < d-1} (1 - x_k)^2 + 100 (x_{k+1} - x_k^2)^2                      (fused) */
   MCX_VL_HOST = 100,      /* any user VLFunc subclass: device -> host callback -> device  */
-  MCX_VL_DEVICE = 101     /* user likelihood as a GPU kernel: stays on the device (see mcx_vlfunc.ctx) */
+  MCX_VL_DEVICE = 101,    /* user likelihood as a GPU kernel: stays on the device (see mcx_vlfunc.ctx) */
+  MCX_VL_SOURCE = 102     /* user likelihood as HIP SOURCE of device functions, compiled into the engine's fused step
+                             kernels at run time (hiprtc): one launch per segment like the built-ins (see below) */
 };
+
+/* MCX_VL_SOURCE -- the VLFunc contract (src/vlfunc.hh:9-12) for ONE parameter set, as device code the engine inlines into
+ * its own step kernels.  ctx = the NUL-terminated source text, params / ncomp = `ncomp` floats handed to the functions as
+ * `par` (copied to the device by mcx_run).  The text defines, in the global namespace, EITHER
+ *
+ *     __device__ float mcx_user_loglike(const float *x, int d, const float *par);      // log L of x[0..d-1]
+ *
+ * (x points to on-chip memory; every call sees one whole parameter set) OR, for likelihoods that are a sum over
+ * blocks of four consecutive parameters -- the engine's own decomposition, one GPU lane per block --
+ *
+ *     #define MCX_USER_BLOCK_FORM
+ *     __device__ float mcx_user_block(const float xb[4], int nv, int k0, int d, const float *par);
+ *         // partial of parameters k0 .. k0+nv-1 (nv = 4 except in the last block when d % 4 != 0)
+ *     #define MCX_USER_FINISH                                                            // optional
+ *     __device__ float mcx_user_finish(float sum, int d, const float *par);             // log L from the sum (default: sum)
+ *
+ * The partials are added in the order of the built-ins, so a restatement of a built-in returns
+ * its bits.  "mcx_numerics.hpp" is already included: mcx::logf_v1, mcx::expf_v2, ... are the engine's (and the CPU
+ * oracle's) own transcendentals.  Compiled with -O3 -ffp-contract=off (write fma explicitly: __builtin_fmaf), once per
+ * (text, np) per process; a text that does not compile fails mcx_run with MCX_ERR_VLFUNC and the compiler's messages
+ * in mcx_last_error().  Without libhiprtc: MCX_ERR_UNSUPPORTED (MCX_VL_DEVICE and MCX_VL_HOST remain). */
+int mcx_user_source_available(void); /* 1 / 0 (mcx_last_error says why not) */
+/* the compile step alone, for a chain of np parameters (needs no GPU): MCX_OK and the code object's size, or MCX_ERR_VLFUNC */
+int mcx_debug_user_source_compile(const char *source, int np, size_t *code_bytes);
+/* For MCX_VL_DEVICE without a compiler at hand: source of a whole kernel
+ *   extern "C" __global__ void f(int npset, const float *x, float *y)   -> *function = its hipFunction_t (for mcx_vlfunc.ctx) */
+int mcx_user_kernel_compile(const char *source, const char *symbol, void **function);
 
 /* same contract as VLFunc::operator()(int npset, const float *x, float *restrict y): x is
  * row-major [npset][d], y is [npset]; the return code is ignored like the reference's
@@ -61,11 +90,11 @@ typedef int (*mcx_host_fn)(void *ctx, int npset, const float *x, float *y);
 typedef struct mcx_vlfunc {
   int kind;            /* MCX_VL_* */
   int d;               /* parameters per set; must equal the engine's np */
-  int ncomp;           /* GAUSSMIX: number of components K (<= 64) */
+  int ncomp;           /* GAUSSMIX: number of components K (<= 64); SOURCE: number of floats in params */
   const float *params; /* GAUSSIAN: mu[d], sig2[d] (NULL = standard normal); DUALGAUSS: w;
-                          GAUSSMIX: means[K*d], weights[K].  Copied by mcx_run. */
+                          GAUSSMIX: means[K*d], weights[K]; SOURCE: the user's `par`.  Copied by mcx_run. */
   mcx_host_fn fn;      /* HOST */
-  void *ctx;           /* HOST: passed to fn.  DEVICE: a hipFunction_t (from the caller's own code object,
+  void *ctx;           /* HOST: passed to fn.  SOURCE: const char *, the source text.  DEVICE: a hipFunction_t (from the caller's own code object,
                           hipModuleGetFunction) of a kernel with the VLFunc contract on device memory,
                             extern "C" __global__ void f(int npset, const float *x, float *y);
                           launched with 256-thread blocks, ceil(npset / 256) blocks, on the engine's

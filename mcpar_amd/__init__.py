@@ -6,7 +6,7 @@ There is no CPU fallback: importing works anywhere, but every compute call needs
 library and a GPU, and raises McxError otherwise.
 """
 from ._lib import McxError, load, lib_path  # noqa: F401
-from .engine import (Engine, VL_DEVICE, VL_DUALGAUSS, VL_GAUSSIAN, VL_GAUSSMIX, VL_HOST,  # noqa: F401
+from .engine import (Engine, VL_DEVICE, VL_SOURCE, VL_DUALGAUSS, VL_GAUSSIAN, VL_GAUSSMIX, VL_HOST,  # noqa: F401
                      VL_ROSENBROCK1, VL_ROSENBROCK2, debug_normals, debug_numerics, device_info,
                      make_vlfunc, vlfunc_eval)
 

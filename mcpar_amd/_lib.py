@@ -101,6 +101,9 @@ def load():
         "mcx_device_count": [C.POINTER(C.c_int)],
         "mcx_device_pci_bus_id": [C.c_char_p, C.c_size_t],
         "mcx_rccl_available": [],
+        "mcx_user_source_available": [],
+        "mcx_debug_user_source_compile": [C.c_char_p, C.c_int, C.POINTER(C.c_size_t)],
+        "mcx_user_kernel_compile": [C.c_char_p, C.c_char_p, C.POINTER(vp)],
         "mcx_rccl_unique_id": [vp],
         "mcx_exchange_rccl_init": [vp, vp],
         "mcx_exchange_rccl_adopt": [vp, vp],

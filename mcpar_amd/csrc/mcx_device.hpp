@@ -23,7 +23,9 @@ constexpr int BLOCK = 256;  // 4 wavefronts per workgroup
 constexpr int MAXD_LDS = 32;  // full-covariance factor is staged in LDS up to this np, read from L2 above
 constexpr int MAXD = 256;     // lanes per chain <= 64
 
-enum LikKind : int { LIK_ROSEN1 = 1, LIK_ROSEN2 = 2, LIK_GAUSS = 3, LIK_MIX = 5, LIK_ROSEN2F = 6 };
+// LIK_USER: a user's own likelihood, HIP source compiled INTO these kernels at run time (MCX_VL_SOURCE, mcx_user.hip);
+// its code paths exist only in that translation unit (MCX_USER_LIK defined)
+enum LikKind : int { LIK_ROSEN1 = 1, LIK_ROSEN2 = 2, LIK_GAUSS = 3, LIK_MIX = 5, LIK_ROSEN2F = 6, LIK_USER = 7 };
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
@@ -168,6 +170,40 @@ struct Lik<LIK_MIX, LPC> {  // log sum_c w_c exp(-|x-m_c|^2/2); lik = means[K*d]
     return emax + logf_v1(s);
   }
 };
+
+#ifdef MCX_USER_LIK
+// The user's likelihood (src/vlfunc.hh:9-12 as device functions in the global namespace, include/mcx.h MCX_VL_SOURCE).
+//   MCX_USER_LIK == 1: log L = mcx_user_finish(sum over the 4-parameter blocks of mcx_user_block(...)) -- the partials are
+//     added in the MCX order (xor-butterfly over the block index), so a restatement of a built-in gives its bits;
+//   MCX_USER_LIK == 2: log L = mcx_user_loglike(x[d], d, par) on the whole parameter vector, staged through LDS; every
+//     lane of the chain evaluates it (a wavefront's instruction costs the same with one lane active or all).
+template <int LPC>
+struct Lik<LIK_USER, LPC> {
+  const float *par;
+  int d, k0;
+  __device__ __forceinline__ void init(const float *lik, int d_, int k0_, int, int) { par = lik; d = d_; k0 = k0_; }
+  __device__ __forceinline__ float eval(const float xb[4], int nv) const
+  {
+#if MCX_USER_LIK == 1
+    const float acc = nv > 0 ? ::mcx_user_block(xb, nv, k0, d, par) : 0.0f;
+    return ::mcx_user_finish(group_sum<LPC>(acc), d, par);
+#else
+    __shared__ __attribute__((aligned(16))) float xs[BLOCK * 4];
+    float *mine = xs + 4 * ((int)threadIdx.x & ~(LPC - 1));  // the chain's vector, contiguous: lane q holds x[4q .. 4q+3]
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nv) mine[k0 + k] = xb[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // a chain never spans wavefronts; LDS is in order per wavefront
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const float v = ::mcx_user_loglike(mine, d, par);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // this call's reads precede the next call's writes
+    return v;
+#endif
+  }
+};
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // block load / store helpers: row-major [n][d], this lane's block at column k0
@@ -453,7 +489,16 @@ __device__ __forceinline__ void tuner_epilogue(const SegArgs &a, uint32_t wacc)
 }
 
 template <int LPC, int LIK, bool MAIN>
+__device__ __forceinline__ void fused_steps_body(const SegArgs &a);
+
+template <int LPC, int LIK, bool MAIN>
 __global__ __launch_bounds__(BLOCK) void k_fused_steps(const SegArgs a)
+{
+  fused_steps_body<LPC, LIK, MAIN>(a);
+}
+
+template <int LPC, int LIK, bool MAIN>
+__device__ __forceinline__ void fused_steps_body(const SegArgs &a)
 {
   // rows padded by 4 floats: the 4-row blocks of different lanes then start 16 banks apart instead of
   // on the same bank (8-way -> 2-way conflict at d = 32) and stay 16-byte aligned
@@ -675,8 +720,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused_fast(const SegArgs a)
 template <int LPC, bool MAIN, int LIK, bool PREGEN, bool FULL>
 __device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a)
 {
-  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX || (LIK == LIK_ROSEN2F && !PREGEN && !FULL),
-                "fast path: Rosenbrock1, diagonal Gaussian, a mixture of <= 8 unit Gaussians, or (plain kernel only) the overlapping Rosenbrock");
+  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX || (LIK == LIK_ROSEN2F && !PREGEN && !FULL) || (LIK == LIK_USER && !PREGEN),
+                "fast path: Rosenbrock1, diagonal Gaussian, a mixture of <= 8 unit Gaussians, (plain kernel only) the overlapping Rosenbrock, or a user's source");
   static_assert(!(FULL && PREGEN), "the pre-generated normals are laid out for diagonal proposals");
   __shared__ __attribute__((aligned(16))) float4 lds_T[FULL ? 4 * LPC * LPC : 1];
   __shared__ __attribute__((aligned(16))) float4 lds_z[FULL && LPC == 8 ? (BLOCK / 8) * 9 : 1];
@@ -806,6 +851,14 @@ __device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a)
       }
     }
     float lyt;
+#ifdef MCX_USER_LIK
+    if (LIK == LIK_USER) {  // the user's device functions on this lane's four trial parameters (x0, x1, x2, x3)
+      Lik<LIK_USER, LPC> UL;
+      UL.init(a.lik, d, k0, 0, 0);
+      const float ub[4] = {pe.x, po.x, pe.y, po.y};
+      lyt = UL.eval(ub, live ? 4 : 0);
+    } else
+#endif
     if (LIK == LIK_MIX) {
       // log sum_c w_c exp(-|x - m_c|^2 / 2) as a log-sum-exp (DualGaussian: src/rosenbrock.cc:63-78)
       const int K = a.ncomp;
@@ -1034,8 +1087,19 @@ __global__ __launch_bounds__(BLOCK) void k_propose_local(const StepArgs a)
 
 // batched likelihood, the VLFunc call: x[n][d] -> y[n]
 template <int LPC, int LIK>
+__device__ __forceinline__ void eval_body(const float *__restrict__ x, float *__restrict__ y, int n, int d, const float *lik,
+                                          int ncomp, int vec4);
+
+template <int LPC, int LIK>
 __global__ __launch_bounds__(BLOCK) void k_eval(const float *__restrict__ x, float *__restrict__ y,
                                                 int n, int d, const float *lik, int ncomp, int vec4)
+{
+  eval_body<LPC, LIK>(x, y, n, d, lik, ncomp, vec4);
+}
+
+template <int LPC, int LIK>
+__device__ __forceinline__ void eval_body(const float *__restrict__ x, float *__restrict__ y, int n, int d, const float *lik,
+                                          int ncomp, int vec4)
 {
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t chain = gid / LPC;

@@ -142,6 +142,15 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
     L.kind = MCX_VL_DEVICE;
     L.ctx = f->ctx;
     break;
+  case MCX_VL_SOURCE: {
+    if (f->ncomp < 0 || (f->ncomp > 0 && !f->params)) return fail(MCX_ERR_INVALID, "MCX_VL_SOURCE: ncomp floats of params expected");
+    MCXCHK(user_lik_get(static_cast<const char *>(f->ctx), lpc_for(d), &L.user));  // (cached: compiled on first use)
+    L.kind = LIK_USER;
+    L.ncomp = f->ncomp;
+    h.assign(f->params, f->params + (f->params ? f->ncomp : 0));
+    if (h.empty()) h.push_back(0.0f);  // `par` is never a null pointer on the device
+    break;
+  }
   default:
     return fail(MCX_ERR_INVALID, "unknown vlfunc kind %d", f->kind);
   }
@@ -199,6 +208,7 @@ static int launch_eval(int lik, const float *x, float *y, int n, int d, const fl
 
 static int eval_device(const LikDev &L, const float *x, float *y, int n, int d, hipStream_t st)
 {
+  if (L.kind == LIK_USER) return user_lik_launch_eval(*L.user, x, y, n, d, L.params.p, L.ncomp, st);
   const int lpc = lpc_for(d), vec4 = (d % 4 == 0);
   DISPATCH_LPC(lpc, MCXCHK((launch_eval<LPC_>(L.kind, x, y, n, d, L.params.p, L.ncomp, vec4, st))));
   return MCX_OK;
@@ -224,12 +234,14 @@ static bool fused_takes_epilogue(const mcx_engine *e, const SegArgs &a)
   const bool split = fast && fast_lik && (e->opt_split > 0 || (e->opt_split < 0 && waves < SPLIT_AUTO_MAX_WAVES));
   if (split) return false;
   if ((unsigned long long)a.n * (unsigned long long)a.nsteps >= (1ull << 40)) return false;  // tuner_epilogue's 40-bit sums
+  if (lik == LIK_USER) return user_lik_variant(lpc, a) < 2;  // the user's hot-path kernels are k_fused_fast's body + epilogue
   return fast || (lpc <= 8 && fast_lik && !a.diag && a.vec4 && !a.mask);
 }
 
 static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t st)
 {
   const int lik = e->lik.kind, lpc = e->lpc;
+  if (lik == LIK_USER) return user_lik_launch_fused(*e->lik.user, main, a, st);  // MCX_VL_SOURCE: mcx_user.hip
   const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
   // (the overlapping Rosenbrock has the plain hot-path kernel only: no small-n modes, no several blocks per lane)
   const bool fast = lpc <= 8 && (fast_lik || lik == LIK_ROSEN2F) && a.diag && a.vec4 && !a.mask;

@@ -36,6 +36,7 @@ typedef enum { ncclFloat = 7 } ncclDataType_t;
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -141,14 +142,23 @@ struct PinBuf {
 };
 
 // device-side likelihood descriptor built from an mcx_vlfunc
+// mcx_user.hip: a user's likelihood source compiled into the step kernels at run time (MCX_VL_SOURCE)
+struct UserLik;
+int user_lik_get(const char *source, int lpc, std::shared_ptr<UserLik> *out);  // compiled once per (source, lanes per chain)
+int user_lik_launch_fused(const UserLik &u, bool main, const SegArgs &a, hipStream_t st);
+int user_lik_launch_eval(const UserLik &u, const float *x, float *y, int n, int d, const float *par, int ncomp, hipStream_t st);
+int user_lik_variant(int lpc, const SegArgs &a);  // 0 hot-path kernel, 1 its full-covariance form, 2 the generic kernel
+double user_lik_compile_ms(const UserLik &u);
+
 struct LikDev {
-  int kind = 0;  // LikKind, or MCX_VL_HOST
+  int kind = 0;  // LikKind, or MCX_VL_HOST / MCX_VL_DEVICE
   int ncomp = 0;
   DevBuf<float> params;
   std::vector<float> host;  // staging for the asynchronous upload (must outlive it)
   mcx_host_fn fn = nullptr;
   void *ctx = nullptr;
-  bool fusable() const { return kind == LIK_ROSEN1 || kind == LIK_GAUSS || kind == LIK_MIX || kind == LIK_ROSEN2F; }
+  std::shared_ptr<UserLik> user;  // LIK_USER
+  bool fusable() const { return kind == LIK_ROSEN1 || kind == LIK_GAUSS || kind == LIK_MIX || kind == LIK_ROSEN2F || kind == LIK_USER; }
 };
 
 

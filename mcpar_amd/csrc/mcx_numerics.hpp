@@ -9,8 +9,17 @@
 //   viRngUniform                               src/mcpar.cc:337      -> mulhi(word, N)
 //   vsRngGaussianMV(BOXMULLER2)                src/mcpar.cc:306,348  -> normal4()
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else  // hiprtc (MCX_VL_SOURCE: a user's likelihood compiled into the step kernels at run time) has no system headers
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long uint64_t;
+typedef int int32_t;
+typedef long int64_t;
+#endif
 
 #define MCX_HD __host__ __device__ __forceinline__
 

@@ -1,0 +1,262 @@
+// mcx_user.hip -- MCX_VL_SOURCE: a user's likelihood, given as HIP source of device functions, compiled INTO the
+// step kernels at run time.  The reference's plug-in surface is one virtual call per step on the whole batch
+// (src/vlfunc.hh:9-12, called at src/mcpar.cc:60,160); its GPU counterpart with a separately compiled user kernel
+// (MCX_VL_DEVICE) costs three launches per step with the chain state round-tripping HBM in between.  Here the user's
+// functions become Lik<LIK_USER, LPC> of mcx_device.hpp: burn-in with its tuner, main loop, Welford, sample emission stay
+// ONE launch per segment, state in registers, exactly as for the built-in likelihoods.
+//
+// hiprtc is loaded with dlopen on first use (no link dependency); the kernel headers travel inside libmcx.so as
+// strings (mcx_rtc_headers.inc, made by tools/embed_headers.py).  Code objects are cached per (source, lanes per
+// chain) for the life of the process.
+#include "mcx_engine_internal.hpp"
+
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "mcx_rtc_headers.inc"
+
+namespace {
+
+typedef struct _hiprtcProgram *rtcProgram;
+struct RtcApi {
+  void *handle = nullptr;
+  int (*CreateProgram)(rtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+  int (*CompileProgram)(rtcProgram, int, const char **) = nullptr;
+  int (*GetProgramLogSize)(rtcProgram, size_t *) = nullptr;
+  int (*GetProgramLog)(rtcProgram, char *) = nullptr;
+  int (*GetCodeSize)(rtcProgram, size_t *) = nullptr;
+  int (*GetCode)(rtcProgram, char *) = nullptr;
+  int (*DestroyProgram)(rtcProgram *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string why;
+};
+RtcApi g_rtc;
+std::mutex g_user_m;
+
+bool rtc_load()
+{
+  if (g_rtc.handle) return true;
+  if (!g_rtc.why.empty()) return false;
+  const char *names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
+  void *h = nullptr;
+  for (const char *n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) {
+    const char *de = dlerror();
+    g_rtc.why = std::string("libhiprtc.so not loadable: ") + (de ? de : "?");
+    return false;
+  }
+  bool ok = true;
+  auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) { ok = false; g_rtc.why = std::string("missing hiprtc symbol ") + n; } return p; };
+  g_rtc.CreateProgram = (decltype(g_rtc.CreateProgram))sym("hiprtcCreateProgram");
+  g_rtc.CompileProgram = (decltype(g_rtc.CompileProgram))sym("hiprtcCompileProgram");
+  g_rtc.GetProgramLogSize = (decltype(g_rtc.GetProgramLogSize))sym("hiprtcGetProgramLogSize");
+  g_rtc.GetProgramLog = (decltype(g_rtc.GetProgramLog))sym("hiprtcGetProgramLog");
+  g_rtc.GetCodeSize = (decltype(g_rtc.GetCodeSize))sym("hiprtcGetCodeSize");
+  g_rtc.GetCode = (decltype(g_rtc.GetCode))sym("hiprtcGetCode");
+  g_rtc.DestroyProgram = (decltype(g_rtc.DestroyProgram))sym("hiprtcDestroyProgram");
+  g_rtc.GetErrorString = (decltype(g_rtc.GetErrorString))sym("hiprtcGetErrorString");
+  if (!ok) return false;
+  g_rtc.handle = h;
+  return true;
+}
+
+// the flags libmcx.so itself is built with (Makefile HIPFLAGS): the MCX arithmetic is a contract on bits
+const char *const RTC_FLAGS[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                                 "-fno-gpu-flush-denormals-to-zero", "-Wno-unused-function"};
+
+// source -> code object; log = the compiler's words on failure
+int rtc_compile(const std::string &src, const char *name, const std::vector<std::string> &defs, std::vector<char> &code, std::string &log)
+{
+  if (!rtc_load()) return fail(MCX_ERR_UNSUPPORTED, "run-time compilation unavailable: %s", g_rtc.why.c_str());
+  // (a user's text may well start with #include <hip/hip_runtime.h>: hiprtc has the runtime's declarations built in and no
+  // such file, so an empty one stands in)
+  const char *hn[] = {"mcx_numerics.hpp", "mcx_device.hpp", "hip/hip_runtime.h"};
+  const char *hs[] = {k_hdr_mcx_numerics, k_hdr_mcx_device, "// the HIP runtime declarations are built into hiprtc\n"};
+  rtcProgram prog = nullptr;
+  int r = g_rtc.CreateProgram(&prog, src.c_str(), name, 3, hs, hn);
+  if (r != 0) return fail(MCX_ERR_HIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(r));
+  std::vector<const char *> opts(std::begin(RTC_FLAGS), std::end(RTC_FLAGS));
+  for (const std::string &d : defs) opts.push_back(d.c_str());
+  r = g_rtc.CompileProgram(prog, (int)opts.size(), opts.data());
+  size_t nlog = 0;
+  if (g_rtc.GetProgramLogSize(prog, &nlog) == 0 && nlog > 1) {
+    log.resize(nlog);
+    (void)g_rtc.GetProgramLog(prog, &log[0]);
+    while (!log.empty() && (log.back() == '\0' || log.back() == '\n')) log.pop_back();
+  }
+  if (r != 0) {
+    (void)g_rtc.DestroyProgram(&prog);
+    // the tail is where clang puts the error count; the head is where the first error is: keep both ends
+    std::string shown = log.size() > 3000 ? log.substr(0, 2200) + "\n[...]\n" + log.substr(log.size() - 600) : log;
+    return fail(MCX_ERR_VLFUNC, "the likelihood source does not compile (%s):\n%s", g_rtc.GetErrorString(r), shown.c_str());
+  }
+  size_t nb = 0;
+  r = g_rtc.GetCodeSize(prog, &nb);
+  if (r == 0) {
+    code.resize(nb);
+    r = g_rtc.GetCode(prog, code.data());
+  }
+  (void)g_rtc.DestroyProgram(&prog);
+  if (r != 0) return fail(MCX_ERR_HIP, "hiprtcGetCode: %s", g_rtc.GetErrorString(r));
+  return MCX_OK;
+}
+
+// What the run-time translation unit looks like around the user's text.  The user's functions live in the global
+// namespace and may use mcx_numerics.hpp (mcx::logf_v1, mcx::expf_v2, ... -- the functions the built-ins and the CPU
+// oracle use, for results that agree with them bit for bit).
+const char *const TU_HEAD =
+    "#include \"mcx_numerics.hpp\"\n"
+    "#line 1 \"mcx_user_likelihood\"\n";
+const char *const TU_TAIL =
+    "\n#line 1 \"mcx_user_kernels\"\n"
+    "#ifdef MCX_USER_BLOCK_FORM\n"
+    "#define MCX_USER_LIK 1\n"
+    "#ifndef MCX_USER_FINISH\n"
+    "__device__ __forceinline__ float mcx_user_finish(float s, int, const float *) { return s; }\n"
+    "#endif\n"
+    "#else\n"
+    "#define MCX_USER_LIK 2\n"
+    "#endif\n"
+    "#include \"mcx_device.hpp\"\n"
+    "using namespace mcx;\n"
+    "#define K extern \"C\" __global__ __launch_bounds__(BLOCK) void\n"
+    "#if MCX_USER_LPC <= 8\n"
+    "K mcx_user_fast_burn(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, false, LIK_USER, false, false>(a); tuner_epilogue(a, w); }\n"
+    "K mcx_user_fast_main(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, true, LIK_USER, false, false>(a); tuner_epilogue(a, w); }\n"
+    "K mcx_user_full_burn(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, false, LIK_USER, false, true>(a); tuner_epilogue(a, w); }\n"
+    "K mcx_user_full_main(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, true, LIK_USER, false, true>(a); tuner_epilogue(a, w); }\n"
+    "#endif\n"
+    "K mcx_user_steps_burn(const SegArgs a) { fused_steps_body<MCX_USER_LPC, LIK_USER, false>(a); }\n"
+    "K mcx_user_steps_main(const SegArgs a) { fused_steps_body<MCX_USER_LPC, LIK_USER, true>(a); }\n"
+    "K mcx_user_eval(const float *x, float *y, int n, int d, const float *lik, int ncomp, int vec4) { eval_body<MCX_USER_LPC, LIK_USER>(x, y, n, d, lik, ncomp, vec4); }\n";
+
+}  // namespace
+
+struct UserLik {
+  std::string source;
+  int lpc = 0;
+  int device = -1;
+  hipModule_t mod = nullptr;
+  hipFunction_t fast[2] = {nullptr, nullptr}, full[2] = {nullptr, nullptr}, steps[2] = {nullptr, nullptr}, eval = nullptr;
+  double compile_ms = 0.0;
+  ~UserLik() { if (mod) (void)hipModuleUnload(mod); }
+};
+
+namespace {
+std::map<std::string, std::shared_ptr<UserLik>> g_user_cache;
+}
+
+int user_lik_get(const char *source, int lpc, std::shared_ptr<UserLik> *out)
+{
+  if (!source || !*source) return fail(MCX_ERR_VLFUNC, "MCX_VL_SOURCE without source text (ctx)");
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_user_m);
+  const std::string key = std::to_string(dev) + ":" + std::to_string(lpc) + ":" + std::to_string(std::hash<std::string>{}(source)) + ":" +
+                          std::to_string(std::strlen(source));
+  auto it = g_user_cache.find(key);
+  if (it != g_user_cache.end() && it->second->source == source) {
+    *out = it->second;
+    return MCX_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<char> code;
+  std::string log;
+  MCXCHK(rtc_compile(std::string(TU_HEAD) + source + TU_TAIL, "mcx_user.hip", {"-DMCX_USER_LPC=" + std::to_string(lpc)}, code, log));
+  auto u = std::make_shared<UserLik>();
+  u->source = source;
+  u->lpc = lpc;
+  u->device = dev;
+  HIPCHK(hipModuleLoadData(&u->mod, code.data()));
+  if (lpc <= 8) {
+    HIPCHK(hipModuleGetFunction(&u->fast[0], u->mod, "mcx_user_fast_burn"));
+    HIPCHK(hipModuleGetFunction(&u->fast[1], u->mod, "mcx_user_fast_main"));
+    HIPCHK(hipModuleGetFunction(&u->full[0], u->mod, "mcx_user_full_burn"));
+    HIPCHK(hipModuleGetFunction(&u->full[1], u->mod, "mcx_user_full_main"));
+  }
+  HIPCHK(hipModuleGetFunction(&u->steps[0], u->mod, "mcx_user_steps_burn"));
+  HIPCHK(hipModuleGetFunction(&u->steps[1], u->mod, "mcx_user_steps_main"));
+  HIPCHK(hipModuleGetFunction(&u->eval, u->mod, "mcx_user_eval"));
+  u->compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("MCX_VERBOSE"))
+    fprintf(stderr, "mcx: user likelihood compiled for %d lanes per chain in %.0f ms (%zu bytes of code)\n", lpc, u->compile_ms, code.size());
+  g_user_cache[key] = u;
+  *out = u;
+  return MCX_OK;
+}
+
+// which of the user's step kernels a segment takes: the same tests as launch_fused_plain for the built-ins
+int user_lik_variant(int lpc, const mcx::SegArgs &a)
+{
+  if (lpc <= 8 && a.vec4 && !a.mask) return a.diag ? 0 : 1;  // hot-path kernel, diagonal / full factor
+  return 2;                                                   // generic kernel: any d, accept mask
+}
+
+int user_lik_launch_fused(const UserLik &u, bool main, const mcx::SegArgs &a, hipStream_t st)
+{
+  const int v = user_lik_variant(u.lpc, a);
+  hipFunction_t f = v == 0 ? u.fast[main ? 1 : 0] : (v == 1 ? u.full[main ? 1 : 0] : u.steps[main ? 1 : 0]);
+  if (!f) return fail(MCX_ERR_UNSUPPORTED, "no user step kernel for this configuration");
+  mcx::SegArgs arg = a;
+  void *args[] = {&arg};
+  const unsigned grid = (unsigned)(((size_t)a.n * u.lpc + mcx::BLOCK - 1) / mcx::BLOCK);
+  HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, mcx::BLOCK, 1, 1, 0, st, args, nullptr));
+  return MCX_OK;
+}
+
+int user_lik_launch_eval(const UserLik &u, const float *x, float *y, int n, int d, const float *par, int ncomp, hipStream_t st)
+{
+  int vec4 = (d % 4 == 0) ? 1 : 0;
+  void *args[] = {&x, &y, &n, &d, &par, &ncomp, &vec4};
+  const unsigned grid = (unsigned)(((size_t)n * u.lpc + mcx::BLOCK - 1) / mcx::BLOCK);
+  HIPCHK(hipModuleLaunchKernel(u.eval, grid, 1, 1, mcx::BLOCK, 1, 1, 0, st, args, nullptr));
+  return MCX_OK;
+}
+
+double user_lik_compile_ms(const UserLik &u) { return u.compile_ms; }
+
+extern "C" int mcx_user_source_available(void)
+{
+  std::lock_guard<std::mutex> lk(g_user_m);
+  if (rtc_load()) return 1;
+  (void)fail(MCX_ERR_UNSUPPORTED, "%s", g_rtc.why.c_str());
+  return 0;
+}
+
+// The compile step alone (no GPU needed: hiprtc cross-compiles for gfx950 like hipcc): does this text build into the
+// step kernels for a chain of `np` parameters?  -> bytes of the code object; MCX_ERR_VLFUNC + the compiler's messages if not.
+extern "C" int mcx_debug_user_source_compile(const char *source, int np, size_t *code_bytes)
+{
+  if (!source || np < 1 || np > mcx::MAXD) return fail(MCX_ERR_INVALID, "bad arguments");
+  std::lock_guard<std::mutex> lk(g_user_m);
+  std::vector<char> code;
+  std::string log;
+  MCXCHK(rtc_compile(std::string(TU_HEAD) + source + TU_TAIL, "mcx_user.hip", {"-DMCX_USER_LPC=" + std::to_string(lpc_for(np))}, code, log));
+  if (code_bytes) *code_bytes = code.size();
+  return MCX_OK;
+}
+
+// A whole user KERNEL from source (the MCX_VL_DEVICE contract: extern "C" __global__ void f(int npset, const float *x,
+// float *y)) for hosts that have no hipcc at hand: -> hipFunction_t for mcx_vlfunc.ctx.  The module lives until the
+// process ends.
+extern "C" int mcx_user_kernel_compile(const char *source, const char *symbol, void **function)
+{
+  if (!source || !symbol || !function) return fail(MCX_ERR_INVALID, "bad arguments");
+  MCXCHK(need_device());
+  std::lock_guard<std::mutex> lk(g_user_m);
+  std::vector<char> code;
+  std::string log;
+  MCXCHK(rtc_compile(std::string(TU_HEAD) + source, "mcx_user_kernel.hip", {}, code, log));
+  hipModule_t mod = nullptr;
+  hipFunction_t f = nullptr;
+  HIPCHK(hipModuleLoadData(&mod, code.data()));
+  const hipError_t ge = hipModuleGetFunction(&f, mod, symbol);
+  if (ge != hipSuccess) {
+    (void)hipModuleUnload(mod);
+    return fail(MCX_ERR_VLFUNC, "kernel '%s' not found in the compiled source (declare it extern \"C\" __global__)", symbol);
+  }
+  *function = (void *)f;
+  return MCX_OK;
+}

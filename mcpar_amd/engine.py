@@ -7,6 +7,7 @@ from ._lib import (HOSTFN, K_NAMES, OUTFN, SINKFN, TEXTSINKFN, XCHGFN, Counters,
 
 VL_ROSENBROCK1, VL_ROSENBROCK2, VL_GAUSSIAN, VL_DUALGAUSS, VL_GAUSSMIX, VL_HOST = 1, 2, 3, 4, 5, 100
 VL_DEVICE = 101
+VL_SOURCE = 102
 VL_ROSENBROCK2_FIXED = 6
 OPT_SAMPLES, OPT_ACCEPT_MASK, OPT_FUSE, OPT_MAX_SEGMENT, OPT_PROFILE, OPT_STREAM, OPT_EAGER_EXCHANGE = 1, 2, 3, 4, 5, 6, 7
 OPT_SAMPLE_STRIDE = 8
@@ -37,11 +38,27 @@ def format_rows(rows):
     return buf.raw[:nb.value]
 
 
-def make_vlfunc(kind, d, params=None, ncomp=0, host_fn=None, device_fn=None):
+def user_source_available():
+    return bool(load().mcx_user_source_available())
+
+
+def compile_user_kernel(source, symbol):
+    """HIP source of a whole kernel with the MCX_VL_DEVICE contract -> its hipFunction_t (int), through hiprtc"""
+    fn = C.c_void_p()
+    check(load().mcx_user_kernel_compile(source.encode(), symbol.encode(), C.byref(fn)))
+    return fn.value
+
+
+def make_vlfunc(kind, d, params=None, ncomp=0, host_fn=None, device_fn=None, source=None):
     """Build an mcx_vlfunc.  host_fn(x[npset, d]) -> y[npset] wraps a user VLFunc (src/vlfunc.hh:9-12);
-    device_fn is a hipFunction_t (int) of a user kernel f(int npset, const float *x, float *y).
+    device_fn is a hipFunction_t (int) of a user kernel f(int npset, const float *x, float *y);
+    source (VL_SOURCE) is HIP text of the user's device functions, params their `par`.
     Returns (struct, keepalive)."""
     p = None if params is None else np.ascontiguousarray(params, dtype=np.float32)
+    if source is not None:
+        txt = C.create_string_buffer(source.encode() if isinstance(source, str) else bytes(source))
+        v = VLFunc(kind, d, 0 if p is None else p.size, _fp(p) if p is not None else None, HOSTFN(), C.cast(txt, C.c_void_p))
+        return v, (p, txt)
     cb = HOSTFN()
     if host_fn is not None:
         def tramp(ctx, npset, x, y):
