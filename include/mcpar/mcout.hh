@@ -63,7 +63,8 @@ public:
   void text_only(bool on) { text_only_ = on; }
   bool text_only(void) const { return text_only_; }
   void write_text(const char *text, std::size_t nbytes);              // (MCPar::run's text sink; collective)
-  // addition: the text of text_only() / of a plain-text dump goes to this FILE instead of rank 0's stream, and with
+  // addition: every dump -- the text of text_only(), the rows output() prints (as "%g" text, or raw under binary()) --
+  // goes to this FILE instead of rank 0's stream, and with
   // several ranks every rank writes its own share of a block itself, at the byte offset an MPI_Exscan of the shares'
   // sizes gives it -- the file is byte for byte what the funnel through rank 0 (the scheme the reference calls a
   // stop-gap, src/mcout.cc:22-35) would have written, without 8 ranks' text squeezing through one loop.  The file
@@ -96,6 +97,7 @@ private:
   int text_fd_;                   // text_file(): this rank's descriptor of the shared file, or -1
   unsigned long long text_pos_;   // bytes of it written by all ranks so far
   void note_row(const float *row);
+  void output_to_file(void);      // output() under text_file(): every rank's own rows, text or binary, into the file
 };
 
 MCPAR_ABI_NAMESPACE_END

@@ -247,6 +247,9 @@ enum {
                               mcx_run has returned): call mcx_synchronize before anything else touches the communicator */
   MCX_OPT_SINK_TEXT = 16,    /* a row sink (mcx_set_sink) also gets every block as text: inside the callback, mcx_sink_text
                               returns the characters MCout::output would print for the block's rows [default 0] */
+  MCX_OPT_MURRAY_OVERLAP = 18, /* Murray passes over many chains (np = 16 or 32, the per-pair screen): cut the Gaussians into this
+                              many column chunks and screen chunk c + 1 (matrix cores, step stream) while chunk c is swept
+                              (vector units, a side stream).  Same bits.  0 / 1: one screen, then one sweep */
   MCX_OPT_MEET_UNDER_GATHER = 17 /* small-n mode, sharded runs: may a launch with tuner meetings -- whose workgroups must all
                               be resident at once -- start while this engine's own last gather is still in flight
                               (MCX_OPT_ASYNC_TAIL)?  0: no, the step stream waits for the gather first: no cycle of a

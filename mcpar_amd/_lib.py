@@ -49,6 +49,7 @@ def lib_path():
 
 
 _lib = None
+ABI_VERSION = 4  # include/mcx.h MCX_ABI_VERSION
 
 
 def load():
@@ -129,6 +130,13 @@ def load():
         f.restype = C.c_int
     L.mcx_last_error.restype = C.c_char_p
     L.mcx_last_error.argtypes = []
+    if os.environ.get("MCX_LIBMCX"):
+        # a substituted build (tools/persist_ab.py) must at least speak this binding's ABI: the structs above are laid out for it
+        import sys
+        print("mcpar_amd: using MCX_LIBMCX=%s instead of the package's libmcx.so" % p, file=sys.stderr)
+        got = L.mcx_abi_version()
+        if got != ABI_VERSION:
+            raise McxError(-1, "MCX_LIBMCX=%s is ABI %d, this binding is for ABI %d" % (p, got, ABI_VERSION))
     _lib = L
     return L
 

@@ -234,9 +234,83 @@ void MCout::add_rows(const float *rows, size_t nrows, bool track_best)
   stored_rows_ += static_cast<int>(nrows);
 }
 
+// rows [r0, r0 + batch) of `all` (w columns) as the reference's text -- every field followed by two blanks, "%g" -- cut
+// into pieces for the host's threads: text[t][0 .. used[t]) for t < the returned count, in row order
+static unsigned format_batch(const float *all, size_t r0, size_t batch, size_t w, unsigned nthreads,
+                             std::vector<std::vector<char> > &text, std::vector<size_t> &used)
+{
+  const unsigned nt = batch * w < (size_t(1) << 16) ? 1u : nthreads;  // (small dumps: not worth the threads)
+  const size_t per = (batch + nt - 1) / nt;
+  auto work = [&](unsigned t) {
+    const size_t a = std::min(batch, t * per), b = std::min(batch, a + per);
+    text[t].resize((b - a) * (w * 18 + 1) + 16);
+    char *p = text[t].data();
+    for (size_t r = r0 + a; r < r0 + b; ++r) {
+      const float *row = all + r * w;
+      for (size_t c = 0; c < w; ++c) {
+        p = fmtg6::append(p, row[c]);
+        *p++ = ' ';
+        *p++ = ' ';
+      }
+      *p++ = '\n';
+    }
+    used[t] = static_cast<size_t>(p - text[t].data());
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  return nt;
+}
+
+// text_file(): a dump goes to the FILE, whoever asks for it -- MCPar::run's row path when a block's GPU text is not to be
+// had, a driver's own output() call, binary() rows too.  Nothing is gathered: every rank turns its own fresh rows into
+// bytes and write_text() puts them where the ranks' sizes say, i.e. in the rank-major row order of a gathered dump
+// (src/mcout.cc:62-69).  COLLECTIVE like the gather it replaces; the ranks hold equal numbers of rows (src/mcpar.cc:225),
+// hence make the same number of write_text() calls.  The text is printf("%g")'s -- the stream, whatever state a caller
+// left it in, is not involved.
+void MCout::output_to_file()
+{
+  const size_t count = fill_ > flushed_ ? fill_ - flushed_ : 0;
+  const float *all = count ? &rows_[flushed_] : 0;
+  flushed_ = fill_;
+  if (binary_) {
+    write_text(reinterpret_cast<const char *>(all), count * sizeof(float));
+    return;
+  }
+  const size_t w = static_cast<size_t>(width_), nrows = count / w;
+  const size_t piece_rows = std::max<size_t>(1, (size_t(1) << 21) / w);
+  const unsigned nthreads = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+  std::vector<std::vector<char> > text(nthreads);
+  std::vector<size_t> used(nthreads, 0);
+  std::vector<char> joined;
+  if (nrows == 0) write_text(0, 0);  // (still collective)
+  for (size_t r0 = 0; r0 < nrows; r0 += piece_rows * nthreads) {
+    const size_t batch = std::min(nrows - r0, piece_rows * nthreads);
+    const unsigned nt = format_batch(all, r0, batch, w, nthreads, text, used);
+    size_t total = 0;
+    for (unsigned t = 0; t < nt; ++t) total += used[t];
+    joined.resize(total);
+    size_t at = 0;
+    for (unsigned t = 0; t < nt; ++t) {
+      std::memcpy(joined.data() + at, text[t].data(), used[t]);
+      at += used[t];
+    }
+    write_text(joined.data(), total);
+  }
+}
+
 // text format of the reference: every field followed by two blanks, stream-default precision
 void MCout::output()
 {
+  if (text_fd_ >= 0) {
+    output_to_file();
+    return;
+  }
   size_t count = 0;
   float *owned = 0;
   const float *all = 0;
@@ -262,37 +336,12 @@ void MCout::output()
   if (stream_prints_like_printf(os)) {
     const size_t w = static_cast<size_t>(width_), nrows = count / w;
     const size_t piece_rows = std::max<size_t>(1, (size_t(1) << 21) / w);  // ~2 M numbers (36 MB of text at most) per piece
-    unsigned nthreads = std::thread::hardware_concurrency();
-    nthreads = std::max(1u, std::min(nthreads, 16u));
+    const unsigned nthreads = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
     std::vector<std::vector<char> > text(nthreads);
     std::vector<size_t> used(nthreads, 0);
     for (size_t r0 = 0; r0 < nrows; r0 += piece_rows * nthreads) {
       const size_t batch = std::min(nrows - r0, piece_rows * nthreads);
-      const unsigned nt = batch * w < (size_t(1) << 16) ? 1u : nthreads;  // (small dumps: not worth the threads)
-      const size_t per = (batch + nt - 1) / nt;
-      auto work = [&](unsigned t) {
-        const size_t a = std::min(batch, t * per), b = std::min(batch, a + per);
-        text[t].resize((b - a) * (w * 18 + 1) + 16);
-        char *p = text[t].data();
-        for (size_t r = r0 + a; r < r0 + b; ++r) {
-          const float *row = all + r * w;
-          for (size_t c = 0; c < w; ++c) {
-            p = fmtg6::append(p, row[c]);
-            *p++ = ' ';
-            *p++ = ' ';
-          }
-          *p++ = '\n';
-        }
-        used[t] = static_cast<size_t>(p - text[t].data());
-      };
-      if (nt == 1) {
-        work(0);
-      } else {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
-      }
+      const unsigned nt = format_batch(all, r0, batch, w, nthreads, text, used);
       for (unsigned t = 0; t < nt; ++t) os.write(text[t].data(), static_cast<std::streamsize>(used[t]));
     }
     for (size_t i = nrows * w; i < count; ++i) os << all[i] << "  ";  // (a ragged tail: never, rows are whole)

@@ -403,6 +403,8 @@ extern "C" int mcx_destroy(mcx_engine *e)
   }
   if (e->meet_fd >= 0) (void)close(e->meet_fd);
   if (e->cstream) (void)hipStreamDestroy(e->cstream);
+  if (e->mstream) (void)hipStreamDestroy(e->mstream);
+  for (hipEvent_t ev : e->mev) (void)hipEventDestroy(ev);
   if (e->tstream) (void)hipStreamDestroy(e->tstream);
   if (e->ev_text) (void)hipEventDestroy(e->ev_text);
   e->sink_text_pin.release();
@@ -458,6 +460,10 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
   case MCX_OPT_MEET_TIMEOUT_MS:
     if (value < 1) return fail(MCX_ERR_INVALID, "MEET_TIMEOUT_MS must be >= 1");
     e->opt_meet_timeout_ms = (int)std::min<int64_t>(value, 600000);
+    break;
+  case MCX_OPT_MURRAY_OVERLAP:
+    if (value < 0 || value > 64) return fail(MCX_ERR_INVALID, "MURRAY_OVERLAP: 0 (off) or the number of column chunks, <= 64");
+    e->opt_murray_overlap = (int)value;
     break;
   case MCX_OPT_MEET_UNDER_GATHER: e->opt_meet_under_gather = value < 0 ? -1 : (value ? 1 : 0); break;
   case MCX_OPT_DEBUG_MEET:

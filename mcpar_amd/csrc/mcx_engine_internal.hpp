@@ -277,6 +277,9 @@ struct mcx_engine {
   // native RCCL exchange (mcx_exchange_rccl_*): in-place ncclAllGather of the musigall slots on a side stream
   ncclComm_t xcomm = nullptr;
   bool xcomm_owned = false;
+  hipStream_t mstream = nullptr;   // Murray passes by column chunks: the sweeps' stream (mcx_murray.hip: screen_sweep_chunked)
+  std::vector<hipEvent_t> mev;
+  int opt_murray_overlap = 0;
   hipStream_t xstream = nullptr;
   hipEvent_t xready = nullptr, xdone = nullptr;
   mcx_output_fn ofn = nullptr;

@@ -5,6 +5,7 @@
 #include <atomic>
 
 #include "mcx_engine_internal.hpp"
+#include <sched.h>
 #include "mcx_remote.hpp"
 #include "mcx_cull_proj.hpp"
 #include "mcx_screen.hpp"
@@ -28,6 +29,32 @@ constexpr int MULTI_MAX_CHAINS = 1024, MULTI_K = 4;  // (from 128 / 448 / 1024 /
 // / 42.7 -- the staging is not what a sweep waits for.
 // Returns the number of entries per chain the sweep leaves in pmax for k_remote_cmax_combine (!SUMS): the blocks, or
 // fewer where a wavefront carries its minimum through several of them.
+// does the row-by-row kernel take this sweep, and in what grid: blocks per wavefront, grid y (see launch_sweep_exact)
+template <int DM, bool SUMS>
+static bool sweep_is_srow(int cnt, const unsigned long long *excl, int ngroups, int S, int *bpw_out, int *gy_out)
+{
+  if constexpr (DM == 16 || DM == 32) {
+    if (excl || (DM == 16 && cnt <= SROW_UNMASKED_MAX_CHAINS)) {
+      int bpw = (excl && !SUMS) ? (int)(((long long)ngroups * S) / 8192) : 1;
+      bpw = bpw < 1 ? 1 : (bpw > SROW_MAX_BLOCKS_PER_WAVE ? SROW_MAX_BLOCKS_PER_WAVE : bpw);
+      *bpw_out = bpw;
+      *gy_out = (S + bpw - 1) / bpw;
+      return true;
+    }
+  }
+  return false;
+}
+
+// rows [y0, y0 + ny) of the row-by-row sweep's grid (a column chunk of a pass), on stream st
+template <int DM, bool SUMS>
+static void launch_srow_range(const float *x, const int *list, int cnt, const float *qpar, float *psum, float *pmax, int N, int own0,
+                              const unsigned long long *excl, int ngroups, int bpw, int y0, int ny, hipStream_t st)
+{
+  if constexpr (DM == 16 || DM == 32)
+    hipLaunchKernelGGL((k_remote_sweep_srow<DM, SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)ny), dim3(BLOCK), 0, st,
+                       x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups, bpw, y0);
+}
+
 template <int DM, bool SUMS>
 static int launch_sweep_exact(const float *x, const int *list, int cnt, const float *qpar, float *psum, float *pmax,
                               int N, int own0, const unsigned long long *excl, int ngroups, int S, hipStream_t st)
@@ -46,7 +73,7 @@ static int launch_sweep_exact(const float *x, const int *list, int cnt, const fl
       bpw = bpw < 1 ? 1 : (bpw > SROW_MAX_BLOCKS_PER_WAVE ? SROW_MAX_BLOCKS_PER_WAVE : bpw);
       const int gy = (S + bpw - 1) / bpw;
       hipLaunchKernelGGL((k_remote_sweep_srow<DM, SUMS>), dim3((unsigned)((ngroups + BLOCK / 64 - 1) / (BLOCK / 64)), gy), dim3(BLOCK), 0, st,
-                         x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups, bpw);
+                         x, list, cnt, qpar, psum, pmax, N, own0, excl, ngroups, bpw, 0);
       return SUMS ? S : gy;
     }
   }
@@ -129,9 +156,23 @@ static int cull_prepare_proj(mcx_engine *e, const float *xrows, const int *ain, 
 // The same sort, then the per-pair bound on the matrix cores (mcx_screen.hpp) in place of the boxes.  `fresh_q`: the
 // Gaussians' side (centre, B') has not been built for this genRemote call yet.  *order_out: the list the masks' groups
 // are cut from (the sorted list, or `ain` itself -- null = every chain in index order -- where nothing was sorted).
+// the screen's matrix-core kernel as screen_prepare would launch it, kept for launching by column chunks
+struct ScreenLaunch {
+  int gx = 0, bchunk = 1, nblk = 0, nact = 0, N = 0, ng = 0, nw = 0;
+  unsigned long long *nkept = nullptr;
+};
+
+template <int DMAX>
+static void screen_gemm_go(mcx_engine *e, const ScreenLaunch &L, int blk0, int blk1, hipStream_t st)
+{
+  hipLaunchKernelGGL((k_screen_gemm<DMAX>), dim3((unsigned)L.gx, (unsigned)((blk1 - blk0 + L.bchunk - 1) / L.bchunk)), dim3(SCR_WAVES * 64), 0, st,
+                     (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, L.nact, L.N, L.ng, L.bchunk, e->cull_excl.p, L.nw,
+                     L.nkept, blk0, blk1);
+}
+
 template <int DMAX>
 static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int nact, bool sums, int own0, bool *fresh_q,
-                          const int **order_out, hipStream_t st, bool may_sort = true)
+                          const int **order_out, hipStream_t st, bool may_sort = true, ScreenLaunch *defer = nullptr, int chunks = 1)
 {
   const int d = e->nparam, N = e->tchains;
   const int ng = (nact + CULL_W - 1) / CULL_W, nw = (N + 63) / 64, nblk = (N + SCR_BLK - 1) / SCR_BLK;
@@ -172,17 +213,74 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
   }
   const int resident = nb * (e->ncu > 0 ? e->ncu : 256);
   const int gx = (ng + SCR_WAVES - 1) / SCR_WAVES;
+  const int per_launch = (nblk + chunks - 1) / chunks;  // (by column chunks: every chunk's grid is sized like a whole screen's)
   const int gy_want = std::max(1, (rounds * resident) / gx);
-  int bchunk = (nblk + gy_want - 1) / gy_want;
+  int bchunk = (per_launch + gy_want - 1) / gy_want;
   if (bchunk < 1) bchunk = 1;
+  ScreenLaunch L;
+  L.gx = gx; L.bchunk = bchunk; L.nblk = nblk; L.nact = nact; L.N = N; L.ng = ng; L.nw = nw;
+  L.nkept = reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0);
+  if (defer) {
+    *defer = L;
+    HIPCHK(hipGetLastError());
+    return MCX_OK;
+  }
   {
     ProfScope sg(e, MCX_K_REMOTE_SCREEN, (uint64_t)nact * (uint64_t)N);
-    hipLaunchKernelGGL((k_screen_gemm<DMAX>), dim3((unsigned)gx, (unsigned)((nblk + bchunk - 1) / bchunk)), dim3(SCR_WAVES * 64), 0, st,
-                       (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, nact, N, ng, bchunk, e->cull_excl.p, nw,
-                       reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0));
+    screen_gemm_go<DMAX>(e, L, 0, nblk, st);
   }
   HIPCHK(hipGetLastError());
   e->cnt.kernel_launches += 1;  // (+1: the screen's own scope)
+  return MCX_OK;
+}
+
+// A pass over many chains with the per-pair screen, its Gaussians cut into `chunks` column chunks: chunk c + 1 is screened
+// on the step stream (matrix cores) while chunk c is swept on a side stream (vector units) -- the two kernels alternated
+// before, each leaving the other's pipe idle (screen 36 % + sweep 36 % of C3-murray's job).  Nothing about
+// the sums changes: block partials are per block of QBLOCK Gaussians and combined in index order as ever.  Returns false
+// (nothing launched but the preparation) where the pass does not cut evenly or is not the row-by-row kernel's.
+constexpr int OVERLAP_MIN_CHAINS = 8192;
+template <int DM, bool SUMS>
+static int screen_sweep_chunked(mcx_engine *e, const float *xrows, const int *ain, int nact, int own0, bool *fresh_q, const int **order_out,
+                                float *psum, float *pmax, int S, int chunks, int *entries_out, bool *done, hipStream_t st)
+{
+  *done = false;
+  if constexpr (DM == 16 || DM == 32) {
+    const int N = e->tchains, ng = (nact + CULL_W - 1) / CULL_W;
+    int bpw = 1, gy = S;
+    if (!sweep_is_srow<DM, SUMS>(nact, e->cull_excl.p, ng, S, &bpw, &gy)) return MCX_OK;
+    const int nblk = (N + SCR_BLK - 1) / SCR_BLK;
+    // a chunk = gy / chunks rows of the sweep's grid = bpw * QBLOCK Gaussians each = whole blocks of the screen
+    static_assert(QBLOCK % SCR_BLK == 0, "a sweep block is a whole number of screen blocks");
+    while (chunks > 1 && (gy % chunks != 0 || N % QBLOCK != 0)) chunks >>= 1;
+    if (chunks < 2) return MCX_OK;
+    const int ny = gy / chunks, blk_per = ny * bpw * (QBLOCK / SCR_BLK);
+    ScreenLaunch L;
+    MCXCHK((screen_prepare<DM>(e, xrows, ain, nact, SUMS, own0, fresh_q, order_out, st, true, &L, chunks)));
+    if (!e->mstream) HIPCHK(hipStreamCreateWithFlags(&e->mstream, hipStreamNonBlocking));
+    while ((int)e->mev.size() < chunks + 1) {
+      hipEvent_t ev = nullptr;
+      HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      e->mev.push_back(ev);
+    }
+    {
+      // (profile: the phase as a whole counts as the sweep -- the screen has no time of its own any more)
+      ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)nact * (uint64_t)N);
+      for (int c = 0; c < chunks; ++c) {
+        const int b0 = c * blk_per, b1 = std::min(nblk, b0 + blk_per);
+        screen_gemm_go<DM>(e, L, b0, b1, st);
+        HIPCHK(hipEventRecord(e->mev[c], st));
+        HIPCHK(hipStreamWaitEvent(e->mstream, e->mev[c], 0));
+        launch_srow_range<DM, SUMS>(xrows, *order_out, nact, e->winvall.p, psum, pmax, N, own0, e->cull_excl.p, ng, bpw, c * ny, ny, e->mstream);
+      }
+      HIPCHK(hipEventRecord(e->mev[chunks], e->mstream));
+      HIPCHK(hipStreamWaitEvent(st, e->mev[chunks], 0));
+    }
+    HIPCHK(hipGetLastError());
+    e->cnt.kernel_launches += 2 * chunks - 1;
+    *entries_out = SUMS ? S : gy;
+    *done = true;
+  }
   return MCX_OK;
 }
 
@@ -232,6 +330,7 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
   // 0.999 like the boxes -- there a pair is dead because the chain is far from the Gaussian in the 31 directions ACROSS
   // the mixture's axis (the per-chain Gaussians are still narrow), which no bound for 128 chains at once can see.
   const bool proj = e->opt_cull == 2;
+  const int overlap = e->opt_murray_overlap;  // column chunks of a big pass: the next chunk's screen beside this chunk's sweep (0 / 1: off)
   bool fresh_q = true;
   // (the screens' cells and, right behind them, the word k_remote_decide counts its workgroups in)
   HIPCHK(hipMemsetAsync(e->nact.p + 2, 0, 2 * CULL_NCOUNT * sizeof(unsigned long long) + 2 * sizeof(int), st));
@@ -258,9 +357,15 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     const int *order = nullptr;
     const unsigned long long *excl = nullptr;
     int S_min = S;  // entries per chain the min-arg sweep leaves for the combining kernel
+    bool swept = false;  // the screen and the sweep went out together, by column chunks
     if (cull) {
       order = e->cull_sorted.p;
-      if (gemm) {  // (boxes here and the per-pair bound for the sums only: C3-murray 18.1 -> 25.6 ms, C5 26.0 -> 38.8)
+      if (gemm && overlap > 1 && n >= OVERLAP_MIN_CHAINS && d == dm) {
+        DISPATCH_DMAX(dm, MCXCHK((screen_sweep_chunked<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16, false>(
+                              e, pvals, nullptr, n, own0, &fresh_q, &order, (float *)nullptr, e->pmax.p, S, overlap, &S_min, &swept, st))));
+      }
+      if (swept) {
+      } else if (gemm) {  // (boxes here and the per-pair bound for the sums only: C3-murray 18.1 -> 25.6 ms, C5 26.0 -> 38.8)
         DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, &fresh_q, &order, st))));
       } else if (proj) {
         DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, pvals, nullptr, n, false, own0, st))));
@@ -271,7 +376,7 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     } else {
       evaluated_host += (uint64_t)n * (uint64_t)N;
     }
-    {
+    if (!swept) {
       ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)n * (uint64_t)N);
       if (d == dm) {
         DISPATCH_DMAX(dm, (S_min = launch_sweep_exact<DMAX_, false>(pvals, order, n, e->winvall.p, (float *)nullptr, e->pmax.p,
@@ -355,9 +460,16 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       const bool cull = cull_now(nact) && cull_sums;
       const int *list = ain;
       const unsigned long long *excl = nullptr;
+      bool swept = false;
       if (cull) {  // the proposals have just been drawn: sort, box and test them
         list = e->cull_sorted.p;
-        if (gemm) {
+        if (gemm && overlap > 1 && nact >= OVERLAP_MIN_CHAINS && d == dm) {
+          int entries = S;
+          DISPATCH_DMAX(dm, MCXCHK((screen_sweep_chunked<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16, true>(
+                                e, ptrial, ain, nact, -1, &fresh_q, &list, e->psum.p, e->pmax.p, S, overlap, &entries, &swept, st))));
+        }
+        if (swept) {
+        } else if (gemm) {
           DISPATCH_DMAX(dm, MCXCHK((screen_prepare<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, &fresh_q, &list, st))));
         } else if (proj) {
           DISPATCH_DMAX(dm, MCXCHK((cull_prepare_proj<(DMAX_ == 16 || DMAX_ == 32) ? DMAX_ : 16>(e, ptrial, ain, nact, true, -1, st))));
@@ -369,7 +481,7 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       } else {
         evaluated_host += (uint64_t)nact * (uint64_t)N;
       }
-      {
+      if (!swept) {
       ProfScope sw(e, MCX_K_REMOTE_SWEEP, (uint64_t)nact * (uint64_t)N);
       if (d == dm) {
         DISPATCH_DMAX(dm, (launch_sweep_exact<DMAX_, true>(ptrial, list, nact, e->winvall.p, e->psum.p, e->pmax.p, N,
@@ -394,11 +506,27 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
       // the wait on one box: C3-murray 16.2 -> 16.1 ms, C5 23.6 -> 23.4: the counters' way over PCIe is 6-11 us of the
       // kernel now, what the copy kernel and its launch were) -- with a look at the stream now and then, so that a
       // launch that failed or a device that is gone ends the wait
+      // The busy wait is BOUNDED: a short pass answers within tens of microseconds and is worth a core's
+      // attention; past SPIN_US the thread yields between looks (8 ranks + their MCout formatting threads + MPI progress
+      // on 16 cores: a spinning waiter must not hold a core from the work it waits for), and past YIELD_US it sleeps in
+      // hipStreamSynchronize like any other wait.
+      constexpr long SPIN_US = 60, YIELD_US = 2000;
       volatile unsigned long long *const flag = back + a.nflag;
+      const auto t_wait = std::chrono::steady_clock::now();
+      bool polite = false;
       for (unsigned spins = 0; __atomic_load_n(const_cast<unsigned long long *>(flag), __ATOMIC_ACQUIRE) != a.serial; ++spins) {
+        if (!polite) {
 #if defined(__x86_64__) || defined(__i386__)
-        __builtin_ia32_pause();  // (the sibling hyperthread and the other engines' threads get the core's issue slots)
+          __builtin_ia32_pause();  // (the sibling hyperthread gets the core's issue slots)
 #endif
+        } else {
+          sched_yield();
+        }
+        if ((spins & 0xffu) == 0xffu || polite) {
+          const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wait).count();
+          if (us > YIELD_US) break;  // (the blocking wait below)
+          polite = us > SPIN_US;
+        }
         if ((spins & 0xfffu) == 0xfffu) {
           const hipError_t q = hipStreamQuery(st);
           if (q == hipSuccess) break;  // the stream is empty: the word is there (or never will be: checked below)
@@ -489,7 +617,7 @@ extern "C" int mcx_debug_murray_screen(int d, int nact, int N, const float *x, c
       hipLaunchKernelGGL((k_screen_prep_x<DM, false>), gp, dim3(BLOCK), 0, st, (const float *)dx.p, (const int *)nullptr, nact, ng * CULL_W, \
                          (const float *)q.p, own0, (const float *)centre.p, A.p, stats.p, hist.p);                               \
     hipLaunchKernelGGL((k_screen_gemm<DM>), gg, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)A.p, (const unsigned short *)B.p, nact, N, \
-                       ng, 1, excl.p, nw, kept.p);
+                       ng, 1, excl.p, nw, kept.p, 0, nblk);
     if (d == 16) { SCREEN_FOR(16) } else { SCREEN_FOR(32) }
 #undef SCREEN_FOR
     HIPCHK(hipGetLastError());

@@ -32,8 +32,15 @@
 // partitioned device or a foreign kernel holding LDS can still keep workgroups out, so a meeting that is not
 // complete after RunArgs::meet_timeout ticks of the 100 MHz wall clock is ABANDONED -- the waiting owner marks
 // the meeting's leaves, every owner that sees the mark goes on with a count of zero and skips the meetings that
-// follow, the launch runs to its end WITHOUT writing state back, ctr[5] tells the host, and mcx_run repeats the run on
-// the per-segment kernels.  Launches of main-loop steps only have no meetings.
+// follow, the launch runs to its end without its EPILOGUE (chain state x / ly / T, moments mu / psum2, accept counts,
+// tuner counters, ntrace stay as they were), ctr[5] tells the host, and mcx_run repeats the run on the per-segment
+// kernels.  What an abandoned launch DOES dirty, because the recording of a phase is not predicated on the flag (the
+// owner / recorder wavefronts are the latency-critical ones): the sample rows samp_x / samp_ly of the steps it got to,
+// the shard's musigall slot and sig (the snapshot / final publish), trace[].  All of them are rewritten in full by the
+// repeated run before anything may look at them, and NOTHING may look before meet_release() has read ctr[5]: every
+// host path that hands results out -- getters, the output hook, the sink, exchange begin / publish -- goes through it
+// (mcx_engine.hip: meet_release callers).  A new consumer of those buffers must do the same.
+// Launches of main-loop steps only have no meetings.
 #pragma once
 #include "mcx_device.hpp"
 
@@ -583,8 +590,8 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
                                                        a.meet_timeout);
 #else
             // An abandoned meeting (wave-uniform) does not cut the phase short: the wave goes on with a count of zero,
-            // skips later meetings, and the flag ends the launch at the next phase boundary; nothing an abandoned
-            // launch computes is ever written back.
+            // skips later meetings, and the flag makes the launch skip its epilogue; what an abandoned launch may have
+            // dirtied on the way (sample rows, the slot snapshot, trace[]) is listed at the top of this file.
             unsigned long long seg = 0;
             if (!aborted) {
               seg = owners_meet(a.bar + (size_t)nevent * PLEAVES, wacc, own_here, nwg, &lds_sum, &lds_cnt, &lds_out[nevent], a.meet_timeout);
@@ -707,7 +714,7 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // (every iteration ends with a barrier: a flag raised during the last phase is visible here)
   if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) aborted = true;
-  if (aborted) return;  // abandoned launch: nothing is written back, the host repeats the run (ctr[5] is set)
+  if (aborted) return;  // abandoned launch: no state is written back, the host repeats the run (ctr[5] is set)
   if (owner) {
     if (live) {
 #pragma unroll

@@ -444,9 +444,10 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow(const float *__rest
                                                                int nact, const float *__restrict__ qpar,
                                                                float *__restrict__ psum, float *__restrict__ pmax, int N,
                                                                int own0, const unsigned long long *__restrict__ excl,
-                                                               int ngroups, int bpw)
+                                                               int ngroups, int bpw, int y0)
 {
   static_assert(DMAX == 16 || DMAX == 32, "rows of one or two 16-dimension halves");
+  const int by = (int)blockIdx.y + y0;  // (y0 > 0: a column chunk of the pass, launched on its own: mcx_murray.hip)
   // dimensions per half-row, halves, dimensions between two early-out tests (two tests per row: behind the per-pair
   // screen few rows leave early, and four tests cost 1.5 % of both Murray jobs more than two or one)
   constexpr int H = 16, NH = DMAX / H, G = DMAX / 2;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow(const float *__rest
   // DESIGN.md S3.5); !SUMS: the minimum runs on through the wavefront's blocks and is stored once, at "block"
   // blockIdx.y (the combining kernel takes a minimum: fewer entries, the same result).
   const int nsb = (N + QBLOCK - 1) / QBLOCK;
-  const int sb0 = (int)blockIdx.y * bpw, sb1 = sb0 + bpw < nsb ? sb0 + bpw : nsb;
+  const int sb0 = by * bpw, sb1 = sb0 + bpw < nsb ? sb0 + bpw : nsb;
   int pos[2], jj[2];
   bool valid[2];
 #pragma unroll
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow(const float *__rest
   if (!SUMS) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-      if (valid[c]) pmax[(size_t)blockIdx.y * nact + pos[c]] = c == 0 ? amin.x : amin.y;
+      if (valid[c]) pmax[(size_t)by * nact + pos[c]] = c == 0 ? amin.x : amin.y;
   }
 }
 

@@ -216,7 +216,7 @@ template <int DMAX>
 __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
                                                                 int nact, int N, int ngroups, int bchunk,
                                                                 unsigned long long *__restrict__ excl, int excl_words,
-                                                                unsigned long long *__restrict__ nkept)
+                                                                unsigned long long *__restrict__ nkept, int blk0, int blk1)
 {
   constexpr int K = scr_k(DMAX), KS = K / 16, ROWB = K * 2, LROW = ROWB + 16;
   constexpr int NT = SCR_WAVES * 64, CH = SCR_BLK * ROWB / 16, PER = (CH + NT - 1) / NT;
@@ -234,8 +234,10 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigne
       const size_t pos = (size_t)(have_g ? g : 0) * CULL_W + rt * 32 + r;
       a[rt][s] = *reinterpret_cast<const scr_bf16x8 *>(A + pos * K + s * 16 + h * 8);
     }
-  const int nblk = (N + SCR_BLK - 1) / SCR_BLK;
-  const int b0 = (int)blockIdx.y * bchunk, b1 = b0 + bchunk < nblk ? b0 + bchunk : nblk;
+  // this launch's blocks of Gaussians: [blk0, blk1) of the ceil(N / SCR_BLK) there are (all of them, or one column chunk of
+  // a pass whose sweep runs beside the next chunk's screen: mcx_murray.hip)
+  const int nblk = blk1;
+  const int b0 = blk0 + (int)blockIdx.y * bchunk, b1 = b0 + bchunk < nblk ? b0 + bchunk : nblk;
   if (b0 >= b1) return;  // (the whole workgroup)
   scr_u32x4 hold[PER];
   {

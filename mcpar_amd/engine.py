@@ -20,6 +20,7 @@ OPT_BLOCKS_PER_LANE = 14
 OPT_ASYNC_TAIL = 15
 OPT_SINK_TEXT = 16
 OPT_MEET_UNDER_GATHER = 17
+OPT_MURRAY_OVERLAP = 18
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 

@@ -111,3 +111,40 @@ def test_exclusion_keeps_nan_and_degenerate_inputs_identical():
             assert same_bits(a, b), (mode, name)
         eg.close()
 
+
+
+@pytest.mark.parametrize("cfg,chunks", [("rosen16", 4), ("rosen16", 8), ("mix32", 2), ("mix32", 8)])
+def test_big_passes_by_column_chunks_on_two_streams_same_bits(cfg, chunks):
+    """MCX_OPT_MURRAY_OVERLAP: the Gaussians of a pass over many chains cut into column chunks, chunk c + 1 screened on the
+    matrix cores while chunk c is swept on the vector units (src/mcpar.cc:367-395 is one loop over all Gaussians there; block
+    partials are combined in index order whatever stream produced them): the whole job must equal the oracle bit for bit,
+    pass counts included, and the chunked launches must really have happened"""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    if cfg == "rosen16":
+        d, n, nburn, nsamp, pl = 16, 16384, 300, 40, 0.85
+        spec_o, spec_g = (O.VL_ROSENBROCK1, d), (M.VL_ROSENBROCK1, d)
+    else:
+        d, n, nburn, nsamp, pl = 32, 8192, 300, 40, 0.85
+        par = mix_params(d, 8)
+        spec_o, spec_g = (O.VL_GAUSSMIX, d, par, 8), (M.VL_GAUSSMIX, d, par, 8)
+    p = O.default_pinit(d, n)
+    vo, _k = O.make_vlfunc(*spec_o)
+    eo = O.Engine(d, n, pl=pl, threads=THREADS)
+    eo.set_record(samples=False, mask=False)
+    eo.run(nsamp, nburn, p, vo)
+    assert eo.remote_steps > 0
+    launches = {}
+    for c in (0, chunks):
+        vg, _k2 = M.make_vlfunc(*spec_g)
+        eg = M.Engine(d, n, pl=pl)
+        eg.set_option(E.OPT_SAMPLES, 0)
+        eg.set_option(E.OPT_MURRAY_OVERLAP, c)
+        eg.run(nsamp, nburn, p, vg)
+        cn = eg.counters
+        assert (cn["remote_steps"], cn["remote_passes"], cn["naccept_main"]) == (eo.remote_steps, eo.remote_passes, eo.naccept_main), c
+        for name in ("state", "loglike", "mean", "var", "musigall"):
+            assert same_bits(getattr(eg, name), getattr(eo, name)), (c, name)
+        launches[c] = cn["kernel_launches"]
+        eg.close()
+    assert launches[chunks] > launches[0]  # two big passes per Murray step went out as 2 * chunks launches each

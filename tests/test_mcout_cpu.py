@@ -132,7 +132,11 @@ def test_text_written_side_by_side_equals_the_funnel(tmp_path, nranks):
                          timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
-    assert lines[0] == "funnel in dump order" and lines[1].startswith("same ") and lines[1].endswith("%d ranks" % nranks), out.stdout
+    # output() under text_file() -- the row path, as text between write_text blocks and as raw rows under binary() -- lands in
+    # the file, in dump order, and nowhere else (it used to go to the stream and leave the file short)
+    assert lines[0].startswith("rows same ") and lines[1].startswith("binary same %d bytes" % (nranks * (7 + 8 + 9) * 12)), out.stdout
+    assert lines[2] == "funnel in dump order" and lines[3].startswith("same ") and lines[3].endswith("%d ranks" % nranks), out.stdout
+    assert len(lines) == 4, out.stdout
 
 
 def test_percent_g_is_the_reference_row_format():
