@@ -772,7 +772,10 @@ def main():
                    unit="TFLOP/s", frac=ach / FP32_VALU_PEAK, pairs=sw["chain_steps"], flop_per_pair=3 * dd + 4,
                    launches=sw["launches"], total_ms=sw["ms"], remote_steps=cn["remote_steps"], passes=cn["remote_passes"],
                    whole_genremote_ms=pr["remote"]["ms"], pairs_evaluated=cn.get("remote_pairs_evaluated"),
-                   pairs_evaluated_frac=kept)
+                   pairs_evaluated_frac=kept,
+                   pairs_evaluated_note="approximate: the groups of 128 chains the masks are made for depend on a counting sort's "
+                                        "atomics, so the count of pairs left varies by a few in ten thousand from run to run; "
+                                        "results and pass counts do not")
         if kept is not None:
             # `achieved` counts the algorithm's pairs, skipped or not (with the screens it passes the vector peak: the
             # point of them); this is the rate on the pairs the sweeps actually swept

@@ -47,4 +47,33 @@ public:
   }
 };
 
+// A likelihood supplied as HIP SOURCE of device functions (MCX_VL_SOURCE, include/mcx.h): the engine compiles it into its
+// own fused step kernels at run time -- one launch per segment of steps, chain state in registers, like the built-in
+// functors (a separately compiled DeviceVLFunc kernel costs three launches per step).  The text defines
+//   __device__ float mcx_user_loglike(const float *x, int d, const float *par);            // one parameter set
+// or the per-block form described in mcx.h.  `params` (np_par floats) arrive as `par`.  The text and the parameters
+// are copied; the object may be used for any number of runs.
+#include <string>
+#include <vector>
+class SourceVLFunc : public VLFunc {
+  const int n;
+  const std::string text;
+  const std::vector<float> par;
+public:
+  SourceVLFunc(int np, const char *hip_source, const float *params = 0, int np_par = 0)
+      : n(np), text(hip_source ? hip_source : ""), par(params, params + (params ? np_par : 0)) {}
+  bool device_descriptor(int, mcx_vlfunc *o) const
+  {
+    *o = mcx_vlfunc{MCX_VL_SOURCE, n, (int)par.size(), par.empty() ? 0 : par.data(), 0,
+                    const_cast<char *>(text.c_str())};
+    return true;
+  }
+  int operator()(int npset, const float *x, float *restrict y)
+  {
+    mcx_vlfunc f;
+    device_descriptor(n, &f);
+    return mcx_vlfunc_eval(&f, npset, x, y) == MCX_OK ? 0 : 1;
+  }
+};
+
 #endif

@@ -71,7 +71,10 @@ enum {
  *     __device__ float mcx_user_finish(float sum, int d, const float *par);             // log L from the sum (default: sum)
  *
  * The partials are added in the order of the built-ins, so a restatement of a built-in returns
- * its bits.  "mcx_numerics.hpp" is already included: mcx::logf_v1, mcx::expf_v2, ... are the engine's (and the CPU
+ * its bits.  MCX_USER_NP (= np) and MCX_USER_LPC (= the number of 4-parameter blocks, rounded up to a power of two) are
+ * defined when the text is compiled: loops over them unroll, small arrays stay in registers.  In the whole-vector form a
+ * chain of np <= 16 is held by ONE lane (four blocks per lane) and the function runs once per chain; above that by
+ * np / 16 lanes, each of which evaluates it.  "mcx_numerics.hpp" is already included: mcx::logf_v1, mcx::expf_v2, ... are the engine's (and the CPU
  * oracle's) own transcendentals.  Compiled with -O3 -ffp-contract=off (write fma explicitly: __builtin_fmaf), once per
  * (text, np) per process; a text that does not compile fails mcx_run with MCX_ERR_VLFUNC and the compiler's messages
  * in mcx_last_error().  Without libhiprtc: MCX_ERR_UNSUPPORTED (MCX_VL_DEVICE and MCX_VL_HOST remain). */

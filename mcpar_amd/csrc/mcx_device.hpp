@@ -188,8 +188,11 @@ struct Lik<LIK_USER, LPC> {
     const float acc = nv > 0 ? ::mcx_user_block(xb, nv, k0, d, par) : 0.0f;
     return ::mcx_user_finish(group_sum<LPC>(acc), d, par);
 #else
-    __shared__ __attribute__((aligned(16))) float xs[BLOCK * 4];
-    float *mine = xs + 4 * ((int)threadIdx.x & ~(LPC - 1));  // the chain's vector, contiguous: lane q holds x[4q .. 4q+3]
+    // the chain's vector, contiguous (lane q holds x[4q .. 4q+3]); an odd stride between chains: the lanes of a wavefront
+    // read x[k] of different chains from different banks
+    constexpr int CS = 4 * LPC + 1;
+    __shared__ float xs[(BLOCK / LPC) * CS];
+    float *mine = xs + ((int)threadIdx.x / LPC) * CS;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (k < nv) mine[k0 + k] = xb[k];
@@ -723,9 +726,18 @@ __device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a)
   static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX || (LIK == LIK_ROSEN2F && !PREGEN && !FULL) || (LIK == LIK_USER && !PREGEN),
                 "fast path: Rosenbrock1, diagonal Gaussian, a mixture of <= 8 unit Gaussians, (plain kernel only) the overlapping Rosenbrock, or a user's source");
   static_assert(!(FULL && PREGEN), "the pre-generated normals are laid out for diagonal proposals");
-  __shared__ __attribute__((aligned(16))) float4 lds_T[FULL ? 4 * LPC * LPC : 1];
+  // MCX_FULL_T_REGS: up to 16-D (<= 64 registers) a lane's four rows of the factor live in REGISTERS for the whole launch
+  // instead of being re-read from LDS every step: 16-D 2.78 -> 2.73 ms per job (tools/fullcov_ab.sh).  At 32-D the same
+  // takes 128 registers -- two wavefronts per SIMD instead of four -- and LOSES: 6.31 -> 6.91 ms, although 32 of the
+  // lane's 41 LDS reads per step go away; there the factor stays in LDS and the work is cut by k_fused_fastb's mirrored
+  // layout instead (mcx_fastb.hpp).  0: the factor in LDS everywhere (the round-2 kernel), for A/B.
+#ifndef MCX_FULL_T_REGS
+#define MCX_FULL_T_REGS 1
+#endif
+  constexpr bool TREGS = FULL && LPC <= 4 && (MCX_FULL_T_REGS != 0);
+  __shared__ __attribute__((aligned(16))) float4 lds_T[FULL && !TREGS ? 4 * LPC * LPC : 1];
   __shared__ __attribute__((aligned(16))) float4 lds_z[FULL && LPC == 8 ? (BLOCK / 8) * 9 : 1];
-  if (FULL) {
+  if (FULL && !TREGS) {
     const int dd = a.d;
     // slot [(qq * 4 + c) * LPC + qv] = column 4 qq + c of the four rows of lane qv, as (row 0, row 2, row 1, row 3):
     // the two halves are the packed operands of the lane's (x0, x2) / (x1, x3) accumulators
@@ -770,6 +782,19 @@ __device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a)
       se = f32x2{p.x, p.z}; so = f32x2{p.y, p.w};
     }
   }
+  // FULL, factor in registers: column col of this lane's rows (0, 2) and (1, 3) -- the packed operands of the two
+  // multiply-adds a column costs; zero beyond the matrix (and, the factor being lower triangular, beyond the diagonal)
+  f32x2 tre[TREGS ? 4 * LPC : 1], tro[TREGS ? 4 * LPC : 1];
+  if (TREGS) {
+#pragma unroll
+    for (int col = 0; col < 4 * LPC; ++col) {
+      const bool in = live && col < d;
+      tre[col] = in ? f32x2{a.T[(k0 + 0) * d + col], a.T[(k0 + 2) * d + col]} : f32x2{0.0f, 0.0f};
+      tro[col] = in ? f32x2{a.T[(k0 + 1) * d + col], a.T[(k0 + 3) * d + col]} : f32x2{0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int col = 0; col < 4 * LPC; ++col) asm volatile("" ::"v"(tre[col]), "v"(tro[col]));  // (awaited here, once: see below)
+  }
   f32x2 gme = {0, 0}, gmo = {0, 0};  // Gaussian: this lane's means and 1/sigma^2 (lik = mu[d], s2inv[d])
   float gs0 = 0, gs1 = 0, gs2 = 0, gs3 = 0;
   if (LIK == LIK_GAUSS && live) {
@@ -808,11 +833,19 @@ __device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a)
         else zz = make_float4(quad_bcast<LPC>(zv[0], qq), quad_bcast<LPC>(zv[1], qq), quad_bcast<LPC>(zv[2], qq), quad_bcast<LPC>(zv[3], qq));
         const float zc[4] = {zz.x, zz.y, zz.z, zz.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {  // one read = column 4 qq + c of the lane's four rows: two packed multiply-adds
-          const float4 tr = lds_T[(qq * 4 + c) * LPC + q];
-          ae = fma2(f32x2{tr.x, tr.y}, splat2(zc[c]), ae);
-          ao = fma2(f32x2{tr.z, tr.w}, splat2(zc[c]), ao);
+        for (int c = 0; c < 4; ++c) {  // column 4 qq + c of the lane's four rows: two packed multiply-adds
+          if (TREGS) {
+            ae = fma2(tre[qq * 4 + c], splat2(zc[c]), ae);
+            ao = fma2(tro[qq * 4 + c], splat2(zc[c]), ao);
+          } else {
+            const float4 tr = lds_T[(qq * 4 + c) * LPC + q];  // (one read = the column's four entries)
+            ae = fma2(f32x2{tr.x, tr.y}, splat2(zc[c]), ae);
+            ao = fma2(f32x2{tr.z, tr.w}, splat2(zc[c]), ao);
+          }
         }
+        // (pinned once per column block: the multiply-adds are pure and get sunk behind ALL the step's reads of T
+        // otherwise -- every entry read stays alive until then: mcx_fastb.hpp found 380 registers wanted that way)
+        if (!TREGS) asm volatile("" : "+v"(ae), "+v"(ao));
       }
       if (LPC == 8) __builtin_amdgcn_wave_barrier();  // this step's reads precede the next step's write
       pe = ae;

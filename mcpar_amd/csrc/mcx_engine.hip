@@ -144,7 +144,7 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
     break;
   case MCX_VL_SOURCE: {
     if (f->ncomp < 0 || (f->ncomp > 0 && !f->params)) return fail(MCX_ERR_INVALID, "MCX_VL_SOURCE: ncomp floats of params expected");
-    MCXCHK(user_lik_get(static_cast<const char *>(f->ctx), lpc_for(d), &L.user));  // (cached: compiled on first use)
+    MCXCHK(user_lik_get(static_cast<const char *>(f->ctx), d, &L.user));  // (cached: compiled on first use)
     L.kind = LIK_USER;
     L.ncomp = f->ncomp;
     h.assign(f->params, f->params + (f->params ? f->ncomp : 0));
@@ -165,13 +165,18 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
 
 // The fused-kernel families are compiled in their own translation units (mcx_k_fast.hip,
 // mcx_k_pregen.hip, mcx_k_generic_*.hip) so that the library builds in parallel; see mcx_launch.hpp.
-static int launch_fused_plain(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st, bool fast, int bpl = 1)
+static int launch_fused_plain(int lpc, int lik, bool main, const SegArgs &a, hipStream_t st, bool fast, int bpl = 1, int full_bpl = 0)
 {
   hipError_t err;
   const bool fast_lik = lik == LIK_ROSEN1 || lik == LIK_GAUSS || (lik == LIK_MIX && a.ncomp <= 8);
   if (fast && fast_lik && bpl > 1 && bpl <= lpc) err = mcxk_launch_fastb(lpc, bpl, lik, main, a, st);  // hot path, several blocks per lane
   else if (fast) err = mcxk_launch_fast(lpc, lik, main, a, st);  // hot path
-  else if (lpc <= 8 && fast_lik && !a.diag && a.vec4 && !a.mask) err = mcxk_launch_fast_full(lpc, lik, main, a, st);
+  else if (lpc <= 8 && fast_lik && !a.diag && a.vec4 && !a.mask) {
+    // full covariance: one block per lane, or two mirrored ones (mcx_fastb.hpp) -- bpl as MCX_OPT_BLOCKS_PER_LANE says,
+    // else what tools/fullcov_ab.sh measured best per size
+    const bool mirrored = (lpc == 4 || lpc == 8) && (full_bpl == 2 || (full_bpl == 0 && lpc == 8));
+    err = mirrored ? mcxk_launch_fastb_full(lpc, lik, main, a, st) : mcxk_launch_fast_full(lpc, lik, main, a, st);
+  }
   else err = main ? mcxk_launch_generic_main(lpc, lik, a, st) : mcxk_launch_generic_burn(lpc, lik, a, st);
   if (err == hipErrorInvalidValue) return fail(MCX_ERR_UNSUPPORTED, "no fused kernel for lanes/chain = %d, likelihood %d", lpc, lik);
   HIPCHK(err);
@@ -256,7 +261,7 @@ static int launch_fused(mcx_engine *e, bool main, const SegArgs &a, hipStream_t 
     int bpl = e->opt_bpl;
     if (bpl == 0) bpl = (lik == LIK_MIX && lpc == 8) ? 2 : 1;
     while (bpl > lpc) bpl >>= 1;
-    return launch_fused_plain(lpc, lik, main, a, st, fast, bpl);
+    return launch_fused_plain(lpc, lik, main, a, st, fast, bpl, e->opt_bpl);
   }
   // generator and step kernel alternate on the engine's stream (overlapping them on two streams was
   // measured slower: the cross-stream event waits cost more than the generator, which is ~10 % of a chunk)

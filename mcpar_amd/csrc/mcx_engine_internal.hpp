@@ -144,7 +144,7 @@ struct PinBuf {
 // device-side likelihood descriptor built from an mcx_vlfunc
 // mcx_user.hip: a user's likelihood source compiled into the step kernels at run time (MCX_VL_SOURCE)
 struct UserLik;
-int user_lik_get(const char *source, int lpc, std::shared_ptr<UserLik> *out);  // compiled once per (source, lanes per chain)
+int user_lik_get(const char *source, int np, std::shared_ptr<UserLik> *out);  // compiled once per (source, np)
 int user_lik_launch_fused(const UserLik &u, bool main, const SegArgs &a, hipStream_t st);
 int user_lik_launch_eval(const UserLik &u, const float *x, float *y, int n, int d, const float *par, int ncomp, hipStream_t st);
 int user_lik_variant(int lpc, const SegArgs &a);  // 0 hot-path kernel, 1 its full-covariance form, 2 the generic kernel

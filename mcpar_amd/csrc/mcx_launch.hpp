@@ -9,6 +9,8 @@ hipError_t mcxk_launch_fast(int lpc, int lik, bool main, const mcx::SegArgs &a, 
 hipError_t mcxk_launch_fastb(int lpc, int bpl, int lik, bool main, const mcx::SegArgs &a, hipStream_t st);  // mcx_k_fastb.hip
 // full lower-triangular factor a.T (a.diag == 0), np <= 32, np % 4 == 0
 hipError_t mcxk_launch_fast_full(int lpc, int lik, bool main, const mcx::SegArgs &a, hipStream_t st);  // mcx_k_fast_full.hip
+// the same with two mirrored blocks per lane (mcx_fastb.hpp, FULL): lpc = 4 or 8
+hipError_t mcxk_launch_fastb_full(int lpc, int lik, bool main, const mcx::SegArgs &a, hipStream_t st);  // mcx_k_fastb_full.hip
 // small-n mode: a.zpre / a.upre must hold the output of mcxk_launch_gen for the same (t0, nsteps)
 hipError_t mcxk_launch_fast_pregen(int lpc, int lik, bool main, const mcx::SegArgs &a, hipStream_t st);  // mcx_k_pregen.hip
 hipError_t mcxk_launch_gen(int lpc, float *Z, float *U, int n, int d, int nsteps, uint32_t t0, uint32_t g0,

@@ -72,10 +72,10 @@ int rtc_compile(const std::string &src, const char *name, const std::vector<std:
   if (!rtc_load()) return fail(MCX_ERR_UNSUPPORTED, "run-time compilation unavailable: %s", g_rtc.why.c_str());
   // (a user's text may well start with #include <hip/hip_runtime.h>: hiprtc has the runtime's declarations built in and no
   // such file, so an empty one stands in)
-  const char *hn[] = {"mcx_numerics.hpp", "mcx_device.hpp", "hip/hip_runtime.h"};
-  const char *hs[] = {k_hdr_mcx_numerics, k_hdr_mcx_device, "// the HIP runtime declarations are built into hiprtc\n"};
+  const char *hn[] = {"mcx_numerics.hpp", "mcx_device.hpp", "mcx_fastb.hpp", "hip/hip_runtime.h"};
+  const char *hs[] = {k_hdr_mcx_numerics, k_hdr_mcx_device, k_hdr_mcx_fastb, "// the HIP runtime declarations are built into hiprtc\n"};
   rtcProgram prog = nullptr;
-  int r = g_rtc.CreateProgram(&prog, src.c_str(), name, 3, hs, hn);
+  int r = g_rtc.CreateProgram(&prog, src.c_str(), name, 4, hs, hn);
   if (r != 0) return fail(MCX_ERR_HIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(r));
   std::vector<const char *> opts(std::begin(RTC_FLAGS), std::end(RTC_FLAGS));
   for (const std::string &d : defs) opts.push_back(d.c_str());
@@ -119,9 +119,16 @@ const char *const TU_TAIL =
     "#else\n"
     "#define MCX_USER_LIK 2\n"
     "#endif\n"
-    "#include \"mcx_device.hpp\"\n"
+    "#include \"mcx_fastb.hpp\"\n"
     "using namespace mcx;\n"
     "#define K extern \"C\" __global__ __launch_bounds__(BLOCK) void\n"
+    // whole-vector form: as many blocks per lane as the hot-path kernel has (4, or 2 for np <= 8) -- a chain of np <= 16 is
+    // then ONE lane and the function is evaluated once per chain, not once per lane of it
+    "#if MCX_USER_LIK == 2 && MCX_USER_LPC >= 2 && MCX_USER_LPC <= 8\n"
+    "#define MCX_USER_BPL (MCX_USER_LPC >= 4 ? 4 : 2)\n"
+    "K mcx_user_fastb_burn(const SegArgs a) { const uint32_t w = fused_fastb_body<MCX_USER_LPC / MCX_USER_BPL, MCX_USER_BPL, false, LIK_USER>(a); tuner_epilogue(a, w); }\n"
+    "K mcx_user_fastb_main(const SegArgs a) { const uint32_t w = fused_fastb_body<MCX_USER_LPC / MCX_USER_BPL, MCX_USER_BPL, true, LIK_USER>(a); tuner_epilogue(a, w); }\n"
+    "#endif\n"
     "#if MCX_USER_LPC <= 8\n"
     "K mcx_user_fast_burn(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, false, LIK_USER, false, false>(a); tuner_epilogue(a, w); }\n"
     "K mcx_user_fast_main(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, true, LIK_USER, false, false>(a); tuner_epilogue(a, w); }\n"
@@ -140,6 +147,8 @@ struct UserLik {
   int device = -1;
   hipModule_t mod = nullptr;
   hipFunction_t fast[2] = {nullptr, nullptr}, full[2] = {nullptr, nullptr}, steps[2] = {nullptr, nullptr}, eval = nullptr;
+  hipFunction_t fastb[2] = {nullptr, nullptr};  // whole-vector form, 2 <= lpc <= 8: the hot-path kernel with `bpl` blocks per lane
+  int bpl = 1;
   double compile_ms = 0.0;
   ~UserLik() { if (mod) (void)hipModuleUnload(mod); }
 };
@@ -148,13 +157,14 @@ namespace {
 std::map<std::string, std::shared_ptr<UserLik>> g_user_cache;
 }
 
-int user_lik_get(const char *source, int lpc, std::shared_ptr<UserLik> *out)
+int user_lik_get(const char *source, int np, std::shared_ptr<UserLik> *out)
 {
+  const int lpc = lpc_for(np);
   if (!source || !*source) return fail(MCX_ERR_VLFUNC, "MCX_VL_SOURCE without source text (ctx)");
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_user_m);
-  const std::string key = std::to_string(dev) + ":" + std::to_string(lpc) + ":" + std::to_string(std::hash<std::string>{}(source)) + ":" +
+  const std::string key = std::to_string(dev) + ":" + std::to_string(np) + ":" + std::to_string(std::hash<std::string>{}(source)) + ":" +
                           std::to_string(std::strlen(source));
   auto it = g_user_cache.find(key);
   if (it != g_user_cache.end() && it->second->source == source) {
@@ -164,7 +174,8 @@ int user_lik_get(const char *source, int lpc, std::shared_ptr<UserLik> *out)
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<char> code;
   std::string log;
-  MCXCHK(rtc_compile(std::string(TU_HEAD) + source + TU_TAIL, "mcx_user.hip", {"-DMCX_USER_LPC=" + std::to_string(lpc)}, code, log));
+  MCXCHK(rtc_compile(std::string(TU_HEAD) + source + TU_TAIL, "mcx_user.hip",
+                     {"-DMCX_USER_LPC=" + std::to_string(lpc), "-DMCX_USER_NP=" + std::to_string(np)}, code, log));
   auto u = std::make_shared<UserLik>();
   u->source = source;
   u->lpc = lpc;
@@ -175,6 +186,13 @@ int user_lik_get(const char *source, int lpc, std::shared_ptr<UserLik> *out)
     HIPCHK(hipModuleGetFunction(&u->fast[1], u->mod, "mcx_user_fast_main"));
     HIPCHK(hipModuleGetFunction(&u->full[0], u->mod, "mcx_user_full_burn"));
     HIPCHK(hipModuleGetFunction(&u->full[1], u->mod, "mcx_user_full_main"));
+  }
+  if (lpc >= 2 && lpc <= 8 && hipModuleGetFunction(&u->fastb[0], u->mod, "mcx_user_fastb_burn") == hipSuccess &&
+      hipModuleGetFunction(&u->fastb[1], u->mod, "mcx_user_fastb_main") == hipSuccess) {
+    u->bpl = lpc >= 4 ? 4 : 2;
+  } else {
+    (void)hipGetLastError();  // (block form: the kernels are not in the module)
+    u->fastb[0] = u->fastb[1] = nullptr;
   }
   HIPCHK(hipModuleGetFunction(&u->steps[0], u->mod, "mcx_user_steps_burn"));
   HIPCHK(hipModuleGetFunction(&u->steps[1], u->mod, "mcx_user_steps_main"));
@@ -198,10 +216,15 @@ int user_lik_launch_fused(const UserLik &u, bool main, const mcx::SegArgs &a, hi
 {
   const int v = user_lik_variant(u.lpc, a);
   hipFunction_t f = v == 0 ? u.fast[main ? 1 : 0] : (v == 1 ? u.full[main ? 1 : 0] : u.steps[main ? 1 : 0]);
+  int lanes = u.lpc;
+  if (v == 0 && u.fastb[0]) {  // whole-vector form on the diagonal hot path: several blocks per lane
+    f = u.fastb[main ? 1 : 0];
+    lanes = u.lpc / u.bpl;
+  }
   if (!f) return fail(MCX_ERR_UNSUPPORTED, "no user step kernel for this configuration");
   mcx::SegArgs arg = a;
   void *args[] = {&arg};
-  const unsigned grid = (unsigned)(((size_t)a.n * u.lpc + mcx::BLOCK - 1) / mcx::BLOCK);
+  const unsigned grid = (unsigned)(((size_t)a.n * lanes + mcx::BLOCK - 1) / mcx::BLOCK);
   HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, mcx::BLOCK, 1, 1, 0, st, args, nullptr));
   return MCX_OK;
 }
@@ -233,7 +256,8 @@ extern "C" int mcx_debug_user_source_compile(const char *source, int np, size_t 
   std::lock_guard<std::mutex> lk(g_user_m);
   std::vector<char> code;
   std::string log;
-  MCXCHK(rtc_compile(std::string(TU_HEAD) + source + TU_TAIL, "mcx_user.hip", {"-DMCX_USER_LPC=" + std::to_string(lpc_for(np))}, code, log));
+  MCXCHK(rtc_compile(std::string(TU_HEAD) + source + TU_TAIL, "mcx_user.hip",
+                     {"-DMCX_USER_LPC=" + std::to_string(lpc_for(np)), "-DMCX_USER_NP=" + std::to_string(np)}, code, log));
   if (code_bytes) *code_bytes = code.size();
   return MCX_OK;
 }

@@ -1,7 +1,10 @@
 // mcpar-run -- the BASELINE configurations as a first-class driver (the reference reaches them
 // only through its library API: SURVEY fact 3).
-//   mcpar-run [--func rosen1|rosen2|rosen2fixed|gauss|dgauss|mix] [--np D] [--nc CHAINS] [--nsamp N]
-//             [--nburn B] [--pl P] [--sync S] [--ncomp K] [--quiet] [--iter] [--binary] [--stream-text] [--out FILE]
+//   mcpar-run [--func rosen1|rosen2|rosen2fixed|gauss|dgauss|mix | --func-source FILE.hip [--par a,b,...]] [--np D]
+//             [--nc CHAINS] [--nsamp N] [--nburn B] [--pl P] [--sync S] [--ncomp K] [--quiet] [--iter] [--binary]
+//             [--stream-text] [--out FILE]
+// --func-source: the user's own likelihood as HIP source of device functions (SourceVLFunc, MCX_VL_SOURCE: compiled into
+// the engine's fused step kernels at run time; mcpar_amd/examples/ has three), --par its parameter block.
 // Output: the reference's row format (src/mcout.cc:41-45); --iter prepends the iteration index
 // that src/anly/mcpar-analysis.R:80-120 reconstructs; --quiet prints only the summary (stderr); --out FILE: the sample
 // text goes to FILE, every rank writing its own share at its place (MCout::text_file) instead of through rank 0.
@@ -27,11 +30,17 @@ int main(int argc, char *argv[])
   int np = 16, nc = 4096, nsamp = 100, nburn = 500, sync = 10, ncomp = 8;
   float pl = 1.0f;
   bool quiet = false, iter = false, binary = false, stream_text = false;
-  std::string out_file;
+  std::string out_file, func_source;
+  std::vector<float> user_par;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : "0"; };
     if (a == "--func") func = val();
+    else if (a == "--func-source") func_source = val();
+    else if (a == "--par") {
+      std::stringstream ss(val());
+      for (std::string tok; std::getline(ss, tok, ',');) user_par.push_back((float)atof(tok.c_str()));
+    }
     else if (a == "--np") np = atoi(val());
     else if (a == "--nc") nc = atoi(val());
     else if (a == "--nsamp") nsamp = atoi(val());
@@ -54,6 +63,16 @@ int main(int argc, char *argv[])
   VLFunc *L = 0;
   std::vector<float> means, w;
   try {
+    if (!func_source.empty()) {
+      FILE *f = fopen(func_source.c_str(), "rb");
+      if (!f) { std::cerr << "cannot read " << func_source << "\n"; return 2; }
+      std::string text;
+      char buf[4096];
+      for (size_t k; (k = fread(buf, 1, sizeof buf, f)) > 0;) text.append(buf, k);
+      fclose(f);
+      func = "source:" + func_source;
+      L = new SourceVLFunc(np, text.c_str(), user_par.empty() ? 0 : user_par.data(), (int)user_par.size());
+    } else
     if (func == "rosen1") L = new Rosenbrock1(np);
     else if (func == "rosen2") L = new Rosenbrock2(np);
     else if (func == "rosen2fixed") L = new Rosenbrock2Fixed(np);  // flagged variant, not reference behaviour

@@ -173,3 +173,47 @@ def test_small_n_blocks_per_lane_multishard_snapshot(bpl):
         assert egs[s].counters["remote_passes"] == eos[s].remote_passes
         for name in ("state", "mean", "var", "samples", "musigall"):
             assert same_bits(getattr(egs[s], name), getattr(eos[s], name)), (s, name)
+
+
+@pytest.mark.parametrize("bpl", [1, 2, 0], ids=["one-block", "mirrored", "engine-choice"])
+@pytest.mark.parametrize("kind,d,n,pl", [("rosen", 32, 640, 1.0), ("rosen", 16, 1500, 0.9), ("gauss", 32, 300, 0.9), ("mix", 32, 512, 1.0),
+                                         ("rosen", 28, 257, 1.0), ("rosen", 12, 700, 0.9), ("gauss", 16, 900, 1.0), ("mix", 16, 333, 0.85)])
+def test_full_covariance_kernels_same_bits_as_oracle(kind, d, n, pl, bpl):
+    """Full-covariance proposals (src/mcpar.cc:302-312 with covar_setup's factor, :454-484) on both hot-path kernels: one block
+    per lane (k_fused_fast<..., FULL>: the factor in registers up to 16-D, in LDS above) and two MIRRORED blocks per lane
+    (k_fused_fastb<..., FULL>, mcx_fastb.hpp: lane q2 holds blocks q2 and NB - 1 - q2, the first block's columns above the
+    diagonal are never issued) -- ragged chains (d = 28, 12: a lane whose second / first block is absent), thinned stores and
+    a sharded snapshot included.  Same bits as the oracle whichever kernel runs."""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    so, sg = specs(kind, d)
+    nburn, nsamp = 110, 45
+    a = np.random.default_rng(5 + d).normal(size=(d, d))
+    cov = (0.02 * (np.eye(d) + 0.5 * a @ a.T / d)).astype(np.float32)
+    p = O.default_pinit(d, n)
+    vo, k1 = O.make_vlfunc(*so)
+    eo = O.Engine(d, n, pl=pl, threads=8)
+    eo.run(nsamp, nburn, p, vo, cov)
+    vg, k2 = M.make_vlfunc(*sg)
+    eg = M.Engine(d, n, pl=pl)
+    eg.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
+    eg.set_option(E.OPT_PERSIST, 0)
+    eg.set_option(E.OPT_SPLIT_RNG, 0)
+    eg.run(nsamp, nburn, p, vg, cov)
+    c = eg.counters
+    assert (c["naccept_burn"], c["naccept_main"]) == (eo.naccept_burn, eo.naccept_main)
+    assert (c["remote_steps"], c["remote_passes"]) == (eo.remote_steps, eo.remote_passes)
+    assert np.array_equal(eg.accept_counts, eo.accept_counts)
+    assert np.array_equal(eg.tuner_trace, eo.tuner_trace)
+    for name in ("state", "loglike", "mean", "var", "musigall", "samples", "chol"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
+    # a second run on the same engine (the factor is reinstalled, the tuner starts over), thinned store
+    eo.set_record(samples=True, mask=False, stride=3)
+    eo.run(nsamp, nburn, p, vo, cov)
+    eg.set_option(E.OPT_SAMPLE_STRIDE, 3)
+    eg.run(nsamp, nburn, p, vg, cov)
+    for name in ("state", "mean", "var"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
+    so_ = eo.samples
+    assert same_bits(eg.samples, so_[so_.shape[0] - eg.samples.shape[0]:])
+    eg.close()

@@ -132,6 +132,43 @@ def test_mcpar_run_binary_rows_equal_text_rows(tmp_path):
     assert it.stdout.decode().splitlines() == ["%d  %s" % (r // 96, line) for r, line in enumerate(want)]
 
 
+def test_mcpar_run_with_the_users_own_likelihood_as_source(tmp_path):
+    """mcpar-run --func-source FILE: SourceVLFunc (include/mcpar/vlfunc.hh) -> MCX_VL_SOURCE, the user's device functions
+    compiled into the fused step kernels.  The example restates Rosenbrock1: the driver's text must be the built-in's, byte
+    for byte; a text that does not compile ends the run with the compiler's message (the reference abort()s on library
+    failures: src/mcpar.hh:93)"""
+    build_drivers()
+    args = ["--np", "16", "--nc", "200", "--nsamp", "40", "--nburn", "120", "--pl", "0.9"]
+    ex = os.path.join(ROOT, "mcpar_amd", "examples")
+    ref = subprocess.run([os.path.join(DRV, "mcpar-run"), "--func", "rosen1"] + args, cwd=tmp_path, capture_output=True, timeout=300)
+    assert ref.returncode == 0, ref.stderr
+    for name, par in (("user_rosenbrock1_blocks.hip", []), ("user_rosenbrock1_whole.hip", ["--par", "1.0"])):
+        r = subprocess.run([os.path.join(DRV, "mcpar-run"), "--func-source", os.path.join(ex, name)] + par + args, cwd=tmp_path,
+                           capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == ref.stdout and len(r.stdout) > 100000, name
+    bad = tmp_path / "bad.hip"
+    bad.write_text("__device__ float mcx_user_loglike(const float *x, int d, const float *par) { return x[0] +; }\n")
+    r = subprocess.run([os.path.join(DRV, "mcpar-run"), "--func-source", str(bad)] + args, cwd=tmp_path, capture_output=True, timeout=300)
+    assert r.returncode != 0 and b"does not compile" in r.stderr and b"mcx_user_likelihood:1" in r.stderr
+
+
+def test_mcpar_run_out_file_takes_every_kind_of_dump(tmp_path):
+    """--out FILE (MCout::text_file): the file gets what stdout would have got -- also when the rows take MCout::output()'s
+    own path (--iter keeps them for the driver, so run() dumps through output()) and under --binary (the file
+    used to stay empty while the rows went to stdout)"""
+    build_drivers()
+    args = ["--func", "rosen1", "--np", "8", "--nc", "64", "--nsamp", "30", "--nburn", "60", "--pl", "0.9"]
+    t = subprocess.run([os.path.join(DRV, "mcpar-run")] + args, cwd=tmp_path, capture_output=True, timeout=300)
+    b = subprocess.run([os.path.join(DRV, "mcpar-run")] + args + ["--binary"], cwd=tmp_path, capture_output=True, timeout=300)
+    assert t.returncode == 0 and b.returncode == 0
+    for extra, want in (([], t.stdout), (["--binary"], b.stdout)):
+        f = tmp_path / ("out" + "".join(extra))
+        r = subprocess.run([os.path.join(DRV, "mcpar-run")] + args + extra + ["--out", str(f)], cwd=tmp_path, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == b"" and f.read_bytes() == want, extra
+
+
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 

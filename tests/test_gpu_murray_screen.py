@@ -112,3 +112,57 @@ def test_far_from_the_origin_the_cancellation_is_still_bounded():
         masks = debug_murray_screen(x, ms, 0, sums)
         need, kept = check_masks(x, ms, 0, sums, masks)
         print("offset 1e4: rows that matter %.4f, kept %.4f" % (need, kept))
+
+
+@pytest.mark.parametrize("d", [16, 32])
+@pytest.mark.parametrize("sums", [True, False])
+def test_adversarial_states_never_lose_a_row_that_matters(d, sums):
+    """the exactness argument assumes an error model for the matrix core's accumulation that the hardware is
+    not documented to follow.  States built to sit on its weak spots -- where a wrongly skipped row would silently change
+    qisum / qimax (src/mcpar.cc:367-395): (a) a centre far from the chains, so the products that must cancel are orders of
+    magnitude above the arg that is left; (b) Gaussians placed so that a chain's arg is within 1e-6 .. 1e-2 of its bound,
+    on either side; (c) weights and coordinates of very different magnitudes from one dimension to the next."""
+    from mcpar_amd.engine import debug_murray_screen
+    rng = np.random.default_rng(1000 + d + int(sums))
+    # (a) most Gaussians (and with them the screen's centre) around the origin, the chains -- and the few Gaussians near
+    #     them -- in a tight cloud far away: |A_j| |B_i| ~ (30 sqrt(d))^2 / width^2 against args of tens
+    N, n = 2048, 512
+    ms = np.empty((N, d, 2), np.float32)
+    ms[:, :, 0] = rng.normal(0.0, 0.3, (N, d))
+    ms[:, :, 1] = rng.uniform(0.05, 0.2, (N, d)) ** 2
+    ms[:n, :, 0] = np.float32(30.0) + rng.normal(0.0, 0.3, (n, d))
+    x = (ms[:n, :, 0] + np.sqrt(ms[:n, :, 1]) * rng.standard_normal((n, d)) * 1.5).astype(np.float32)
+    masks = debug_murray_screen(x, ms, 0, sums)
+    need, kept = check_masks(x, ms, 0, sums, masks)
+    print("far centre: rows that matter %.4f, kept %.4f" % (need, kept))
+    # (b) unit weights; Gaussian n + i sits at distance sqrt(L (1 + eps_i)) from chain (i mod n) in a random direction,
+    #     L = 176 (sum sweep) or the chain's own arg (min-arg sweep, made ~40 by construction)
+    N, n = 1024, 256
+    ms = np.empty((N, d, 2), np.float32)
+    ms[:, :, 1] = 1.0
+    ms[:, :, 0] = rng.normal(0.0, 1.0, (N, d)) * 40.0   # far from everybody unless placed below
+    x = rng.normal(0.0, 1.0, (n, d)).astype(np.float32)
+    own = x + (rng.standard_normal((n, d)) * np.sqrt(40.0 / d)).astype(np.float32)   # own arg ~ 40
+    ms[:n, :, 0] = own
+    a_own = ((ms[:n, :, 0].astype(np.float64) - x) ** 2).sum(axis=1)
+    eps = np.concatenate([s * 10.0 ** e for e in (-6, -5, -4, -3, -2) for s in (-1.0, 1.0)])
+    for i in range(n, N):
+        j = (i - n) % n
+        L = 176.0 if sums else min(176.0, a_own[j])
+        u = rng.standard_normal(d)
+        u /= np.linalg.norm(u)
+        ms[i, :, 0] = (x[j].astype(np.float64) + np.sqrt(L * (1.0 + eps[(i - n) % eps.size])) * u).astype(np.float32)
+    masks = debug_murray_screen(x, ms, 0, sums)
+    need, kept = check_masks(x, ms, 0, sums, masks)
+    print("at the bounds: rows that matter %.4f, kept %.4f" % (need, kept))
+    # (c) per-dimension scales from 1e-3 to 1e3 (coordinates) with weights that undo them (every dimension contributes
+    #     alike to arg, none alike to |A| |B|), shuffled so that neighbouring dimensions differ by orders of magnitude
+    N, n = 1536, 384
+    scale = (10.0 ** rng.permutation(np.linspace(-3, 3, d))).astype(np.float32)
+    ms = np.empty((N, d, 2), np.float32)
+    ms[:, :, 0] = rng.normal(0.4, 1.0, (N, d)) * scale
+    ms[:, :, 1] = (rng.uniform(0.1, 0.3, (N, d)) * scale) ** 2
+    x = (ms[:n, :, 0] + np.sqrt(ms[:n, :, 1]) * rng.standard_normal((n, d)) * 2.0).astype(np.float32)
+    masks = debug_murray_screen(x, ms, 0, sums)
+    need, kept = check_masks(x, ms, 0, sums, masks)
+    print("mixed magnitudes: rows that matter %.4f, kept %.4f" % (need, kept))

@@ -299,3 +299,25 @@ def test_small_n_mode_split_rng(split, persist, kind, d, n, nburn, nsamp, pl):
         assert np.array_equal(getattr(eg, name).view(np.uint32), getattr(eo, name).view(np.uint32)), name
     want = eo.samples.reshape(nsamp, n, d + 1)[::1 + split].reshape(-1, d + 1)
     assert np.array_equal(eg.samples.view(np.uint32), want.view(np.uint32))
+
+
+def test_np_bound_is_256_and_says_so():
+    """The one size limit the reference does not have (src/mcpar.hh:32 takes any np): a chain's parameters live in the lanes
+    of ONE wavefront, 4 per lane, so np <= 256 (include/mcx.h MCX_ERR_UNSUPPORTED; INTEGRATION.md "drop-in caveats").
+    np = 256 itself is a whole, bit-exact run; 257 is refused at construction with a message -- never a wrong answer."""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    d, n, nburn, nsamp = 256, 48, 60, 25
+    p = O.default_pinit(d, n)
+    vo, _k = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=0.85, threads=4)
+    eo.run(nsamp, nburn, p, vo)
+    vg, _k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eg = M.Engine(d, n, pl=0.85)
+    eg.set_option(E.OPT_ACCEPT_MASK, 1)
+    eg.run(nsamp, nburn, p, vg)
+    assert_same(eo, eg, "np = 256")
+    eg.close()
+    with pytest.raises(M.McxError) as ei:
+        M.Engine(257, 8)
+    assert ei.value.code == 4 and "257" in str(ei.value)  # MCX_ERR_UNSUPPORTED

@@ -10,10 +10,14 @@ import mcpar_amd as M
 from mcpar_amd import engine as E
 from bench import pinit_for, spd_covariance
 
+BPL = int(os.environ.get("MCX_PROBE_BPL", "0"))  # MCX_OPT_BLOCKS_PER_LANE: 0 = the engine's choice, 1 = one block per lane, 2 = two (full covariance: mirrored)
+
+
 def probe(d, full, samples, nburn=500, nsamp=1000, n=65536):
     vl, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     e = M.Engine(d, n, pl=1.0)
     e.set_option(E.OPT_SAMPLES, samples)
+    e.set_option(E.OPT_BLOCKS_PER_LANE, BPL)
     p = pinit_for(d, n, 0)
     cov = spd_covariance(d) if full else None
     e.run(nsamp, nburn, p, vl, cov)
@@ -43,6 +47,7 @@ for d in (16, 32):
     vl, keep = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     e = M.Engine(d, n, pl=1.0)
     e.set_option(E.OPT_SAMPLES, 0)
+    e.set_option(E.OPT_BLOCKS_PER_LANE, BPL)
     e.stage_pinit(pinit_for(d, n, 0))
     for label, cov in (("diag", None), ("full", spd_covariance(d)), ("diag again", None), ("full again", spd_covariance(d))):
         ts = []
