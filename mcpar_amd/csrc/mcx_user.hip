@@ -278,6 +278,7 @@ extern "C" int mcx_user_kernel_compile(const char *source, const char *symbol, v
   HIPCHK(hipModuleLoadData(&mod, code.data()));
   const hipError_t ge = hipModuleGetFunction(&f, mod, symbol);
   if (ge != hipSuccess) {
+    (void)hipGetLastError();  // (the runtime remembers the failure: the next hipGetLastError() of this thread must not find it)
     (void)hipModuleUnload(mod);
     return fail(MCX_ERR_VLFUNC, "kernel '%s' not found in the compiled source (declare it extern \"C\" __global__)", symbol);
   }
