@@ -250,6 +250,15 @@ enum {
                               mcx_run has returned): call mcx_synchronize before anything else touches the communicator */
   MCX_OPT_SINK_TEXT = 16,    /* a row sink (mcx_set_sink) also gets every block as text: inside the callback, mcx_sink_text
                               returns the characters MCout::output would print for the block's rows [default 0] */
+  MCX_OPT_ASYNC_RUN = 19,    /* 1: mcx_run returns as soon as the run is QUEUED (one shard, no sink / output hook / host likelihood,
+                              no Murray step, samples > 0; other runs are waited for as ever).  Every other entry point -- the
+                              getters, mcx_samples_*, mcx_get_counters, mcx_synchronize, mcx_set_option, mcx_destroy -- first
+                              finishes it (waits, takes its counters, repeats a run whose tuner meeting was abandoned), so results
+                              are what a synchronous run gives.  Calling mcx_run again before looking queues the next run behind
+                              it (at most two in flight): launch and completion latency of back-to-back small jobs overlap the
+                              jobs; the overtaken run's results are never seen (the next run overwrites them, as ever) and its
+                              counters are not reported.  pinit / incov / the vlfunc are copied during the call as ever.
+                              [default 0] */
   MCX_OPT_MURRAY_OVERLAP = 18, /* Murray passes over many chains (np = 16 or 32, the per-pair screen): cut the Gaussians into this
                               many column chunks and screen chunk c + 1 (matrix cores, step stream) while chunk c is swept
                               (vector units, a side stream).  Same bits.  0 / 1: one screen, then one sweep */

@@ -156,6 +156,7 @@ static int lik_setup(LikDev &L, const mcx_vlfunc *f, int np, hipStream_t st)
   }
   if (L.params.p && h.size() == L.host.size() && (h.empty() || std::memcmp(h.data(), L.host.data(), h.size() * sizeof(float)) == 0))
     return MCX_OK;  // same parameters as the last call: they are on the device already
+  HIPCHK(hipStreamSynchronize(st));  // (the last upload, or a run still in flight, may be reading L.host / L.params)
   L.host.swap(h);
   MCXCHK(L.params.alloc(L.host.size()));
   if (!L.host.empty())
@@ -380,6 +381,9 @@ extern "C" int mcx_destroy(mcx_engine *e)
   (void)hipSetDevice(e->device);
   e->tail_publish = 0;  // (nobody will look at the slot; the gather itself is waited for by mcx_exchange_rccl_destroy)
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  e->pend.active = false;  // (a run nobody waited for: over now; its results go with the engine)
+  if (e->meet_held) { (void)flock(e->meet_fd, LOCK_UN); e->meet_held = false; }
+  for (hipEvent_t &ev : e->run_ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
   prof_collect(e);
   (void)mcx_exchange_rccl_destroy(e);
   e->pvals.release(); e->ptrial.release(); e->mu.release(); e->sig.release(); e->psum2.release();
@@ -422,6 +426,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
 extern "C" int mcx_set_exchange(mcx_engine *e, mcx_exchange_fn fn, void *ctx)
 {
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  if (e->pend.active) MCXCHK(enter(e));
   MCXCHK(finish_tail(e));  // (a gather of the exchange being replaced may still be in flight)
   e->xfn = fn;
   e->xctx = ctx;
@@ -439,6 +444,7 @@ extern "C" int mcx_set_output_hook(mcx_engine *e, mcx_output_fn fn, void *ctx)
 extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
 {
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
+  if (e->pend.active) MCXCHK(enter(e));  // (options apply to whole runs: the one in flight is finished first)
   switch (opt) {
   case MCX_OPT_SAMPLES: e->opt_samples = value ? 1 : 0; break;
   case MCX_OPT_SAMPLE_STRIDE:
@@ -466,6 +472,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
     if (value < 1) return fail(MCX_ERR_INVALID, "MEET_TIMEOUT_MS must be >= 1");
     e->opt_meet_timeout_ms = (int)std::min<int64_t>(value, 600000);
     break;
+  case MCX_OPT_ASYNC_RUN: e->opt_async_run = value ? 1 : 0; break;
   case MCX_OPT_MURRAY_OVERLAP:
     if (value < 0 || value > 64) return fail(MCX_ERR_INVALID, "MURRAY_OVERLAP: 0 (off) or the number of column chunks, <= 64");
     e->opt_murray_overlap = (int)value;
@@ -716,13 +723,104 @@ static int meet_lock_take(mcx_engine *e)
   return MCX_OK;
 }
 
-static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L, const float *incov);
+// rerun: repeat the run that was just abandoned -- same likelihood and factor as installed (L and incov are not looked at),
+// from the staged state or, when the run started from caller memory that may be gone by now, from the copy kept of it
+static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L, const float *incov, bool rerun = false);
 constexpr int PERSIST_RETRY_RUNS = 16;
+
+// A tuner meeting of the one-launch small-n kernel was abandoned: some workgroup of its grid was not resident (CU mask,
+// partitioned device, a foreign kernel on the CUs).  The launch wrote no state back: the run is repeated on the
+// per-segment kernels (same bits), which the engine then keeps to for PERSIST_RETRY_RUNS runs.
+static int repeat_abandoned_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L, const float *incov, bool rerun)
+{
+  (void)hipStreamSynchronize(e->stream);
+  e->persist_broken = true;
+  e->runs_since_broken = 0;
+  e->meet_total++;
+  if (getenv("MCX_VERBOSE"))
+    fprintf(stderr, "mcx: a tuner meeting of the one-launch small-n kernel was abandoned after %d ms (a workgroup of its grid "
+                    "was not resident); the run is repeated on the per-segment kernels\n", e->opt_meet_timeout_ms);
+  const int async = e->opt_async_run;
+  e->opt_async_run = 0;  // (the repeat is waited for: whoever asked is about to look at its results)
+  int rc = run_once(e, nsamp, nburn, pinit, L, incov, rerun);
+  e->opt_async_run = async;
+  if (rc == MCX_INTERNAL_MEET_ABANDONED) rc = fail(MCX_ERR_HIP, "internal: meeting abandoned without the one-launch kernel");
+  e->cnt.meet_timeouts = 1;
+  return rc;
+}
+
+static void never_leave_the_lock_behind(mcx_engine *e, int rc)
+{
+  if (rc == MCX_OK) return;
+  if (e->meet_held) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)flock(e->meet_fd, LOCK_UN);
+    e->meet_held = false;
+  }
+  e->meet_check = false;
+}
+
+// the books of a run that was queued asynchronously and never looked at (the next run was queued behind it): was one of
+// its meetings abandoned?  Nobody saw its results -- nothing to repeat -- but the engine keeps to the per-segment kernels
+static void note_superseded(mcx_engine *e)
+{
+  if (!e->superseded_hctr) return;
+  if (e->superseded_hctr[5] != 0) {
+    e->persist_broken = true;
+    e->runs_since_broken = 0;
+    e->meet_total++;
+  }
+  e->superseded_hctr = nullptr;
+}
+
+// MCX_OPT_ASYNC_RUN: the end of the run that mcx_run queued and returned from.  Called by every entry point but mcx_run
+// (enter(), mcx_engine_internal.hpp).
+int finish_pending(mcx_engine *e)
+{
+  if (!e->pend.active) return MCX_OK;
+  const mcx_engine::PendingRun p = e->pend;
+  e->pend.active = false;
+  const hipError_t se = hipStreamSynchronize(e->stream);
+  const bool abandoned = p.meet_check && se == hipSuccess && p.hctr[5] != 0;
+  e->meet_check = false;
+  (void)meet_release(e, true);
+  note_superseded(e);
+  HIPCHK(se);
+  int rc = MCX_OK;
+  if (abandoned) {
+    e->tbase = p.tbase0;  // (the abandoned launch moved nothing but the step counter)
+    rc = repeat_abandoned_run(e, p.nsamp, p.nburn, nullptr, nullptr, nullptr, true);
+  } else {
+    e->cnt.naccept_burn = p.hctr[3];
+    e->cnt.naccept_main = p.hctr[4];
+    xwait_collect(e);
+    if (e->persist_broken && ++e->runs_since_broken >= PERSIST_RETRY_RUNS) e->persist_broken = false;
+  }
+  never_leave_the_lock_behind(e, rc);
+  return rc;
+}
 
 extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L,
                        const float *incov)
 {
-  MCXCHK(enter(e));
+  MCXCHK(enter_raw(e));
+  if (e->pend.active) {
+    // A run is still in flight.  With MCX_OPT_ASYNC_RUN the next one is queued right behind it: nobody has looked at its
+    // results, and nobody will -- this run overwrites them -- so it needs no waiting for (launch and completion latency
+    // of back-to-back small jobs overlap the jobs themselves); its counters are looked at later, for the books only.
+    if (e->opt_async_run && hipStreamQuery(e->stream) == hipErrorNotReady) {
+      (void)hipGetLastError();
+      // at most TWO runs in flight: the one before the pending one must be over before this call reuses its counter slot
+      // (the host queues a small job in 15 us, the GPU takes 400: without a bound the queue would only grow)
+      if (e->run_ev[e->hctr_slot ^ 1]) HIPCHK(hipEventSynchronize(e->run_ev[e->hctr_slot ^ 1]));
+      note_superseded(e);
+      e->superseded_hctr = e->pend.meet_check ? e->pend.hctr : nullptr;
+      e->pend.active = false;
+    } else {
+      (void)hipGetLastError();
+      MCXCHK(finish_pending(e));
+    }
+  }
   static const int verbose = getenv("MCX_VERBOSE") ? atoi(getenv("MCX_VERBOSE")) : 0;
   const auto ht0 = std::chrono::steady_clock::now();
   e->ht_mark[0] = e->ht_mark[1] = e->ht_mark[2] = ht0;
@@ -737,43 +835,35 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
   }
   uint64_t repeated = 0;
   if (rc == MCX_INTERNAL_MEET_ABANDONED) {
-    // A tuner meeting of the one-launch small-n kernel was abandoned: some workgroup of its grid was not
-    // resident (CU mask, partitioned device, a foreign kernel on the CUs).  The launch wrote nothing back and
-    // the step counter has not moved: repeat the run on the per-segment kernels (same bits), and keep to them.
-    (void)hipStreamSynchronize(e->stream);
-    e->persist_broken = true;
-    e->runs_since_broken = 0;
-    e->meet_total++;
     repeated = 1;
-    if (getenv("MCX_VERBOSE"))
-      fprintf(stderr, "mcx: a tuner meeting of the one-launch small-n kernel was abandoned after %d ms (a workgroup of its grid "
-                      "was not resident); the run is repeated on the per-segment kernels\n", e->opt_meet_timeout_ms);
-    rc = run_once(e, nsamp, nburn, pinit, L, incov);
-    if (rc == MCX_INTERNAL_MEET_ABANDONED) rc = fail(MCX_ERR_HIP, "internal: meeting abandoned without the one-launch kernel");
+    rc = repeat_abandoned_run(e, nsamp, nburn, pinit, L, incov, false);
   }
-  e->cnt.meet_timeouts = repeated;
-  // whatever kept a workgroup out may be gone: the one-launch kernel is tried again after PERSIST_RETRY_RUNS runs
-  if (e->persist_broken && !repeated && rc == MCX_OK && ++e->runs_since_broken >= PERSIST_RETRY_RUNS) e->persist_broken = false;
-  if (rc != MCX_OK) {  // never leave the GPU's meeting lock behind a failed run
-    if (e->meet_held) {
-      (void)hipStreamSynchronize(e->stream);
-      (void)flock(e->meet_fd, LOCK_UN);
-      e->meet_held = false;
-    }
-    e->meet_check = false;
+  if (!e->pend.active) {
+    e->cnt.meet_timeouts = repeated;
+    // whatever kept a workgroup out may be gone: the one-launch kernel is tried again after PERSIST_RETRY_RUNS runs
+    if (e->persist_broken && !repeated && rc == MCX_OK && ++e->runs_since_broken >= PERSIST_RETRY_RUNS) e->persist_broken = false;
   }
+  never_leave_the_lock_behind(e, rc);
   return rc;
 }
 
-static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L, const float *incov)
+static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, const mcx_vlfunc *L, const float *incov, bool rerun)
 {
   if (nsamp < 0 || nburn < 0) return fail(MCX_ERR_INVALID, "bad run arguments");
-  if (!pinit && !e->pinit_staged) return fail(MCX_ERR_INVALID, "pinit is NULL and no state was staged (mcx_stage_pinit)");
+  // the state a run without `pinit` starts from: what mcx_stage_pinit put there, or (the repeat of an asynchronous run
+  // that started from caller memory) the copy kept of that memory
+  const float *const staged = (rerun && e->pend.host_pinit) ? e->pinit_async.p : e->pinit_dev.p;
+  if (rerun) pinit = nullptr;
+  if (!pinit && !rerun && !e->pinit_staged) return fail(MCX_ERR_INVALID, "pinit is NULL and no state was staged (mcx_stage_pinit)");
   if (e->size > 1 && !e->xfn) return fail(MCX_ERR_EXCHANGE, "nshards > 1 needs mcx_set_exchange()");
   const int n = e->nchain, d = e->nparam;
   hipStream_t st = e->stream;
-  MCXCHK(lik_setup(e->lik, L, d, st));
-  MCXCHK(covar_install(e, incov, nullptr, false));  // src/mcpar.cc:20
+  if (!rerun) {
+    MCXCHK(lik_setup(e->lik, L, d, st));
+    MCXCHK(covar_install(e, incov, nullptr, false));  // src/mcpar.cc:20
+  } else {
+    e->cov_pending = true;  // the factor as installed (cov0), rescaled by nothing yet
+  }
   e->cull_skip[0] = e->cull_skip[1] = 0;  // a new job starts from pinit: what the last one's Murray sweeps found useless is no guide
   // sample store: every chain, every main-loop step (src/mcpar.cc:31-40, 177-182), kept in HBM
   e->samp_steps = 0;
@@ -858,7 +948,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   if (pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
   if (!lead) {
     hipLaunchKernelGGL(k_run_reset, dim3(nblocks((size_t)e->ntot)), dim3(BLOCK), 0, st, e->acc_slots.p, (size_t)e->nslots,
-                       e->acc_cnt.p, (size_t)n, e->ntrace.p, e->pvals.p, pinit ? (const float *)nullptr : e->pinit_dev.p,
+                       e->acc_cnt.p, (size_t)n, e->ntrace.p, e->pvals.p, pinit ? (const float *)nullptr : staged,
                        (size_t)e->ntot, e->cov.p, e->cov_pending ? (const float *)e->cov0.p : (const float *)nullptr,
                        (size_t)e->ncov);
     HIPCHK(hipGetLastError());
@@ -954,7 +1044,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         ra.armin = e->TGT_ARATE_MIN; ra.armax = e->TGT_ARATE_MAX; ra.dfac = e->SCALE_DEC; ra.ifac = e->SCALE_INC;
         ra.ctr = ctrp; ra.bar = ctrp + 8; ra.trace = e->trace.p; ra.ntrace = e->ntrace.p;
         // the run's first launch takes the state where it lies, evaluates it, and starts the counters afresh
-        ra.x0 = lead ? (pinit ? e->pvals.p : e->pinit_dev.p) : nullptr;
+        ra.x0 = lead ? (pinit ? e->pvals.p : staged) : nullptr;
         ra.T0 = e->cov_pending ? e->cov0.p : nullptr;
         ra.fresh = lead ? 1 : 0;
         if (e->cov_pending && e->cov_offdiag) {
@@ -1177,11 +1267,33 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, ctrp + 4);
     HIPCHK(hipGetLastError());
   }
-  MCXCHK(e->h_ctr.alloc(8));  // pinned: the copy queues behind the last kernel instead of staging through the runtime
-  unsigned long long *hctr = e->h_ctr.p;
+  MCXCHK(e->h_ctr.alloc(16));  // pinned: the copy queues behind the last kernel instead of staging through the runtime;
+  e->hctr_slot ^= 1;           // two slots in turn (MCX_OPT_ASYNC_RUN: the previous run's may not have been read yet)
+  unsigned long long *hctr = e->h_ctr.p + 8 * e->hctr_slot;
   MCXCHK(cov_reset(e));  // (a run without any step)
   HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   e->ht_mark[1] = std::chrono::steady_clock::now();
+  // MCX_OPT_ASYNC_RUN: everything is queued -- return.  Only runs whose end needs nothing from the host: one shard, no
+  // sink / output hook / host likelihood, no Murray step (a pass waits for its survivors' count), no profiling.
+  bool go_async = e->opt_async_run && !rerun && e->size == 1 && !sink && !e->ofn && nsamp > 0 && e->lik.kind != MCX_VL_HOST &&
+                  !e->opt_profile && !e->trace_clk.p;
+  for (const mcx_plan_item &it : plan) go_async = go_async && it.kind != MCX_PLAN_REMOTE_STEP && it.kind != MCX_PLAN_OUTPUT;
+  if (go_async) {
+    if (pinit) {  // a repeat (abandoned meeting) must not need the caller's memory again
+      MCXCHK(e->pinit_async.alloc((size_t)e->ntot));
+      HIPCHK(hipMemcpyAsync(e->pinit_async.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    if (!e->run_ev[e->hctr_slot]) HIPCHK(hipEventCreateWithFlags(&e->run_ev[e->hctr_slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->run_ev[e->hctr_slot], st));
+    e->pend.active = true;
+    e->pend.nsamp = nsamp; e->pend.nburn = nburn; e->pend.tbase0 = e->tbase;
+    e->pend.meet_check = e->meet_check; e->pend.hctr = hctr; e->pend.host_pinit = pinit != nullptr;
+    e->meet_check = false;  // (finish_pending looks at the word itself)
+    e->samp_steps = e->opt_samples ? nkeep : 0;
+    e->last_nsamp = nsamp; e->last_nburn = nburn; e->have_run = true;
+    e->tbase += (uint32_t)(nburn + nsamp);
+    return MCX_OK;
+  }
   {
     const hipError_t se = hipStreamSynchronize(st);
     e->ht_mark[2] = std::chrono::steady_clock::now();
@@ -1342,7 +1454,7 @@ template <typename T>
 static int d2h(mcx_engine *e, T *dst, const T *src, size_t count)
 {
   if (!e || !dst) return fail(MCX_ERR_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(e->device));
+  MCXCHK(enter(e));  // (also: an asynchronous run in flight is finished first)
   HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return MCX_OK;
@@ -1351,6 +1463,7 @@ static int d2h(mcx_engine *e, T *dst, const T *src, size_t count)
 extern "C" int mcx_get_counters(mcx_engine *e, mcx_counters *c)
 {
   if (!e || !c) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (e->pend.active) MCXCHK(enter(e));  // (an asynchronous run's counters exist once it is over)
   *c = e->cnt;
   c->meet_timeouts_total = e->meet_total;
   return MCX_OK;

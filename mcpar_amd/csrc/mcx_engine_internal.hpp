@@ -277,6 +277,20 @@ struct mcx_engine {
   // native RCCL exchange (mcx_exchange_rccl_*): in-place ncclAllGather of the musigall slots on a side stream
   ncclComm_t xcomm = nullptr;
   bool xcomm_owned = false;
+  // MCX_OPT_ASYNC_RUN: a run whose kernels are queued and whose end nobody has waited for yet (mcx_engine.hip: finish_pending)
+  int opt_async_run = 0;
+  struct PendingRun {
+    bool active = false;
+    int nsamp = 0, nburn = 0;
+    uint32_t tbase0 = 0;                 // the RNG step index the run started from (a repeat starts there again)
+    bool meet_check = false;             // its one-launch kernel had tuner meetings: word 5 of its counters says if one was abandoned
+    unsigned long long *hctr = nullptr;  // its slot of the pinned counter ring
+    bool host_pinit = false;             // it started from caller memory (kept in pinit_async for a repeat), not from the staged state
+  } pend;
+  unsigned long long *superseded_hctr = nullptr;  // a run nobody looked at before the next was queued: its counters, for the books only
+  DevBuf<float> pinit_async;
+  int hctr_slot = 0;
+  hipEvent_t run_ev[2] = {nullptr, nullptr};  // recorded behind each asynchronous run's last command, by counter slot
   hipStream_t mstream = nullptr;   // Murray passes by column chunks: the sweeps' stream (mcx_murray.hip: screen_sweep_chunked)
   std::vector<hipEvent_t> mev;
   int opt_murray_overlap = 0;
@@ -325,11 +339,20 @@ struct mcx_engine {
   mcx_profile prof{};
 };
 
-// every entry point may be called from a thread whose current device is another one
-static inline int enter(mcx_engine *e)
+// every entry point may be called from a thread whose current device is another one; whatever an asynchronous run
+// (MCX_OPT_ASYNC_RUN) left in flight is finished first -- waited for, its counters taken, a run whose tuner meeting was
+// abandoned repeated -- so that no entry point ever sees a run half done (mcx_run itself queues behind it instead)
+int finish_pending(mcx_engine *e);  // mcx_engine.hip
+static inline int enter_raw(mcx_engine *e)
 {
   if (!e) return fail(MCX_ERR_INVALID, "engine is NULL");
   HIPCHK(hipSetDevice(e->device));
+  return MCX_OK;
+}
+static inline int enter(mcx_engine *e)
+{
+  MCXCHK(enter_raw(e));
+  if (e->pend.active) MCXCHK(finish_pending(e));
   return MCX_OK;
 }
 

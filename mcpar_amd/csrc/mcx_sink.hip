@@ -142,6 +142,7 @@ int sink_drain(mcx_engine *e, int nblocks_done)
 extern "C" int mcx_set_sink(mcx_engine *e, mcx_sink_fn fn, void *ctx, int block_steps)
 {
   if (!e || (fn && block_steps < 1)) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (e->pend.active) MCXCHK(enter(e));  // (an asynchronous run in flight is finished first)
   e->sfn = fn;
   e->tfn = nullptr;
   e->sctx = ctx;
@@ -161,6 +162,7 @@ extern "C" int mcx_sink_text(mcx_engine *e, const char **text, size_t *nbytes)
 extern "C" int mcx_set_text_sink(mcx_engine *e, mcx_text_sink_fn fn, void *ctx, int block_steps)
 {
   if (!e || (fn && block_steps < 1)) return fail(MCX_ERR_INVALID, "bad arguments");
+  if (e->pend.active) MCXCHK(enter(e));  // (an asynchronous run in flight is finished first)
   e->tfn = fn;
   e->sfn = nullptr;
   e->sctx = ctx;

@@ -21,6 +21,7 @@ OPT_ASYNC_TAIL = 15
 OPT_SINK_TEXT = 16
 OPT_MEET_UNDER_GATHER = 17
 OPT_MURRAY_OVERLAP = 18
+OPT_ASYNC_RUN = 19
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 

@@ -145,7 +145,7 @@ def test_adversarial_states_never_lose_a_row_that_matters(d, sums):
     own = x + (rng.standard_normal((n, d)) * np.sqrt(40.0 / d)).astype(np.float32)   # own arg ~ 40
     ms[:n, :, 0] = own
     a_own = ((ms[:n, :, 0].astype(np.float64) - x) ** 2).sum(axis=1)
-    eps = np.concatenate([s * 10.0 ** e for e in (-6, -5, -4, -3, -2) for s in (-1.0, 1.0)])
+    eps = np.array([s * 10.0 ** e for e in (-6, -5, -4, -3, -2) for s in (-1.0, 1.0)])
     for i in range(n, N):
         j = (i - n) % n
         L = 176.0 if sums else min(176.0, a_own[j])
