@@ -19,8 +19,8 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 # the kernel headers as strings inside the library: a user's likelihood source is compiled against them at run time (hiprtc)
-$(CSRC)/mcx_rtc_headers.inc: $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_device.hpp $(CSRC)/mcx_fastb.hpp tools/embed_headers.py
-	python3 tools/embed_headers.py $@ k_hdr_mcx_numerics=$(CSRC)/mcx_numerics.hpp k_hdr_mcx_device=$(CSRC)/mcx_device.hpp k_hdr_mcx_fastb=$(CSRC)/mcx_fastb.hpp
+$(CSRC)/mcx_rtc_headers.inc: $(CSRC)/mcx_numerics.hpp $(CSRC)/mcx_device.hpp $(CSRC)/mcx_fastb.hpp $(CSRC)/mcx_persist.hpp tools/embed_headers.py
+	python3 tools/embed_headers.py $@ k_hdr_mcx_numerics=$(CSRC)/mcx_numerics.hpp k_hdr_mcx_device=$(CSRC)/mcx_device.hpp k_hdr_mcx_fastb=$(CSRC)/mcx_fastb.hpp k_hdr_mcx_persist=$(CSRC)/mcx_persist.hpp
 $(CSRC)/mcx_user.o: $(CSRC)/mcx_rtc_headers.inc
 
 # what only one translation unit sees

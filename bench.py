@@ -1262,6 +1262,24 @@ def device_vlfunc_leg(M, E, cfg, n, headline_ms, emit):
                             first_run_s_including_the_build=first, accept_rate_main=acc, stats=st)
         except Exception as ex_:  # noqa: BLE001
             out[key] = dict(error=repr(ex_))
+    try:  # few chains (the strong-scaled per-GPU shape): the block form also gets the one-launch small-n kernel
+        ns = 8192
+        vl, _keep = M.make_vlfunc(M.VL_SOURCE, d, source=open(os.path.join(ex, "user_rosenbrock1_blocks.hip")).read())
+        eng = M.Engine(d, ns, pl=cfg["pl"])
+        eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
+        t = time_job(eng, vl, pinit_for(d, ns, 0), nsamp, nburn, reps=11)
+        st = job_stats(eng)
+        eng.close()
+        vb, _keepb = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+        eng = M.Engine(d, ns, pl=cfg["pl"])
+        eng.set_option(E.OPT_SAMPLES, 1 if emit else 0)
+        tb = time_job(eng, vb, pinit_for(d, ns, 0), nsamp, nburn, reps=11)
+        eng.close()
+        out["source_block_form_8192_chains"] = dict(workload="the same text, %d chains: the whole run in one launch of the small-n kernel" % ns,
+                                                    ms_per_job=t * 1e3, value=ns * (nburn + nsamp) / t, unit="chain-steps/s",
+                                                    builtin_ms_per_job=tb * 1e3, fraction_of_builtin=tb / t, stats=st)
+    except Exception as ex_:  # noqa: BLE001
+        out["source_block_form_8192_chains"] = dict(error=repr(ex_))
     try:
         fn = E.compile_user_kernel(USER_KERNEL_TEMPLATE % dict(d=d, nb=d // 4), "user_rosenbrock")
         vl, _keep = M.make_vlfunc(M.VL_DEVICE, d, device_fn=fn)

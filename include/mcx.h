@@ -77,10 +77,15 @@ enum {
  * np / 16 lanes, each of which evaluates it.  "mcx_numerics.hpp" is already included: mcx::logf_v1, mcx::expf_v2, ... are the engine's (and the CPU
  * oracle's) own transcendentals.  Compiled with -O3 -ffp-contract=off (write fma explicitly: __builtin_fmaf), once per
  * (text, np) per process; a text that does not compile fails mcx_run with MCX_ERR_VLFUNC and the compiler's messages
- * in mcx_last_error().  Without libhiprtc: MCX_ERR_UNSUPPORTED (MCX_VL_DEVICE and MCX_VL_HOST remain). */
+ * in mcx_last_error().  Without libhiprtc: MCX_ERR_UNSUPPORTED (MCX_VL_DEVICE and MCX_VL_HOST remain).  A text in block form
+ * also gets the one-launch small-n kernel (few chains: burn-in, tuner meetings and main loop in ONE launch), built when a
+ * run first qualifies for it. */
 int mcx_user_source_available(void); /* 1 / 0 (mcx_last_error says why not) */
 /* the compile step alone, for a chain of np parameters (needs no GPU): MCX_OK and the code object's size, or MCX_ERR_VLFUNC */
 int mcx_debug_user_source_compile(const char *source, int np, size_t *code_bytes);
+/* the same for the one-launch small-n kernel (few chains: the whole run in one launch), which takes the block form only and is
+ * built when a run first wants it: bpl = 1 or 2 blocks per lane, rec = with recorder wavefronts */
+int mcx_debug_user_source_compile_small(const char *source, int np, int bpl, int rec, size_t *code_bytes);
 /* For MCX_VL_DEVICE without a compiler at hand: source of a whole kernel
  *   extern "C" __global__ void f(int npset, const float *x, float *y)   -> *function = its hipFunction_t (for mcx_vlfunc.ctx) */
 int mcx_user_kernel_compile(const char *source, const char *symbol, void **function);

@@ -104,6 +104,7 @@ def load():
         "mcx_rccl_available": [],
         "mcx_user_source_available": [],
         "mcx_debug_user_source_compile": [C.c_char_p, C.c_int, C.POINTER(C.c_size_t)],
+        "mcx_debug_user_source_compile_small": [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
         "mcx_user_kernel_compile": [C.c_char_p, C.c_char_p, C.POINTER(vp)],
         "mcx_rccl_unique_id": [vp],
         "mcx_exchange_rccl_init": [vp, vp],

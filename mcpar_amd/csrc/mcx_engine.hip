@@ -931,7 +931,8 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   // (the mode is for chains that fill at most POWN_MAX wavefronts per CU at ONE block per lane: beyond that the per-segment
   // kernels are as fast or faster -- 65 536 x 16-D would fit the grid with two blocks per lane and run 35 % slower)
   const size_t nown_one_block = ((size_t)n * e->lpc + 63) / 64;
-  const bool fast_lik = e->lik.kind == LIK_ROSEN1 || e->lik.kind == LIK_GAUSS || (e->lik.kind == LIK_MIX && e->lik.ncomp <= 8);
+  const bool fast_lik = e->lik.kind == LIK_ROSEN1 || e->lik.kind == LIK_GAUSS || (e->lik.kind == LIK_MIX && e->lik.ncomp <= 8) ||
+                        (e->lik.kind == LIK_USER && user_lik_small_ok(*e->lik.user));  // (a user's source in block form)
   const bool persist = fused && e->lpc <= 8 && fast_lik && e->diag && e->vec4 && !e->opt_mask && e->ncu > 0 &&
                        nown_one_block <= (size_t)POWN_MAX * (size_t)e->ncu && nown <= POWN_MAX * e->ncu && nburn / 50 + 2 <= PEVENTS &&
                        mcxk_persist_lds_bytes(plpc2, pbpl, (nown + std::min(nown, e->ncu) - 1) / std::max(std::min(nown, e->ncu), 1)) <= MCXK_PERSIST_LDS_LIMIT &&
@@ -1097,7 +1098,8 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         if (pb > 0) MCXCHK(meet_lock_take(e));
         {
           ProfScope ps(e, MCX_K_RUN_SMALL, (uint64_t)(pb + pm) * n);
-          const hipError_t le = mcxk_launch_persist(e->lpc, pbpl, e->lik.kind, ra, st);
+          const hipError_t le = e->lik.kind == LIK_USER ? user_lik_launch_small(*e->lik.user, pbpl, ra, st)
+                                                        : mcxk_launch_persist(e->lpc, pbpl, e->lik.kind, ra, st);
           if (le != hipSuccess) (void)meet_release(e, true);
           if (le == hipErrorCooperativeLaunchTooLarge) {  // the grid cannot be resident at once on this device
             (void)hipGetLastError();

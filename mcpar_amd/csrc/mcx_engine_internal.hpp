@@ -149,6 +149,8 @@ int user_lik_launch_fused(const UserLik &u, bool main, const SegArgs &a, hipStre
 int user_lik_launch_eval(const UserLik &u, const float *x, float *y, int n, int d, const float *par, int ncomp, hipStream_t st);
 int user_lik_variant(int lpc, const SegArgs &a);  // 0 hot-path kernel, 1 its full-covariance form, 2 the generic kernel
 double user_lik_compile_ms(const UserLik &u);
+bool user_lik_small_ok(const UserLik &u);  // block form, <= 8 lanes per chain: the one-launch small-n kernel can be built for it
+hipError_t user_lik_launch_small(UserLik &u, int bpl, const RunArgs &a, hipStream_t st);  // (mcxk_launch_persist's role)
 
 struct LikDev {
   int kind = 0;  // LikKind, or MCX_VL_HOST / MCX_VL_DEVICE

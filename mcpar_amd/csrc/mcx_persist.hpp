@@ -200,9 +200,19 @@ __device__ __forceinline__ unsigned long long owners_meet(unsigned long long *le
 // paid once per two blocks, the first stage of the butterfly over the block index is an in-lane add --
 // the same pair, the same sum -- and Philox counters go by block index whichever lane holds the block: same bits.
 template <int LPC2, int BPL, int LIK, bool REC>
+__device__ __forceinline__ void run_small_body(const RunArgs &a);
+
+template <int LPC2, int BPL, int LIK, bool REC>
 __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
 {
-  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX, "hot-path likelihoods only");
+  run_small_body<LPC2, BPL, LIK, REC>(a);
+}
+
+// (the body apart from the kernel: mcx_user.hip compiles it at run time around a user's likelihood source, LIK_USER)
+template <int LPC2, int BPL, int LIK, bool REC>
+__device__ __forceinline__ void run_small_body(const RunArgs &a)
+{
+  static_assert(LIK == LIK_ROSEN1 || LIK == LIK_GAUSS || LIK == LIK_MIX || LIK == LIK_USER, "hot-path likelihoods (or a user's source in block form)");
   static_assert(BPL == 1 || BPL == 2 || BPL == 4, "one, two or four blocks per lane");
 #ifdef MCX_PERSIST_TRACE
   const unsigned long long trace_t_entry = __builtin_amdgcn_s_memtime();
@@ -376,6 +386,17 @@ __global__ __launch_bounds__(PBLOCK) void k_run_small(const RunArgs a)
 
   // likelihood of the proposal (pe, po), same arithmetic as k_fused_fast
   auto loglike = [&](const f32x2 pe[BPL], const f32x2 po[BPL]) -> float {
+#ifdef MCX_USER_LIK
+    if (LIK == LIK_USER) {  // a user's source, block form: per-block partials, the engine's butterfly, the user's finish
+      float acc[BPL];
+#pragma unroll
+      for (int b = 0; b < BPL; ++b) {
+        const float xb[4] = {pe[b].x, po[b].x, pe[b].y, po[b].y};
+        acc[b] = live ? ::mcx_user_block(xb, 4, k0 + 4 * b, d, a.lik) : 0.0f;
+      }
+      return ::mcx_user_finish(blocks_sum(acc), d, a.lik);
+    }
+#endif
     if (LIK == LIK_MIX) {
       const int Kc = a.ncomp;
       float e[8];

@@ -72,10 +72,11 @@ int rtc_compile(const std::string &src, const char *name, const std::vector<std:
   if (!rtc_load()) return fail(MCX_ERR_UNSUPPORTED, "run-time compilation unavailable: %s", g_rtc.why.c_str());
   // (a user's text may well start with #include <hip/hip_runtime.h>: hiprtc has the runtime's declarations built in and no
   // such file, so an empty one stands in)
-  const char *hn[] = {"mcx_numerics.hpp", "mcx_device.hpp", "mcx_fastb.hpp", "hip/hip_runtime.h"};
-  const char *hs[] = {k_hdr_mcx_numerics, k_hdr_mcx_device, k_hdr_mcx_fastb, "// the HIP runtime declarations are built into hiprtc\n"};
+  const char *hn[] = {"mcx_numerics.hpp", "mcx_device.hpp", "mcx_fastb.hpp", "mcx_persist.hpp", "hip/hip_runtime.h"};
+  const char *hs[] = {k_hdr_mcx_numerics, k_hdr_mcx_device, k_hdr_mcx_fastb, k_hdr_mcx_persist,
+                      "// the HIP runtime declarations are built into hiprtc\n"};
   rtcProgram prog = nullptr;
-  int r = g_rtc.CreateProgram(&prog, src.c_str(), name, 4, hs, hn);
+  int r = g_rtc.CreateProgram(&prog, src.c_str(), name, 5, hs, hn);
   if (r != 0) return fail(MCX_ERR_HIP, "hiprtcCreateProgram: %s", g_rtc.GetErrorString(r));
   std::vector<const char *> opts(std::begin(RTC_FLAGS), std::end(RTC_FLAGS));
   for (const std::string &d : defs) opts.push_back(d.c_str());
@@ -122,6 +123,9 @@ const char *const TU_TAIL =
     "#include \"mcx_fastb.hpp\"\n"
     "using namespace mcx;\n"
     "#define K extern \"C\" __global__ __launch_bounds__(BLOCK) void\n"
+    "#if MCX_USER_LIK == 1\n"
+    "extern \"C\" __global__ void mcx_user_is_block_form() {}\n"  // (the host asks the module which form the text has)
+    "#endif\n"
     // whole-vector form: as many blocks per lane as the hot-path kernel has (4, or 2 for np <= 8) -- a chain of np <= 16 is
     // then ONE lane and the function is evaluated once per chain, not once per lane of it
     "#if MCX_USER_LIK == 2 && MCX_USER_LPC >= 2 && MCX_USER_LPC <= 8\n"
@@ -139,6 +143,23 @@ const char *const TU_TAIL =
     "K mcx_user_steps_main(const SegArgs a) { fused_steps_body<MCX_USER_LPC, LIK_USER, true>(a); }\n"
     "K mcx_user_eval(const float *x, float *y, int n, int d, const float *lik, int ncomp, int vec4) { eval_body<MCX_USER_LPC, LIK_USER>(x, y, n, d, lik, ncomp, vec4); }\n";
 
+// The one-launch small-n kernel (mcx_persist.hpp) around the same text: compiled on demand, one instantiation per
+// (lanes per chain, blocks per lane, recorders) the engine picks for the run -- a k_run_small is the largest kernel of the
+// library (2-4 s of hiprtc each).  Block form only: the owners' dependent chain has no room for an LDS round trip.
+const char *const TU_TAIL_SMALL =
+    "\n#line 1 \"mcx_user_small_kernel\"\n"
+    "#ifndef MCX_USER_BLOCK_FORM\n"
+    "#error the one-launch small-n kernel takes the block form only\n"
+    "#endif\n"
+    "#define MCX_USER_LIK 1\n"
+    "#ifndef MCX_USER_FINISH\n"
+    "__device__ __forceinline__ float mcx_user_finish(float s, int, const float *) { return s; }\n"
+    "#endif\n"
+    "#include \"mcx_persist.hpp\"\n"
+    "using namespace mcx;\n"
+    "extern \"C\" __global__ __launch_bounds__(PBLOCK) void mcx_user_small(const RunArgs a)\n"
+    "{ run_small_body<MCX_USER_LPC2, MCX_USER_BPL, LIK_USER, (MCX_USER_REC != 0)>(a); }\n";
+
 }  // namespace
 
 struct UserLik {
@@ -149,8 +170,17 @@ struct UserLik {
   hipFunction_t fast[2] = {nullptr, nullptr}, full[2] = {nullptr, nullptr}, steps[2] = {nullptr, nullptr}, eval = nullptr;
   hipFunction_t fastb[2] = {nullptr, nullptr};  // whole-vector form, 2 <= lpc <= 8: the hot-path kernel with `bpl` blocks per lane
   int bpl = 1;
+  bool block_form = false;
+  int np = 0;
+  struct Small { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; long long resident = -1; size_t lds = 0; };
+  std::map<int, Small> small;  // by bpl * 2 + rec: the one-launch small-n kernel, compiled when a run first wants it
   double compile_ms = 0.0;
-  ~UserLik() { if (mod) (void)hipModuleUnload(mod); }
+  ~UserLik()
+  {
+    if (mod) (void)hipModuleUnload(mod);
+    for (auto &kv : small)
+      if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+  }
 };
 
 namespace {
@@ -194,6 +224,12 @@ int user_lik_get(const char *source, int np, std::shared_ptr<UserLik> *out)
     (void)hipGetLastError();  // (block form: the kernels are not in the module)
     u->fastb[0] = u->fastb[1] = nullptr;
   }
+  {
+    hipFunction_t marker = nullptr;
+    u->block_form = hipModuleGetFunction(&marker, u->mod, "mcx_user_is_block_form") == hipSuccess;
+    if (!u->block_form) (void)hipGetLastError();
+  }
+  u->np = np;
   HIPCHK(hipModuleGetFunction(&u->steps[0], u->mod, "mcx_user_steps_burn"));
   HIPCHK(hipModuleGetFunction(&u->steps[1], u->mod, "mcx_user_steps_main"));
   HIPCHK(hipModuleGetFunction(&u->eval, u->mod, "mcx_user_eval"));
@@ -240,6 +276,54 @@ int user_lik_launch_eval(const UserLik &u, const float *x, float *y, int n, int 
 
 double user_lik_compile_ms(const UserLik &u) { return u.compile_ms; }
 
+// may a run with this likelihood take the one-launch small-n kernel?
+bool user_lik_small_ok(const UserLik &u) { return u.block_form && u.lpc <= 8; }
+
+// mcxk_launch_persist for LIK_USER: the kernel for (blocks per lane, recorders) is built on first use
+hipError_t user_lik_launch_small(UserLik &u, int bpl, const mcx::RunArgs &a, hipStream_t st)
+{
+  const int lpc2 = u.lpc / bpl, rec = mcxk_persist_recorders(a.own, bpl) ? 1 : 0;
+  UserLik::Small *k = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_user_m);
+    k = &u.small[bpl * 2 + rec];
+    if (!k->fn) {
+      const auto t0 = std::chrono::steady_clock::now();
+      std::vector<char> code;
+      std::string log;
+      if (rtc_compile(std::string(TU_HEAD) + u.source + TU_TAIL_SMALL, "mcx_user_small.hip",
+                      {"-DMCX_USER_LPC=" + std::to_string(u.lpc), "-DMCX_USER_NP=" + std::to_string(u.np),
+                       "-DMCX_USER_LPC2=" + std::to_string(lpc2), "-DMCX_USER_BPL=" + std::to_string(bpl),
+                       "-DMCX_USER_REC=" + std::to_string(rec)}, code, log) != MCX_OK)
+        return hipErrorInvalidValue;  // (mcx_last_error holds the compiler's words)
+      hipError_t he = hipModuleLoadData(&k->mod, code.data());
+      if (he == hipSuccess) he = hipModuleGetFunction(&k->fn, k->mod, "mcx_user_small");
+      if (he != hipSuccess) return he;
+      if (getenv("MCX_VERBOSE"))
+        fprintf(stderr, "mcx: user likelihood compiled into the one-launch kernel (%d lanes per chain, %d blocks per lane%s) in %.0f ms\n",
+                lpc2, bpl, rec ? ", recorders" : "", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+  }
+  const unsigned nwg = (unsigned)((a.nown + a.own - 1) / a.own);
+  const size_t lds = mcxk_persist_lds_bytes(lpc2, bpl, a.own);
+  if (a.nburn > 0) {  // tuner meetings inside: every workgroup must be resident at once (mcx_k_persist.hip: go2)
+    std::lock_guard<std::mutex> lk(g_user_m);
+    if (k->resident < 0 || k->lds != lds) {
+      int per_cu = 0, ncu = 0, dev = 0;
+      hipError_t he = hipGetDevice(&dev);
+      if (he == hipSuccess) he = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k->fn, mcx::PBLOCK, lds);
+      if (he == hipSuccess) he = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (he != hipSuccess) return he;
+      k->resident = (long long)per_cu * ncu;
+      k->lds = lds;
+    }
+    if (k->resident < (long long)nwg) return hipErrorCooperativeLaunchTooLarge;
+  }
+  mcx::RunArgs arg = a;
+  void *args[] = {&arg};
+  return hipModuleLaunchKernel(k->fn, nwg, 1, 1, mcx::PBLOCK, 1, 1, (unsigned)lds, st, args, nullptr);
+}
+
 extern "C" int mcx_user_source_available(void)
 {
   std::lock_guard<std::mutex> lk(g_user_m);
@@ -258,6 +342,21 @@ extern "C" int mcx_debug_user_source_compile(const char *source, int np, size_t 
   std::string log;
   MCXCHK(rtc_compile(std::string(TU_HEAD) + source + TU_TAIL, "mcx_user.hip",
                      {"-DMCX_USER_LPC=" + std::to_string(lpc_for(np)), "-DMCX_USER_NP=" + std::to_string(np)}, code, log));
+  if (code_bytes) *code_bytes = code.size();
+  return MCX_OK;
+}
+
+// the same for the one-launch small-n kernel around a block-form text (what user_lik_launch_small builds on first use)
+extern "C" int mcx_debug_user_source_compile_small(const char *source, int np, int bpl, int rec, size_t *code_bytes)
+{
+  if (!source || np < 1 || np > 32 || (bpl != 1 && bpl != 2) || lpc_for(np) % bpl) return fail(MCX_ERR_INVALID, "bad arguments");
+  std::lock_guard<std::mutex> lk(g_user_m);
+  std::vector<char> code;
+  std::string log;
+  const int lpc = lpc_for(np);
+  MCXCHK(rtc_compile(std::string(TU_HEAD) + source + TU_TAIL_SMALL, "mcx_user_small.hip",
+                     {"-DMCX_USER_LPC=" + std::to_string(lpc), "-DMCX_USER_NP=" + std::to_string(np), "-DMCX_USER_LPC2=" + std::to_string(lpc / bpl),
+                      "-DMCX_USER_BPL=" + std::to_string(bpl), "-DMCX_USER_REC=" + std::to_string(rec ? 1 : 0)}, code, log));
   if (code_bytes) *code_bytes = code.size();
   return MCX_OK;
 }

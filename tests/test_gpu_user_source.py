@@ -195,3 +195,38 @@ def test_a_whole_kernel_from_source_for_the_device_kind():
     with pytest.raises(M.McxError):
         E.compile_user_kernel(text, "no_such_kernel")
     eg.close(); eo.close()
+
+
+@pytest.mark.parametrize("d,n", [(8, 4096), (16, 8192), (16, 16384), (2, 1000), (32, 8192), (12, 2048)])
+def test_block_form_source_takes_the_one_launch_small_n_kernel(d, n):
+    """Few chains: burn-in with its tuner meetings, the start of the moments and the main loop are ONE launch of k_run_small
+    (mcx_persist.hpp) -- also around a user's source in block form (built by hiprtc when the first run qualifies).  Same bits
+    as the oracle and as the built-in; the counters say which kernel ran."""
+    import mcpar_amd as M
+    nburn, nsamp = 160, 90
+    p = O.default_pinit(d, n)
+    vo, _k = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=1.0, threads=8)
+    vg, _k2 = M.make_vlfunc(M.VL_SOURCE, d, source=src("user_rosenbrock1_blocks.hip"))
+    eg = M.Engine(d, n, pl=1.0)
+    vb, _k3 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eb = M.Engine(d, n, pl=1.0)
+    for r in range(2):
+        eo.run(nsamp, nburn, p, vo)
+        eg.run(nsamp, nburn, p, vg)
+        assert_equal_runs(eo, eg, "small-n d=%d n=%d run %d" % (d, n, r), mask=False)
+    eb.run(nsamp, nburn, p, vb)
+    cg, cb = eg.counters, eb.counters
+    assert cg["small_n_launches"] == cb["small_n_launches"] and cg["kernel_launches"] == cb["kernel_launches"], (cg, cb)
+    if d % 4 == 0:
+        assert cg["small_n_launches"] >= 1 and cg["kernel_launches"] <= 3
+    # the whole-vector form has no small-n kernel: per-segment kernels, same bits
+    vw, _k4 = M.make_vlfunc(M.VL_SOURCE, d, params=np.array([1.0], np.float32), source=src("user_rosenbrock1_whole.hip"))
+    ew = M.Engine(d, n, pl=1.0)
+    ew.run(nsamp, nburn, p, vw)
+    eo2 = O.Engine(d, n, pl=1.0, threads=8)
+    eo2.run(nsamp, nburn, p, vo)
+    assert_equal_runs(eo2, ew, "whole-vector, few chains", mask=False)
+    assert ew.counters["small_n_launches"] == 0
+    for e in (eg, eb, ew, eo, eo2):
+        e.close()

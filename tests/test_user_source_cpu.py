@@ -30,6 +30,17 @@ def test_hiprtc_is_there_and_the_sample_sources_build():
             assert rc == 0 and nbytes > 10000, (name, d, err)
 
 
+def test_the_one_launch_small_n_kernel_builds_around_a_block_form_text():
+    import mcpar_amd as M
+    lib = M.load()
+    n = C.c_size_t(0)
+    for d, bpl, rec in ((8, 1, 1), (16, 1, 0), (16, 2, 0), (32, 2, 0), (4, 1, 1)):
+        rc = lib.mcx_debug_user_source_compile_small(src("user_rosenbrock1_blocks.hip"), d, bpl, rec, C.byref(n))
+        assert rc == 0 and n.value > 10000, (d, bpl, rec, lib.mcx_last_error())
+    rc = lib.mcx_debug_user_source_compile_small(src("user_banana.hip"), 8, 1, 1, None)  # whole-vector form
+    assert rc == 7 and b"block form only" in lib.mcx_last_error()
+
+
 def test_a_text_that_does_not_compile_says_why():
     import mcpar_amd as M
     lib = M.load()
