@@ -2,6 +2,7 @@
 // The small-n job (one launch of ~0.39 ms) pays launch + completion once per run: 25-30 us of its 0.418 ms (EXPERIMENTS.md).
 // Ways to wait, timed around the same ~100 us kernel (kernel time by events subtracted):
 //   sync    hipStreamSynchronize
+//   copy    a 64-byte hipMemcpyAsync device -> pinned host behind the kernel, then hipStreamSynchronize (what mcx_run does)
 //   event   spin on hipEventQuery of an event recorded behind the kernel
 //   value   hipStreamWriteValue32 of a serial number into pinned host memory behind the kernel, host spins on the word
 //   kernel  the kernel itself stores the serial to pinned host memory (system scope) as its last act, host spins
@@ -51,8 +52,12 @@ int main()
   const unsigned long long ticks = 10000;  // 100 us at 100 MHz
   const int grid = 256, reps = 200;
   unsigned serial = 0;
-  const char *names[] = {"sync", "event", "value", "kernel"};
-  for (int mode = 0; mode < 4; ++mode) {
+  const char *names[] = {"sync", "event", "value", "kernel", "copy"};
+  unsigned long long *dctr = nullptr, *hctr = nullptr;
+  CHK(hipMalloc(&dctr, 64));
+  CHK(hipMemset(dctr, 0, 64));
+  CHK(hipHostMalloc(&hctr, 64, hipHostMallocDefault));
+  for (int mode = 0; mode < 5; ++mode) {
     std::vector<double> over;
     for (int r = 0; r < reps + 20; ++r) {
       ++serial;
@@ -61,6 +66,9 @@ int main()
       hipLaunchKernelGGL(spin_kernel, dim3(grid), dim3(256), 0, st, ticks, mode == 3 ? flag : nullptr, serial, dcount);
       CHK(hipEventRecord(eb, st));
       if (mode == 0) {
+        CHK(hipStreamSynchronize(st));
+      } else if (mode == 4) {
+        CHK(hipMemcpyAsync(hctr, dctr, 64, hipMemcpyDeviceToHost, st));
         CHK(hipStreamSynchronize(st));
       } else if (mode == 1) {
         while (hipEventQuery(eb) == hipErrorNotReady) {}
