@@ -184,7 +184,8 @@ struct UserLik {
 };
 
 namespace {
-std::map<std::string, std::shared_ptr<UserLik>> g_user_cache;
+// never destroyed: at process exit the HIP runtime may be gone before a static destructor could unload a module
+std::map<std::string, std::shared_ptr<UserLik>> &g_user_cache = *new std::map<std::string, std::shared_ptr<UserLik>>;
 }
 
 int user_lik_get(const char *source, int np, std::shared_ptr<UserLik> *out)
