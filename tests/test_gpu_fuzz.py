@@ -52,10 +52,15 @@ def one_case(rng, idx):
     sink = int(rng.choice([0, 0, 1, 3, 10, 64]))  # > 0: samples streamed through the sink in blocks of that many steps
     cull = int(rng.choice([-1, -1, 0, 1, 2, 3]))   # exact exclusion of far Gaussians in the Murray sweeps: auto / off / boxes / one direction / per-pair bound
     bpl = int(rng.choice([0, 0, 1, 2, 4]))      # parameter blocks per lane of the hot-path kernel (0 = automatic)
+    # round 5's options, from a generator of their own (the cases of the fixed set stay the cases they were):
+    rng5 = np.random.default_rng(1000003 * (idx + 1) + int(os.environ.get("MCX_FUZZ_SEED", "0")))
+    async_run = int(rng5.random() < 0.3)         # mcx_run returns once the run is queued (runs that qualify; the getters finish it)
+    overlap = int(rng5.choice([0, 0, 2, 4]))     # Murray passes over many chains by column chunks on two streams
     if os.environ.get("MCX_FUZZ_CULL"):         # a soak of one screen: every case with it
         cull = int(os.environ["MCX_FUZZ_CULL"])
     desc = dict(idx=idx, kind=kind, d=d, n=n, nburn=nburn, nsamp=nsamp, pl=pl, sync=sync, K=K, fullcov=incov is not None,
-                fuse=fuse, mask=mask, maxseg=maxseg, stride=stride, persist=persist, split=split, sink=sink, cull=cull, bpl=bpl)
+                fuse=fuse, mask=mask, maxseg=maxseg, stride=stride, persist=persist, split=split, sink=sink, cull=cull, bpl=bpl,
+                async_run=async_run, overlap=overlap)
     p = (rng.normal(0, 0.7, (n, d))).astype(np.float32)
     vo, k1 = O.make_vlfunc(kind, d, params, K)
     eo = O.Engine(d, n, pl=pl, sync=sync, threads=8 if n >= 200 else 1)
@@ -70,6 +75,8 @@ def one_case(rng, idx):
     eg.set_option(E.OPT_SPLIT_RNG, split)
     eg.set_option(E.OPT_CULL, cull)
     eg.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
+    eg.set_option(E.OPT_ASYNC_RUN, async_run)
+    eg.set_option(E.OPT_MURRAY_OVERLAP, overlap)
     streamed, texts = [], []
     as_text = bool(sink) and rng.random() < 0.2 and n * nsamp * (d + 1) < 200000  # the blocks as text (mcx_set_text_sink)
     if as_text:
