@@ -122,7 +122,7 @@ const char *const TU_TAIL =
     "#endif\n"
     "#include \"mcx_fastb.hpp\"\n"
     "using namespace mcx;\n"
-    "#define K extern \"C\" __global__ __launch_bounds__(BLOCK) void\n"
+    "#define MCX_USER_KERNEL extern \"C\" __global__ __launch_bounds__(BLOCK) void\n"
     "#if MCX_USER_LIK == 1\n"
     "extern \"C\" __global__ void mcx_user_is_block_form() {}\n"  // (the host asks the module which form the text has)
     "#endif\n"
@@ -130,18 +130,18 @@ const char *const TU_TAIL =
     // then ONE lane and the function is evaluated once per chain, not once per lane of it
     "#if MCX_USER_LIK == 2 && MCX_USER_LPC >= 2 && MCX_USER_LPC <= 8\n"
     "#define MCX_USER_BPL (MCX_USER_LPC >= 4 ? 4 : 2)\n"
-    "K mcx_user_fastb_burn(const SegArgs a) { const uint32_t w = fused_fastb_body<MCX_USER_LPC / MCX_USER_BPL, MCX_USER_BPL, false, LIK_USER>(a); tuner_epilogue(a, w); }\n"
-    "K mcx_user_fastb_main(const SegArgs a) { const uint32_t w = fused_fastb_body<MCX_USER_LPC / MCX_USER_BPL, MCX_USER_BPL, true, LIK_USER>(a); tuner_epilogue(a, w); }\n"
+    "MCX_USER_KERNEL mcx_user_fastb_burn(const SegArgs a) { const uint32_t w = fused_fastb_body<MCX_USER_LPC / MCX_USER_BPL, MCX_USER_BPL, false, LIK_USER>(a); tuner_epilogue(a, w); }\n"
+    "MCX_USER_KERNEL mcx_user_fastb_main(const SegArgs a) { const uint32_t w = fused_fastb_body<MCX_USER_LPC / MCX_USER_BPL, MCX_USER_BPL, true, LIK_USER>(a); tuner_epilogue(a, w); }\n"
     "#endif\n"
     "#if MCX_USER_LPC <= 8\n"
-    "K mcx_user_fast_burn(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, false, LIK_USER, false, false>(a); tuner_epilogue(a, w); }\n"
-    "K mcx_user_fast_main(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, true, LIK_USER, false, false>(a); tuner_epilogue(a, w); }\n"
-    "K mcx_user_full_burn(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, false, LIK_USER, false, true>(a); tuner_epilogue(a, w); }\n"
-    "K mcx_user_full_main(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, true, LIK_USER, false, true>(a); tuner_epilogue(a, w); }\n"
+    "MCX_USER_KERNEL mcx_user_fast_burn(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, false, LIK_USER, false, false>(a); tuner_epilogue(a, w); }\n"
+    "MCX_USER_KERNEL mcx_user_fast_main(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, true, LIK_USER, false, false>(a); tuner_epilogue(a, w); }\n"
+    "MCX_USER_KERNEL mcx_user_full_burn(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, false, LIK_USER, false, true>(a); tuner_epilogue(a, w); }\n"
+    "MCX_USER_KERNEL mcx_user_full_main(const SegArgs a) { const uint32_t w = fused_fast_body<MCX_USER_LPC, true, LIK_USER, false, true>(a); tuner_epilogue(a, w); }\n"
     "#endif\n"
-    "K mcx_user_steps_burn(const SegArgs a) { fused_steps_body<MCX_USER_LPC, LIK_USER, false>(a); }\n"
-    "K mcx_user_steps_main(const SegArgs a) { fused_steps_body<MCX_USER_LPC, LIK_USER, true>(a); }\n"
-    "K mcx_user_eval(const float *x, float *y, int n, int d, const float *lik, int ncomp, int vec4) { eval_body<MCX_USER_LPC, LIK_USER>(x, y, n, d, lik, ncomp, vec4); }\n";
+    "MCX_USER_KERNEL mcx_user_steps_burn(const SegArgs a) { fused_steps_body<MCX_USER_LPC, LIK_USER, false>(a); }\n"
+    "MCX_USER_KERNEL mcx_user_steps_main(const SegArgs a) { fused_steps_body<MCX_USER_LPC, LIK_USER, true>(a); }\n"
+    "MCX_USER_KERNEL mcx_user_eval(const float *x, float *y, int n, int d, const float *lik, int ncomp, int vec4) { eval_body<MCX_USER_LPC, LIK_USER>(x, y, n, d, lik, ncomp, vec4); }\n";
 
 // The one-launch small-n kernel (mcx_persist.hpp) around the same text: compiled on demand, one instantiation per
 // (lanes per chain, blocks per lane, recorders) the engine picks for the run -- a k_run_small is the largest kernel of the
