@@ -383,7 +383,9 @@ extern "C" int mcx_destroy(mcx_engine *e)
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   e->pend.active = false;  // (a run nobody waited for: over now; its results go with the engine)
   if (e->meet_held) { (void)flock(e->meet_fd, LOCK_UN); e->meet_held = false; }
+  if (e->astream) { (void)hipStreamSynchronize(e->astream); (void)hipStreamDestroy(e->astream); e->astream = nullptr; }
   for (hipEvent_t &ev : e->run_ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+  for (hipEvent_t &ev : e->copy_ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
   prof_collect(e);
   (void)mcx_exchange_rccl_destroy(e);
   e->pvals.release(); e->ptrial.release(); e->mu.release(); e->sig.release(); e->psum2.release();
@@ -780,7 +782,9 @@ int finish_pending(mcx_engine *e)
   if (!e->pend.active) return MCX_OK;
   const mcx_engine::PendingRun p = e->pend;
   e->pend.active = false;
-  const hipError_t se = hipStreamSynchronize(e->stream);
+  hipError_t se = hipStreamSynchronize(e->stream);
+  if (se == hipSuccess && e->copy_pending[p.slot]) se = hipEventSynchronize(e->copy_ev[p.slot]);  // (its counters: a stream of their own)
+  e->copy_pending[p.slot] = false;
   const bool abandoned = p.meet_check && se == hipSuccess && p.hctr[5] != 0;
   e->meet_check = false;
   (void)meet_release(e, true);
@@ -812,7 +816,10 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       (void)hipGetLastError();
       // at most TWO runs in flight: the one before the pending one must be over before this call reuses its counter slot
       // (the host queues a small job in 15 us, the GPU takes 400: without a bound the queue would only grow)
-      if (e->run_ev[e->hctr_slot ^ 1]) HIPCHK(hipEventSynchronize(e->run_ev[e->hctr_slot ^ 1]));
+      if (e->copy_pending[e->hctr_slot ^ 1]) {  // (its counters' copy runs behind it: over = both over)
+        HIPCHK(hipEventSynchronize(e->copy_ev[e->hctr_slot ^ 1]));
+        e->copy_pending[e->hctr_slot ^ 1] = false;
+      }
       note_superseded(e);
       e->superseded_hctr = e->pend.meet_check ? e->pend.hctr : nullptr;
       e->pend.active = false;
@@ -943,7 +950,11 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   bool lead = persist && nburn + nsamp > 0;
   // this run's counter block: a ring, zeroed as a whole when it wraps
   e->ctr_set = (e->ctr_set + 1) % CTR_RING;
-  if (e->ctr_set == 0) HIPCHK(hipMemsetAsync(e->ctr.p, 0, (size_t)CTR_WORDS * CTR_RING * sizeof(unsigned long long), st));
+  if (e->ctr_set == 0) {
+    for (int sl = 0; sl < 2; ++sl)  // (an asynchronous run's counters may still be on their way out of the ring)
+      if (e->copy_pending[sl]) HIPCHK(hipStreamWaitEvent(st, e->copy_ev[sl], 0));
+    HIPCHK(hipMemsetAsync(e->ctr.p, 0, (size_t)CTR_WORDS * CTR_RING * sizeof(unsigned long long), st));
+  }
   unsigned long long *const ctrp = e->ctr.p + (size_t)e->ctr_set * CTR_WORDS;
   // pinit is pageable caller memory: the runtime stages it before hipMemcpyAsync returns
   if (pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
@@ -1273,8 +1284,6 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   e->hctr_slot ^= 1;           // two slots in turn (MCX_OPT_ASYNC_RUN: the previous run's may not have been read yet)
   unsigned long long *hctr = e->h_ctr.p + 8 * e->hctr_slot;
   MCXCHK(cov_reset(e));  // (a run without any step)
-  HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  e->ht_mark[1] = std::chrono::steady_clock::now();
   // MCX_OPT_ASYNC_RUN: everything is queued -- return.  Only runs whose end needs nothing from the host: one shard, no
   // sink / output hook / host likelihood, no Murray step (a pass waits for its survivors' count), no profiling.
   bool go_async = e->opt_async_run && !rerun && e->size == 1 && !sink && !e->ofn && nsamp > 0 && e->lik.kind != MCX_VL_HOST &&
@@ -1285,9 +1294,20 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
       MCXCHK(e->pinit_async.alloc((size_t)e->ntot));
       HIPCHK(hipMemcpyAsync(e->pinit_async.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));
     }
-    if (!e->run_ev[e->hctr_slot]) HIPCHK(hipEventCreateWithFlags(&e->run_ev[e->hctr_slot], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(e->run_ev[e->hctr_slot], st));
+    // the counters' way to the host on a stream of its own, behind an event: on the step stream the copy would sit between
+    // this run's last kernel and the next run's first one (5-8 us of every queued job)
+    const int sl = e->hctr_slot;
+    if (!e->astream) HIPCHK(hipStreamCreateWithFlags(&e->astream, hipStreamNonBlocking));
+    if (!e->run_ev[sl]) HIPCHK(hipEventCreateWithFlags(&e->run_ev[sl], hipEventDisableTiming));
+    if (!e->copy_ev[sl]) HIPCHK(hipEventCreateWithFlags(&e->copy_ev[sl], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->run_ev[sl], st));
+    HIPCHK(hipStreamWaitEvent(e->astream, e->run_ev[sl], 0));
+    HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->astream));
+    HIPCHK(hipEventRecord(e->copy_ev[sl], e->astream));
+    e->copy_pending[sl] = true;
+    e->ht_mark[1] = std::chrono::steady_clock::now();
     e->pend.active = true;
+    e->pend.slot = sl;
     e->pend.nsamp = nsamp; e->pend.nburn = nburn; e->pend.tbase0 = e->tbase;
     e->pend.meet_check = e->meet_check; e->pend.hctr = hctr; e->pend.host_pinit = pinit != nullptr;
     e->meet_check = false;  // (finish_pending looks at the word itself)
@@ -1296,6 +1316,8 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     e->tbase += (uint32_t)(nburn + nsamp);
     return MCX_OK;
   }
+  HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  e->ht_mark[1] = std::chrono::steady_clock::now();
   {
     const hipError_t se = hipStreamSynchronize(st);
     e->ht_mark[2] = std::chrono::steady_clock::now();

@@ -288,7 +288,11 @@ struct mcx_engine {
     bool meet_check = false;             // its one-launch kernel had tuner meetings: word 5 of its counters says if one was abandoned
     unsigned long long *hctr = nullptr;  // its slot of the pinned counter ring
     bool host_pinit = false;             // it started from caller memory (kept in pinit_async for a repeat), not from the staged state
+    int slot = 0;                        // its counter slot / events
   } pend;
+  hipStream_t astream = nullptr;         // an asynchronous run's counters travel on it, beside the next run's kernels
+  hipEvent_t copy_ev[2] = {nullptr, nullptr};
+  bool copy_pending[2] = {false, false};
   unsigned long long *superseded_hctr = nullptr;  // a run nobody looked at before the next was queued: its counters, for the books only
   DevBuf<float> pinit_async;
   int hctr_slot = 0;
