@@ -264,6 +264,9 @@ enum {
                               jobs; the overtaken run's results are never seen (the next run overwrites them, as ever) and its
                               counters are not reported.  pinit / incov / the vlfunc are copied during the call as ever.
                               [default 0] */
+  MCX_OPT_REFERENCE_CALLS = 20, /* 1: after every main-loop step call a HOST functor once per chain on (1, pvals_j, &y) and discard the
+                              result, as the reference does (src/mcpar.cc:177-182): for functors whose side effects -- a call
+                              counter, a cache -- must see the calls they see there.  Results do not change.  [default 0] */
   MCX_OPT_MURRAY_OVERLAP = 18, /* Murray passes over many chains (np = 16 or 32, the per-pair screen): cut the Gaussians into this
                               many column chunks and screen chunk c + 1 (matrix cores, step stream) while chunk c is swept
                               (vector units, a side stream).  Same bits.  0 / 1: one screen, then one sweep */

@@ -715,6 +715,12 @@ int MCPar::run(int nsamp, int nburn, const float *pinit, VLFunc &L, MCout &outsa
   if (mpi && comm) MPI_Bcast(&gpu_text, 1, MPI_INT, 0, comm->comm);
 #endif
   mcx_set_option(eng, MCX_OPT_SINK_TEXT, gpu_text);
+  // MCPAR_REFERENCE_CALLS=1: a host functor also gets the reference's discarded per-chain calls L(1, pvals_j, &y) after
+  // every main-loop step (src/mcpar.cc:177-182) -- for functors that count or cache their calls; results do not change
+  {
+    const char *rc_env = getenv("MCPAR_REFERENCE_CALLS");
+    mcx_set_option(eng, MCX_OPT_REFERENCE_CALLS, (rc_env && *rc_env && *rc_env != '0') ? 1 : 0);
+  }
   RunCtx ctx = {eng,   &outsamples, &logfile, nchain,   nparam + 1, 0, nsamp, std::vector<float>(),
                 logging, mpi,        logstep,  SYNCSTEP, 0,          outsamples.size(), gpu_text != 0};
   const int outstep = nsamp > 50 ? nsamp / 10 : 5;  // src/mcpar.cc:110

@@ -475,6 +475,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
     e->opt_meet_timeout_ms = (int)std::min<int64_t>(value, 600000);
     break;
   case MCX_OPT_ASYNC_RUN: e->opt_async_run = value ? 1 : 0; break;
+  case MCX_OPT_REFERENCE_CALLS: e->opt_reference_calls = value ? 1 : 0; break;
   case MCX_OPT_MURRAY_OVERLAP:
     if (value < 0 || value > 64) return fail(MCX_ERR_INVALID, "MURRAY_OVERLAP: 0 (off) or the number of column chunks, <= 64");
     e->opt_murray_overlap = (int)value;
@@ -571,6 +572,21 @@ static int eval_trials(mcx_engine *e, const float *x_dev, float *y_dev, uint64_t
     return MCX_OK;
   }
   return eval_device(e->lik, x_dev, y_dev, n, d, e->stream);
+}
+
+// MCX_OPT_REFERENCE_CALLS: the reference evaluates L(1, pvals_j, &y) once per chain after every main-loop step and throws
+// the result away (src/mcpar.cc:177-182).  A host functor with side effects -- a call counter, a cache, a log -- sees those
+// calls there; here they are made only on request, for host functors (a device likelihood has no side effects to keep).
+static int discarded_calls(mcx_engine *e)
+{
+  if (!e->opt_reference_calls || e->lik.kind != MCX_VL_HOST) return MCX_OK;
+  const int n = e->nchain, d = e->nparam;
+  MCXCHK(e->h_ptrial.alloc((size_t)e->ntot));
+  HIPCHK(hipMemcpyAsync(e->h_ptrial.p, e->pvals.p, (size_t)e->ntot * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  float y = 0.0f;
+  for (int j = 0; j < n; ++j) (void)e->lik.fn(e->lik.ctx, 1, e->h_ptrial.p + (size_t)j * d, &y);
+  return MCX_OK;
 }
 
 // Base pointers such that kept step r = isamp / stride of the run lives at base + r * rowsize: the whole-run
@@ -1215,6 +1231,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
       StepArgs a;
       fill_step(e, a, t, isamp, true, (size_t)(nburn + isamp), isamp, 1);
       MCXCHK(launch_accept(e, a, true));
+      MCXCHK(discarded_calls(e));  // :177-182, on request
       slots_used = true;
       break;
     }
@@ -1262,6 +1279,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
           MCXCHK(launch_propose(e, a));
           MCXCHK(eval_trials(e, e->ptrial.p, e->lytrial.p, (uint64_t)n));
           MCXCHK(launch_accept(e, a, true));
+          MCXCHK(discarded_calls(e));  // :177-182, on request
         }
       }
       break;

@@ -281,6 +281,7 @@ struct mcx_engine {
   bool xcomm_owned = false;
   // MCX_OPT_ASYNC_RUN: a run whose kernels are queued and whose end nobody has waited for yet (mcx_engine.hip: finish_pending)
   int opt_async_run = 0;
+  int opt_reference_calls = 0;  // MCX_OPT_REFERENCE_CALLS: make the reference's discarded per-chain L(1, pvals_j) calls (host functors)
   struct PendingRun {
     bool active = false;
     int nsamp = 0, nburn = 0;

@@ -22,6 +22,7 @@ OPT_SINK_TEXT = 16
 OPT_MEET_UNDER_GATHER = 17
 OPT_MURRAY_OVERLAP = 18
 OPT_ASYNC_RUN = 19
+OPT_REFERENCE_CALLS = 20
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 

@@ -78,6 +78,13 @@ def test_cpp_api_builtin_and_user_vlfunc(tmp_path):
     assert a == expect
     # VLFunc is called once before burn-in and once per step (src/mcpar.cc:53,60,160)
     assert "user calls %d" % (1 + nburn + nsamp) in tail
+    # ... and, on request, once more per chain after every main-loop step, result discarded, like the reference
+    # (src/mcpar.cc:177-182: MCX_OPT_REFERENCE_CALLS / MCPAR_REFERENCE_CALLS=1) -- same rows, more calls
+    r2 = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=dict(os.environ, MCPAR_REFERENCE_CALLS="1"))
+    assert r2.returncode == 0, r2.stderr
+    a2, b2, tail2 = r2.stdout.split("=====\n")
+    assert a2 == a and b2 == b
+    assert "user calls %d" % (1 + nburn + nsamp + nsamp * nc) in tail2
     assert "guard: N for Rosenbrock1 must be even and >= 2" in tail
     # mcpar.logging = true, logstep = 7, nsamp = 20 (outstep 5), 4 chains: the reference's diagnostics, in
     # its order (src/mcpar.cc:115-126): dump message of iteration i, then the diagnostic of iteration i
