@@ -380,11 +380,8 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm_sums(const un
     return reinterpret_cast<const scr_u32x4 *>(B + ((size_t)b * SCR_BLK + c / PIECES) * K)[c % PIECES];
   };
   scr_u32x4 hold[PER];
-  float2 cnext[4];  // (C'_i, |B_i|) of this lane's four columns of the next block: requested a block ahead, like the rows
 #pragma unroll
   for (int u = 0; u < PER; ++u) hold[u] = piece(b0, (int)threadIdx.x + u * NT);
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) cnext[ct] = bc[b0 * SCR_BLK + ct * 32 + r];  // (B and bc hold whole blocks: always in range)
   const int members = have_g ? (nact - g * CULL_W < CULL_W ? nact - g * CULL_W : CULL_W) : 0;
   unsigned long long kept = 0;
   for (int b = b0; b < b1; ++b) {
@@ -394,23 +391,18 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm_sums(const un
       const int c = (int)threadIdx.x + u * NT;
       *reinterpret_cast<scr_u32x4 *>(blds + (c / PIECES) * LROW + (c % PIECES) * 16) = hold[u];
     }
-    float2 cnow[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) cnow[ct] = cnext[ct];
     __syncthreads();
     {  // the next block on its way while this one is multiplied (unconditional: the last block once more)
       const int bn = b + 1 < b1 ? b + 1 : b;
 #pragma unroll
       for (int u = 0; u < PER; ++u) hold[u] = piece(bn, (int)threadIdx.x + u * NT);
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) cnext[ct] = bc[bn * SCR_BLK + ct * 32 + r];
     }
     if (!have_g) continue;
     unsigned m32[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       const int col = b * SCR_BLK + ct * 32 + r;
-      const float2 cn = cnow[ct];
+      const float2 cn = bc[col];  // (B and bc have a whole number of blocks: always in range)
       scr_bf16x8 bf[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
