@@ -394,7 +394,7 @@ extern "C" int mcx_destroy(mcx_engine *e)
   e->trace.release(); e->acc_cnt.release(); e->acc_slots.release(); e->ctr.release(); e->active0.release();
   e->active1.release(); e->nact.release(); e->ntrace.release(); e->samp_x.release();
   e->cull_keys.release(); e->cull_hist.release(); e->cull_sorted.release(); e->cull_stats.release(); e->cull_box.release();
-  e->cull_lim.release(); e->cull_excl.release(); e->scr_a.release(); e->scr_b.release(); e->scr_centre.release(); e->scr_bc.release(); e->scr_amax.release(); e->cand.release(); e->proj_acc.release(); e->proj_p.release(); e->proj_lohi.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
+  e->cull_lim.release(); e->cull_excl.release(); e->scr_a.release(); e->scr_b.release(); e->scr_centre.release(); e->cand.release(); e->proj_acc.release(); e->proj_p.release(); e->proj_lohi.release(); e->tun_cells.release(); e->text_wg.release(); e->text_dev.release();
   e->samp_ly.release(); e->mask.release(); e->lik.params.release(); e->winv_tab.release(); e->psum.release(); e->pmax.release(); e->racpt.release(); e->pinit_dev.release();
   e->h_ptrial.release(); e->h_lytrial.release(); e->h_ctr.release(); e->h_nact.release(); e->zpre.release(); e->upre.release(); e->trash.release(); e->deal_tab.release(); e->trace_clk.release();
   for (int b = 0; b < 2; ++b) {

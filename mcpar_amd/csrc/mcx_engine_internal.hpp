@@ -236,8 +236,6 @@ struct mcx_engine {
   DevBuf<unsigned long long> cull_excl;
   DevBuf<unsigned short> scr_a, scr_b;  // mcx_screen.hpp: A' per position of the sorted list, B' per Gaussian (bf16)
   DevBuf<float> scr_centre;
-  DevBuf<float2> scr_bc;    // per Gaussian (C'_i, |B_i| up): the sum screen's epilogue (k_screen_gemm_sums)
-  DevBuf<float> scr_amax;   // per (group, tile of 32 rows): max S |A_j|
   DevBuf<float> cand;  // Murray passes over few chains: the next passes' proposals (p, mu, sig per candidate, then racpt)
   int opt_cull = -1;  // -1 auto (the per-pair bound: many chains, many Gaussians, np = 16 or 32), 0 off, whenever the kernels
                       // allow: 1 boxes, 2 one direction (mcx_cull_proj.hpp), 3 the per-pair bound (mcx_screen.hpp)

@@ -160,27 +160,14 @@ static int cull_prepare_proj(mcx_engine *e, const float *xrows, const int *ain, 
 struct ScreenLaunch {
   int gx = 0, bchunk = 1, nblk = 0, nact = 0, N = 0, ng = 0, nw = 0;
   unsigned long long *nkept = nullptr;
-  bool sums = false;  // a sum sweep's screen: the K = 2 np kernel with the comparison in its epilogue (mcx_screen.hpp)
 };
-
-// MCX_SCREEN_SUMS_OLD=1 (measurement only): the sum screens on the K + 16 kernel too, as in round 4
-static bool screen_sums_kernel()
-{
-  static const bool old = getenv("MCX_SCREEN_SUMS_OLD") && atoi(getenv("MCX_SCREEN_SUMS_OLD")) != 0;
-  return !old;
-}
 
 template <int DMAX>
 static void screen_gemm_go(mcx_engine *e, const ScreenLaunch &L, int blk0, int blk1, hipStream_t st)
 {
-  const dim3 grid((unsigned)L.gx, (unsigned)((blk1 - blk0 + L.bchunk - 1) / L.bchunk));
-  if (L.sums && screen_sums_kernel())
-    hipLaunchKernelGGL((k_screen_gemm_sums<DMAX>), grid, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)e->scr_a.p,
-                       (const unsigned short *)e->scr_b.p, (const float2 *)e->scr_bc.p, (const float *)e->scr_amax.p, L.nact, L.N, L.ng,
-                       L.bchunk, e->cull_excl.p, L.nw, L.nkept, blk0, blk1);
-  else
-    hipLaunchKernelGGL((k_screen_gemm<DMAX>), grid, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)e->scr_a.p,
-                       (const unsigned short *)e->scr_b.p, L.nact, L.N, L.ng, L.bchunk, e->cull_excl.p, L.nw, L.nkept, blk0, blk1);
+  hipLaunchKernelGGL((k_screen_gemm<DMAX>), dim3((unsigned)L.gx, (unsigned)((blk1 - blk0 + L.bchunk - 1) / L.bchunk)), dim3(SCR_WAVES * 64), 0, st,
+                     (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, L.nact, L.N, L.ng, L.bchunk, e->cull_excl.p, L.nw,
+                     L.nkept, blk0, blk1);
 }
 
 template <int DMAX>
@@ -192,7 +179,7 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
   if (*fresh_q) {
     hipLaunchKernelGGL(k_screen_centre, dim3(1), dim3(1024), 0, st, (const float *)e->winvall.p, N, d, e->scr_centre.p);
     hipLaunchKernelGGL((k_screen_prep_q<DMAX>), dim3(nblocks((size_t)nblk * SCR_BLK)), dim3(BLOCK), 0, st, (const float *)e->winvall.p, N,
-                       nblk * SCR_BLK, (const float *)e->scr_centre.p, e->scr_b.p, e->scr_bc.p);
+                       nblk * SCR_BLK, (const float *)e->scr_centre.p, e->scr_b.p);
     e->cnt.kernel_launches += 2;
     *fresh_q = false;
   }
@@ -211,12 +198,10 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
   const dim3 gp(nblocks((size_t)ng * CULL_W));
   if (sums)
     hipLaunchKernelGGL((k_screen_prep_x<DMAX, true>), gp, dim3(BLOCK), 0, st, xrows, order, nact, ng * CULL_W,
-                       (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p,
-                       e->scr_amax.p);
+                       (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p);
   else
     hipLaunchKernelGGL((k_screen_prep_x<DMAX, false>), gp, dim3(BLOCK), 0, st, xrows, order, nact, ng * CULL_W,
-                       (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p,
-                       (float *)nullptr);
+                       (const float *)e->winvall.p, own0, (const float *)e->scr_centre.p, e->scr_a.p, e->cull_stats.p, e->cull_hist.p);
   // The Gaussians' blocks are cut into chunks so that the grid is two chipfuls of workgroups (the kernel's own occupancy
   // x the CUs; one to four chipfuls, or 4096 workgroups whatever the chip holds: the same time within 2 %)
   constexpr int rounds = 2;
@@ -235,7 +220,6 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
   ScreenLaunch L;
   L.gx = gx; L.bchunk = bchunk; L.nblk = nblk; L.nact = nact; L.N = N; L.ng = ng; L.nw = nw;
   L.nkept = reinterpret_cast<unsigned long long *>(e->nact.p) + 1 + (sums ? CULL_NCOUNT : 0);
-  L.sums = sums;
   if (defer) {
     *defer = L;
     HIPCHK(hipGetLastError());
@@ -340,7 +324,6 @@ int remote_device(mcx_engine *e, uint32_t t, const float *pvals, const float *mu
     if (fresh_p) HIPCHK(hipMemsetAsync(e->proj_acc.p, 0, 2 * PROJ_ACC * sizeof(double), st));
     MCXCHK(e->scr_centre.alloc(64)); MCXCHK(e->scr_a.alloc(ngmax * CULL_W * scr_k(dm)));
     MCXCHK(e->scr_b.alloc((((size_t)N + SCR_BLK - 1) / SCR_BLK) * SCR_BLK * scr_k(dm)));
-    MCXCHK(e->scr_bc.alloc((((size_t)N + SCR_BLK - 1) / SCR_BLK) * SCR_BLK)); MCXCHK(e->scr_amax.alloc(ngmax * (CULL_W / 32)));
   }
   // which exact screen: boxes of four coordinates, or -- on request only -- one direction (mcx_cull_proj.hpp).  Measured
   // in round 4: on C3's shape the direction keeps 0.58 of the pairs where the boxes keep 0.41; on C5's mixture it keeps
@@ -608,13 +591,10 @@ extern "C" int mcx_debug_murray_screen(int d, int nact, int N, const float *x, c
   DevBuf<float> dx, dms, q, centre, stats;
   DevBuf<unsigned> hist;
   DevBuf<unsigned short> A, B;
-  DevBuf<float2> bc;
-  DevBuf<float> amax;
   DevBuf<unsigned long long> excl, kept;
   MCXCHK(dx.alloc((size_t)nact * d)); MCXCHK(dms.alloc((size_t)N * d * 2)); MCXCHK(q.alloc((size_t)N * d * 2));
   MCXCHK(centre.alloc(64)); MCXCHK(stats.alloc(2 * CULL_KD)); MCXCHK(hist.alloc(CULL_BINS));
   MCXCHK(A.alloc((size_t)ng * CULL_W * K)); MCXCHK(B.alloc((size_t)nblk * SCR_BLK * K));
-  MCXCHK(bc.alloc((size_t)nblk * SCR_BLK)); MCXCHK(amax.alloc((size_t)ng * (CULL_W / 32)));
   MCXCHK(excl.alloc((size_t)ng * nw)); MCXCHK(kept.alloc(CULL_NCOUNT));
   int rc = MCX_OK;
   auto body = [&]() -> int {
@@ -629,19 +609,15 @@ extern "C" int mcx_debug_murray_screen(int d, int nact, int N, const float *x, c
     const int gx = (ng + SCR_WAVES - 1) / SCR_WAVES;
     const dim3 gg((unsigned)gx, (unsigned)nblk);
 #define SCREEN_FOR(DM)                                                                                                          \
-    hipLaunchKernelGGL((k_screen_prep_q<DM>), gq, dim3(BLOCK), 0, st, (const float *)q.p, N, nblk * SCR_BLK, (const float *)centre.p, B.p, bc.p); \
+    hipLaunchKernelGGL((k_screen_prep_q<DM>), gq, dim3(BLOCK), 0, st, (const float *)q.p, N, nblk * SCR_BLK, (const float *)centre.p, B.p); \
     if (sums)                                                                                                                   \
       hipLaunchKernelGGL((k_screen_prep_x<DM, true>), gp, dim3(BLOCK), 0, st, (const float *)dx.p, (const int *)nullptr, nact, ng * CULL_W, \
-                         (const float *)q.p, -1, (const float *)centre.p, A.p, stats.p, hist.p, amax.p);                         \
+                         (const float *)q.p, -1, (const float *)centre.p, A.p, stats.p, hist.p);                                 \
     else                                                                                                                        \
       hipLaunchKernelGGL((k_screen_prep_x<DM, false>), gp, dim3(BLOCK), 0, st, (const float *)dx.p, (const int *)nullptr, nact, ng * CULL_W, \
-                         (const float *)q.p, own0, (const float *)centre.p, A.p, stats.p, hist.p, (float *)nullptr);             \
-    if (sums && screen_sums_kernel())                                                                                           \
-      hipLaunchKernelGGL((k_screen_gemm_sums<DM>), gg, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)A.p, (const unsigned short *)B.p, \
-                         (const float2 *)bc.p, (const float *)amax.p, nact, N, ng, 1, excl.p, nw, kept.p, 0, nblk);              \
-    else                                                                                                                        \
-      hipLaunchKernelGGL((k_screen_gemm<DM>), gg, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)A.p, (const unsigned short *)B.p, nact, N, \
-                         ng, 1, excl.p, nw, kept.p, 0, nblk);
+                         (const float *)q.p, own0, (const float *)centre.p, A.p, stats.p, hist.p);                               \
+    hipLaunchKernelGGL((k_screen_gemm<DM>), gg, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)A.p, (const unsigned short *)B.p, nact, N, \
+                       ng, 1, excl.p, nw, kept.p, 0, nblk);
     if (d == 16) { SCREEN_FOR(16) } else { SCREEN_FOR(32) }
 #undef SCREEN_FOR
     HIPCHK(hipGetLastError());
@@ -651,6 +627,6 @@ extern "C" int mcx_debug_murray_screen(int d, int nact, int N, const float *x, c
   };
   rc = body();
   dx.release(); dms.release(); q.release(); centre.release(); stats.release(); hist.release(); A.release(); B.release();
-  excl.release(); kept.release(); bc.release(); amax.release();
+  excl.release(); kept.release();
   return rc;
 }

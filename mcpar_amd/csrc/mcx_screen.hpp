@@ -99,13 +99,11 @@ static __global__ __launch_bounds__(1024) void k_screen_centre(const float *__re
 // B'_i, one Gaussian per thread; rows N .. nrows-1 (the padding of the last block) are zero -- their bits are masked.
 template <int DMAX>
 __global__ __launch_bounds__(BLOCK) void k_screen_prep_q(const float *__restrict__ qpar, int N, int nrows,
-                                                         const float *__restrict__ centre, unsigned short *__restrict__ B,
-                                                         float2 *__restrict__ bc)
+                                                         const float *__restrict__ centre, unsigned short *__restrict__ B)
 {
   constexpr int K = scr_k(DMAX);
   const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
   if (i >= nrows) return;
-  float2 bci = make_float2(-SCR_HUGE, 0.0f);  // (C'_i, |B_i| up) for the sum screen's epilogue; a row that excludes nothing
   unsigned short row[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) row[k] = 0;
@@ -136,15 +134,6 @@ __global__ __launch_bounds__(BLOCK) void k_screen_prep_q(const float *__restrict
       row[2 * DMAX + 1] = mid;
       row[2 * DMAX + 2] = scr_trunc(r2);
       row[2 * DMAX + 3] = scr_up((float)(nb * (1.0 + 1e-6)));
-      // the sum screen (k_screen_gemm_sums) takes the constant and the norm in fp32, outside the product: C'_i = a float at
-      // or below cf - up(176 (1 + 1e-4) + 1e-3) -- the chain's bound of a sum sweep is the same 176 for every chain
-      {
-        const double lc = (double)scr_val(scr_up(ZERO_ARG * (1.0f + 1e-4f) + 1e-3f));
-        const double want = (double)cf - lc;
-        float cd = (float)want;
-        if ((double)cd > want) cd = __uint_as_float(cd > 0.0f ? __float_as_uint(cd) - 1u : (cd < 0.0f ? __float_as_uint(cd) + 1u : 0x80000001u));
-        bci = make_float2(cd, scr_val(row[2 * DMAX + 3]));
-      }
     } else {
 #pragma unroll
       for (int k = 0; k < 2 * DMAX; ++k) row[k] = 0;
@@ -152,7 +141,6 @@ __global__ __launch_bounds__(BLOCK) void k_screen_prep_q(const float *__restrict
     }
     row[2 * DMAX + 4] = 0x3f80;  // 1: meets the chain's -L
   }
-  bc[i] = bci;
   uint4 *dst = reinterpret_cast<uint4 *>(B + (size_t)i * K);
 #pragma unroll
   for (int c = 0; c < K / 8; ++c) {
@@ -172,15 +160,13 @@ template <int DMAX, bool SUMS>
 __global__ __launch_bounds__(BLOCK) void k_screen_prep_x(const float *__restrict__ xrows, const int *__restrict__ order, int nact,
                                                          int nrows, const float *__restrict__ qpar, int own0,
                                                          const float *__restrict__ centre, unsigned short *__restrict__ A,
-                                                         float *__restrict__ stats_done, unsigned *__restrict__ hist_done,
-                                                         float *__restrict__ amax)
+                                                         float *__restrict__ stats_done, unsigned *__restrict__ hist_done)
 {
   constexpr int K = scr_k(DMAX);
   for (int i = (int)(blockIdx.x * BLOCK + threadIdx.x); i < CULL_BINS; i += (int)(gridDim.x * BLOCK)) hist_done[i] = 0u;
   if (blockIdx.x == 0 && threadIdx.x < 2 * CULL_KD) stats_done[threadIdx.x] = 0.0f;
   const int p = (int)(blockIdx.x * BLOCK + threadIdx.x);
-  if (p >= nrows) return;  // (nrows is a multiple of 128: whole wavefronts leave)
-  float sa = 0.0f;  // S |A_j| rounded up, as the product carries it: the sum screen takes its maximum over a tile of 32 rows
+  if (p >= nrows) return;
   unsigned short row[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) row[k] = 0;
@@ -210,23 +196,13 @@ __global__ __launch_bounds__(BLOCK) void k_screen_prep_x(const float *__restrict
     if (na < SCR_NORM_MAX && lim >= 0.0f) {
       row[2 * DMAX + 3] = (unsigned short)(scr_up((float)(SCR_S * na * (1.0 + 1e-6))) | 0x8000u);
       row[2 * DMAX + 4] = (unsigned short)(scr_up(lim * (1.0f + 1e-4f) + 1e-3f) | 0x8000u);
-      sa = scr_val((unsigned short)(row[2 * DMAX + 3] & 0x7fffu));
     } else {
 #pragma unroll
       for (int k = 0; k < 2 * DMAX; ++k) row[k] = 0;
       row[2 * DMAX + 4] = scr_trunc(-SCR_HUGE);  // this chain excludes nothing
-      sa = SCR_HUGE;                             // (nor does its tile, in the sum screen)
     }
   } else {
     row[2 * DMAX + 4] = scr_trunc(SCR_HUGE);
-  }
-  if (SUMS && amax) {  // the maximum over the tile of 32 rows = one half-wavefront
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) {
-      const float other = __shfl_xor(sa, o);
-      sa = other > sa ? other : sa;
-    }
-    if ((threadIdx.x & 31u) == 0u) amax[p >> 5] = sa;
   }
   uint4 *dst = reinterpret_cast<uint4 *>(A + (size_t)p * K);
 #pragma unroll
@@ -323,110 +299,6 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigne
       }
       const bool col_ok = b * SCR_BLK + ct * 32 + r < N;
       const unsigned long long bal = __ballot(col_ok && !(mn > 0.0f));  // both halves hold the same 32 Gaussians
-      m32[ct] = (unsigned)bal | (unsigned)(bal >> 32);
-    }
-    const unsigned long long w0 = (unsigned long long)m32[0] | ((unsigned long long)m32[1] << 32);
-    const unsigned long long w1 = (unsigned long long)m32[2] | ((unsigned long long)m32[3] << 32);
-    if (lane == 0) {
-      excl[(size_t)(2 * b) * ngroups + g] = w0;
-      if (2 * b + 1 < excl_words) excl[(size_t)(2 * b + 1) * ngroups + g] = w1;
-    }
-    kept += (unsigned long long)(__popcll(w0) + __popcll(w1)) * (unsigned long long)members;
-  }
-  if (lane == 0 && kept) atomicAdd(nkept + ((blockIdx.x * SCR_WAVES + wv + blockIdx.y) & (CULL_NCOUNT - 1)), kept);
-}
-
-// The SUM screen's own kernel (round 5).  A sum sweep's bound is the same 176 for every chain, so of the sixteen extra
-// products only one depends on the row at all: -up(S |A_j|) up(|B_i|).  Taken out of the product --
-//     arg(j, i) > 176  <=  C'_i + bf16(A_j) . bf16(B_i) - max_{j' in tile}(S |A_j'|) |B_i| > 0,    C'_i = c_i (1 - 2^-14) - 176'
-// with the maximum over the tile of 32 rows (chains next to each other in the sorted list: the bound loosens by the
-// spread of |A| inside a tile, a fraction of an allowance that is itself 2^-7 of |A| |B|) -- the product is K = 2 np:
-// two matrix instructions per tile at 16-D instead of three, four instead of five at 32-D, and the epilogue is the
-// minimum over the tile's accumulators, one multiply-add and one add per tile.  The constants are the very bf16 / fp32
-// values the K + 16 product carries (k_screen_prep_q / prep_x write them next to the rows); the two fp32 operations
-// outside the matrix core round like two of its K + 5 additions did.  The min-arg screen (a bound per chain) keeps the
-// K + 16 kernel.
-template <int DMAX>
-__global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm_sums(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
-                                                                     const float2 *__restrict__ bc, const float *__restrict__ amax,
-                                                                     int nact, int N, int ngroups, int bchunk,
-                                                                     unsigned long long *__restrict__ excl, int excl_words,
-                                                                     unsigned long long *__restrict__ nkept, int blk0, int blk1)
-{
-  constexpr int K = scr_k(DMAX), K2 = 2 * DMAX, KS = K2 / 16, ROWB = K2 * 2, LROW = ROWB + 16;
-  constexpr int NT = SCR_WAVES * 64, PIECES = ROWB / 16, CH = SCR_BLK * PIECES, PER = (CH + NT - 1) / NT;
-  static_assert(CH % NT == 0, "a block of Gaussians is a whole number of 16-byte pieces per thread");
-  __shared__ __attribute__((aligned(16))) unsigned char blds[SCR_BLK * LROW];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
-  const int r = lane & 31, h = lane >> 5;
-  const int g = (int)blockIdx.x * SCR_WAVES + wv;
-  const bool have_g = g < ngroups;
-  scr_bf16x8 a[4][KS];
-  float am[4];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-    am[rt] = have_g ? amax[(size_t)g * 4 + rt] : 0.0f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const size_t pos = (size_t)(have_g ? g : 0) * CULL_W + rt * 32 + r;
-      a[rt][s] = *reinterpret_cast<const scr_bf16x8 *>(A + pos * K + s * 16 + h * 8);
-    }
-  }
-  const int nblk = blk1;
-  const int b0 = blk0 + (int)blockIdx.y * bchunk, b1 = b0 + bchunk < nblk ? b0 + bchunk : nblk;
-  if (b0 >= b1) return;  // (the whole workgroup)
-  // piece c of a block: row c / PIECES, 16 bytes c % PIECES of its first 2 np columns (the row's stride is K)
-  auto piece = [&](int b, int c) {
-    return reinterpret_cast<const scr_u32x4 *>(B + ((size_t)b * SCR_BLK + c / PIECES) * K)[c % PIECES];
-  };
-  scr_u32x4 hold[PER];
-#pragma unroll
-  for (int u = 0; u < PER; ++u) hold[u] = piece(b0, (int)threadIdx.x + u * NT);
-  const int members = have_g ? (nact - g * CULL_W < CULL_W ? nact - g * CULL_W : CULL_W) : 0;
-  unsigned long long kept = 0;
-  for (int b = b0; b < b1; ++b) {
-    __syncthreads();  // the previous block has been consumed
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int c = (int)threadIdx.x + u * NT;
-      *reinterpret_cast<scr_u32x4 *>(blds + (c / PIECES) * LROW + (c % PIECES) * 16) = hold[u];
-    }
-    __syncthreads();
-    {  // the next block on its way while this one is multiplied (unconditional: the last block once more)
-      const int bn = b + 1 < b1 ? b + 1 : b;
-#pragma unroll
-      for (int u = 0; u < PER; ++u) hold[u] = piece(bn, (int)threadIdx.x + u * NT);
-    }
-    if (!have_g) continue;
-    unsigned m32[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const int col = b * SCR_BLK + ct * 32 + r;
-      const float2 cn = bc[col];  // (B and bc have a whole number of blocks: always in range)
-      scr_bf16x8 bf[KS];
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-        bf[s] = *reinterpret_cast<const scr_bf16x8 *>(blds + (ct * 32 + r) * LROW + (s * 16 + h * 8) * 2);
-      float mn = __builtin_inff();
-      auto tile_min = [](const scr_f32x16 &acc) {
-        const float m0 = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
-        const float m1 = __builtin_fminf(__builtin_fminf(acc[3], acc[4]), acc[5]);
-        const float m2 = __builtin_fminf(__builtin_fminf(acc[6], acc[7]), acc[8]);
-        const float m3 = __builtin_fminf(__builtin_fminf(acc[9], acc[10]), acc[11]);
-        const float m4 = __builtin_fminf(__builtin_fminf(acc[12], acc[13]), acc[14]);
-        const float m5 = __builtin_fminf(__builtin_fminf(m0, m1), acc[15]);
-        const float m6 = __builtin_fminf(__builtin_fminf(m2, m3), m4);
-        return __builtin_fminf(m5, m6);
-      };
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        scr_f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][s], bf[s], acc, 0, 0, 0);
-        mn = __builtin_fminf(mn, __builtin_fmaf(-am[rt], cn.y, tile_min(acc)));  // (this half-wavefront's 16 rows of the tile)
-      }
-      const bool col_ok = col < N;
-      const unsigned long long bal = __ballot(col_ok && !(mn + cn.x > 0.0f));  // both halves hold the same 32 Gaussians
       m32[ct] = (unsigned)bal | (unsigned)(bal >> 32);
     }
     const unsigned long long w0 = (unsigned long long)m32[0] | ((unsigned long long)m32[1] << 32);
