@@ -162,23 +162,12 @@ struct ScreenLaunch {
   unsigned long long *nkept = nullptr;
 };
 
-// MCX_SCREEN_ONE_BUFFER=1 (measurement only): the screen's kernel with one LDS buffer and two barriers per block, as in round 4
-static bool screen_double_buffered()
-{
-  static const bool one = getenv("MCX_SCREEN_ONE_BUFFER") && atoi(getenv("MCX_SCREEN_ONE_BUFFER")) != 0;
-  return !one;
-}
-
 template <int DMAX>
 static void screen_gemm_go(mcx_engine *e, const ScreenLaunch &L, int blk0, int blk1, hipStream_t st)
 {
-  const dim3 grid((unsigned)L.gx, (unsigned)((blk1 - blk0 + L.bchunk - 1) / L.bchunk));
-  if (screen_double_buffered())
-    hipLaunchKernelGGL((k_screen_gemm<DMAX, true>), grid, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)e->scr_a.p,
-                       (const unsigned short *)e->scr_b.p, L.nact, L.N, L.ng, L.bchunk, e->cull_excl.p, L.nw, L.nkept, blk0, blk1);
-  else
-    hipLaunchKernelGGL((k_screen_gemm<DMAX, false>), grid, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)e->scr_a.p,
-                       (const unsigned short *)e->scr_b.p, L.nact, L.N, L.ng, L.bchunk, e->cull_excl.p, L.nw, L.nkept, blk0, blk1);
+  hipLaunchKernelGGL((k_screen_gemm<DMAX>), dim3((unsigned)L.gx, (unsigned)((blk1 - blk0 + L.bchunk - 1) / L.bchunk)), dim3(SCR_WAVES * 64), 0, st,
+                     (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, L.nact, L.N, L.ng, L.bchunk, e->cull_excl.p, L.nw,
+                     L.nkept, blk0, blk1);
 }
 
 template <int DMAX>
@@ -219,7 +208,7 @@ static int screen_prepare(mcx_engine *e, const float *xrows, const int *ain, int
   static std::atomic<int> blocks_per_cu{0};  // (per instantiation; engines on several threads may ask at once: the same answer)
   int nb = blocks_per_cu.load(std::memory_order_relaxed);
   if (!nb) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_screen_gemm<DMAX, true>, SCR_WAVES * 64, 0) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_screen_gemm<DMAX>, SCR_WAVES * 64, 0) != hipSuccess || nb < 1) nb = 2;
     blocks_per_cu.store(nb, std::memory_order_relaxed);
   }
   const int resident = nb * (e->ncu > 0 ? e->ncu : 256);

@@ -218,9 +218,7 @@ __global__ __launch_bounds__(BLOCK) void k_screen_prep_x(const float *__restrict
 
 // excl[w][g] bit b = Q_{64 w + b} may matter to group g (the layout of k_cull_test).  Workgroup = SCR_WAVES groups x
 // `bchunk` blocks of SCR_BLK Gaussians.  A has 128 ngroups rows, B a whole number of blocks.
-// DB: two LDS buffers in turn -- block b + 1 is written while block b is multiplied, ONE barrier per block instead of two
-// (the sum screen's K = 2 np experiment showed the kernel is not bound by the matrix pipe alone: EXPERIMENTS.md).
-template <int DMAX, bool DB = true>
+template <int DMAX>
 __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
                                                                 int nact, int N, int ngroups, int bchunk,
                                                                 unsigned long long *__restrict__ excl, int excl_words,
@@ -229,8 +227,7 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigne
   constexpr int K = scr_k(DMAX), KS = K / 16, ROWB = K * 2, LROW = ROWB + 16;
   constexpr int NT = SCR_WAVES * 64, CH = SCR_BLK * ROWB / 16, PER = (CH + NT - 1) / NT;
   static_assert(CH % NT == 0, "a block of Gaussians is a whole number of 16-byte pieces per thread");
-  constexpr int BUFB = SCR_BLK * LROW;
-  __shared__ __attribute__((aligned(16))) unsigned char blds_all[(DB ? 2 : 1) * BUFB];
+  __shared__ __attribute__((aligned(16))) unsigned char blds[SCR_BLK * LROW];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
   const int r = lane & 31, h = lane >> 5;
   const int g = (int)blockIdx.x * SCR_WAVES + wv;
@@ -256,33 +253,18 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigne
   }
   const int members = have_g ? (nact - g * CULL_W < CULL_W ? nact - g * CULL_W : CULL_W) : 0;
   unsigned long long kept = 0;
-  auto to_lds = [&](unsigned char *buf) {
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();  // the previous block has been consumed
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int c = (int)threadIdx.x + u * NT;  // piece c of the block: row c / (K/8), piece c % (K/8) of it
-      *reinterpret_cast<scr_u32x4 *>(buf + (c / (K / 8)) * LROW + (c % (K / 8)) * 16) = hold[u];
+      *reinterpret_cast<scr_u32x4 *>(blds + (c / (K / 8)) * LROW + (c % (K / 8)) * 16) = hold[u];
     }
-  };
-  auto request = [&](int bn) {  // block bn (clamped to the chunk's last: an unconditional load) on its way from memory
-    const scr_u32x4 *src = reinterpret_cast<const scr_u32x4 *>(B + (size_t)(bn < b1 ? bn : b1 - 1) * SCR_BLK * K);
+    __syncthreads();
+    {  // the next block on its way while this one is multiplied (unconditional: the last block once more)
+      const scr_u32x4 *src = reinterpret_cast<const scr_u32x4 *>(B + (size_t)(b + 1 < b1 ? b + 1 : b) * SCR_BLK * K);
 #pragma unroll
-    for (int u = 0; u < PER; ++u) hold[u] = src[(int)threadIdx.x + u * NT];
-  };
-  if (DB) {  // block b0 into buffer 0, block b0 + 1 requested
-    to_lds(blds_all);
-    request(b0 + 1);
-  }
-  for (int b = b0; b < b1; ++b) {
-    unsigned char *blds = blds_all + (DB ? ((b - b0) & 1) * BUFB : 0);
-    if (DB) {
-      __syncthreads();  // block b is in its buffer, and everybody is done with the other one (block b - 1)
-      to_lds(blds_all + (((b - b0) & 1) ^ 1) * BUFB);  // block b + 1 (the chunk's last block once more: never read)
-      request(b + 2);
-    } else {
-      __syncthreads();  // the previous block has been consumed
-      to_lds(blds);
-      __syncthreads();
-      request(b + 1);   // the next block on its way while this one is multiplied
+      for (int u = 0; u < PER; ++u) hold[u] = src[(int)threadIdx.x + u * NT];
     }
     if (!have_g) continue;
     unsigned m32[4];
