@@ -162,24 +162,12 @@ struct ScreenLaunch {
   unsigned long long *nkept = nullptr;
 };
 
-// MCX_SCREEN_NACC=1|2|4 (measurement only): row tiles multiplied at a time, on as many accumulators
-static int screen_nacc()
-{
-  static const int n = getenv("MCX_SCREEN_NACC") ? atoi(getenv("MCX_SCREEN_NACC")) : 1;
-  return n;
-}
-
 template <int DMAX>
 static void screen_gemm_go(mcx_engine *e, const ScreenLaunch &L, int blk0, int blk1, hipStream_t st)
 {
-  const dim3 grid((unsigned)L.gx, (unsigned)((blk1 - blk0 + L.bchunk - 1) / L.bchunk));
-#define GO(NA) hipLaunchKernelGGL((k_screen_gemm<DMAX, NA>), grid, dim3(SCR_WAVES * 64), 0, st, (const unsigned short *)e->scr_a.p, \
-                                  (const unsigned short *)e->scr_b.p, L.nact, L.N, L.ng, L.bchunk, e->cull_excl.p, L.nw, L.nkept, blk0, blk1)
-  const int na = screen_nacc();
-  if (na == 4) GO(4);
-  else if (na == 2) GO(2);
-  else GO(1);
-#undef GO
+  hipLaunchKernelGGL((k_screen_gemm<DMAX>), dim3((unsigned)L.gx, (unsigned)((blk1 - blk0 + L.bchunk - 1) / L.bchunk)), dim3(SCR_WAVES * 64), 0, st,
+                     (const unsigned short *)e->scr_a.p, (const unsigned short *)e->scr_b.p, L.nact, L.N, L.ng, L.bchunk, e->cull_excl.p, L.nw,
+                     L.nkept, blk0, blk1);
 }
 
 template <int DMAX>

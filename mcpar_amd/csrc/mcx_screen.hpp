@@ -218,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) void k_screen_prep_x(const float *__restrict
 
 // excl[w][g] bit b = Q_{64 w + b} may matter to group g (the layout of k_cull_test).  Workgroup = SCR_WAVES groups x
 // `bchunk` blocks of SCR_BLK Gaussians.  A has 128 ngroups rows, B a whole number of blocks.
-template <int DMAX, int NACC = 1>
+template <int DMAX>
 __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigned short *__restrict__ A, const unsigned short *__restrict__ B,
                                                                 int nact, int N, int ngroups, int bchunk,
                                                                 unsigned long long *__restrict__ excl, int excl_words,
@@ -290,28 +290,12 @@ __global__ __launch_bounds__(SCR_WAVES * 64, 2) void k_screen_gemm(const unsigne
       // two accumulators (32-D +3 %, 16-D spills at five wavefronts per SIMD), s_setprio around the products, five
       // wavefronts per SIMD instead of four, grids of exactly one to four chipfuls of workgroups: the matrix cores stay
       // 65 % busy, SQ_VALU_MFMA_BUSY_CYCLES)
-      if (NACC == 1) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          scr_f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      for (int rt = 0; rt < 4; ++rt) {
+        scr_f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][s], bf[s], acc, 0, 0, 0);
-          mn = __builtin_fminf(mn, tile_min(acc));
-        }
-      } else {  // NACC row tiles at a time, their chains of matrix instructions interleaved
-#pragma unroll
-        for (int r0 = 0; r0 < 4; r0 += NACC) {
-          scr_f32x16 acc[NACC];
-#pragma unroll
-          for (int u = 0; u < NACC; ++u)
-            acc[u] = scr_f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int u = 0; u < NACC; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r0 + u][s], bf[s], acc[u], 0, 0, 0);
-#pragma unroll
-          for (int u = 0; u < NACC; ++u) mn = __builtin_fminf(mn, tile_min(acc[u]));
-        }
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][s], bf[s], acc, 0, 0, 0);
+        mn = __builtin_fminf(mn, tile_min(acc));
       }
       const bool col_ok = b * SCR_BLK + ct * 32 + r < N;
       const unsigned long long bal = __ballot(col_ok && !(mn > 0.0f));  // both halves hold the same 32 Gaussians
