@@ -10,6 +10,7 @@
 // chain) for the life of the process.
 #include "mcx_engine_internal.hpp"
 
+#include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -237,6 +238,12 @@ int user_lik_get(const char *source, int np, std::shared_ptr<UserLik> *out)
   u->compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("MCX_VERBOSE"))
     fprintf(stderr, "mcx: user likelihood compiled for %d lanes per chain in %.0f ms (%zu bytes of code)\n", lpc, u->compile_ms, code.size());
+  // (a host that writes its constants into the text instead of `par` makes a new entry per value: beyond 64 entries
+  // the ones no engine holds any more are let go, modules and all)
+  size_t cache_max = 64;
+  if (const char *cm = getenv("MCX_USER_CACHE_MAX")) cache_max = (size_t)std::max(1L, atol(cm));  // (tests)
+  if (g_user_cache.size() >= cache_max)
+    for (auto c = g_user_cache.begin(); c != g_user_cache.end();) c = c->second.use_count() == 1 ? g_user_cache.erase(c) : std::next(c);
   g_user_cache[key] = u;
   *out = u;
   return MCX_OK;

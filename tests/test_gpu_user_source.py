@@ -230,3 +230,37 @@ def test_block_form_source_takes_the_one_launch_small_n_kernel(d, n):
     assert ew.counters["small_n_launches"] == 0
     for e in (eg, eb, ew, eo, eo2):
         e.close()
+
+
+def test_the_cache_of_compiled_sources_lets_go_of_unused_entries(monkeypatch):
+    """Code objects are cached per (device, np, text).  A host that writes constants into the text makes an entry per value:
+    past the cap, entries no engine holds are unloaded -- and a text seen again simply compiles again, same bits."""
+    import mcpar_amd as M
+    monkeypatch.setenv("MCX_USER_CACHE_MAX", "2")
+    d, n = 8, 256
+    p = O.default_pinit(d, n)
+    base = src("user_rosenbrock1_blocks.hip")
+    states = []
+    for k in (0, 1, 2, 3, 0):
+        vg, _k = M.make_vlfunc(M.VL_SOURCE, d, source=base + "\n// variant %d\n" % k)
+        eg = M.Engine(d, n, pl=1.0)
+        eg.run(30, 60, p, vg)
+        states.append(eg.state.copy())
+        eg.close()
+    for s in states[1:]:
+        assert same_bits(s, states[0])
+    # an entry an engine still holds survives the sweep: the engine keeps running on it
+    va, _k = M.make_vlfunc(M.VL_SOURCE, d, source=base + "\n// held\n")
+    ea = M.Engine(d, n, pl=1.0)
+    vb, _k = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eb = M.Engine(d, n, pl=1.0)
+    ea.run(30, 60, p, va); eb.run(30, 60, p, vb)
+    assert same_bits(ea.state, states[0]) and same_bits(eb.state, states[0])
+    for k in (10, 11, 12):
+        vg, _k = M.make_vlfunc(M.VL_SOURCE, d, source=base + "\n// variant %d\n" % k)
+        eg = M.Engine(d, n, pl=1.0)
+        eg.run(5, 0, p, vg)
+        eg.close()
+    ea.run(30, 60, p, va); eb.run(30, 60, p, vb)  # (a second run draws on: compared with the built-in's second run)
+    assert same_bits(ea.state, eb.state)
+    ea.close(); eb.close()
