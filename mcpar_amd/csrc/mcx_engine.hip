@@ -778,17 +778,25 @@ static void never_leave_the_lock_behind(mcx_engine *e, int rc)
   e->meet_check = false;
 }
 
-// the books of a run that was queued asynchronously and never looked at (the next run was queued behind it): was one of
-// its meetings abandoned?  Nobody saw its results -- nothing to repeat -- but the engine keeps to the per-segment kernels
-static void note_superseded(mcx_engine *e)
+// the books of runs that were queued asynchronously and never looked at (the next run was queued behind them): was one of
+// their meetings abandoned?  Nobody saw their results -- nothing to repeat -- but the engine keeps to the per-segment kernels.
+// all = every such run's counters have arrived (the caller waited for a later copy on the same stream); otherwise only those
+// whose copy is over are looked at, the others next time
+static void note_superseded(mcx_engine *e, bool all)
 {
-  if (!e->superseded_hctr) return;
-  if (e->superseded_hctr[5] != 0) {
-    e->persist_broken = true;
-    e->runs_since_broken = 0;
-    e->meet_total++;
+  for (int sl = 0; sl < mcx_engine::HSLOTS && e->superseded_mask; ++sl) {
+    if (!(e->superseded_mask & (1u << sl))) continue;
+    if (!all && e->copy_pending[sl]) {
+      if (hipEventQuery(e->copy_ev[sl]) != hipSuccess) { (void)hipGetLastError(); continue; }
+      e->copy_pending[sl] = false;
+    }
+    if (e->h_ctr.p[8 * sl + 5] != 0) {
+      e->persist_broken = true;
+      e->runs_since_broken = 0;
+      e->meet_total++;
+    }
+    e->superseded_mask &= ~(1u << sl);
   }
-  e->superseded_hctr = nullptr;
 }
 
 // MCX_OPT_ASYNC_RUN: the end of the run that mcx_run queued and returned from.  Called by every entry point but mcx_run
@@ -800,11 +808,13 @@ int finish_pending(mcx_engine *e)
   e->pend.active = false;
   hipError_t se = hipStreamSynchronize(e->stream);
   if (se == hipSuccess && e->copy_pending[p.slot]) se = hipEventSynchronize(e->copy_ev[p.slot]);  // (its counters: a stream of their own)
-  e->copy_pending[p.slot] = false;
+  if (se == hipSuccess)  // (the copies leave in order: every earlier run's counters are in as well)
+    for (bool &cp : e->copy_pending) cp = false;
+  for (bool &rq : e->run_queued) rq = false;
   const bool abandoned = p.meet_check && se == hipSuccess && p.hctr[5] != 0;
   e->meet_check = false;
   (void)meet_release(e, true);
-  note_superseded(e);
+  if (se == hipSuccess) note_superseded(e, true);
   HIPCHK(se);
   int rc = MCX_OK;
   if (abandoned) {
@@ -830,14 +840,18 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
     // of back-to-back small jobs overlap the jobs themselves); its counters are looked at later, for the books only.
     if (e->opt_async_run && hipStreamQuery(e->stream) == hipErrorNotReady) {
       (void)hipGetLastError();
-      // at most TWO runs in flight: the one before the pending one must be over before this call reuses its counter slot
-      // (the host queues a small job in 15 us, the GPU takes 400: without a bound the queue would only grow)
-      if (e->copy_pending[e->hctr_slot ^ 1]) {  // (its counters' copy runs behind it: over = both over)
-        HIPCHK(hipEventSynchronize(e->copy_ev[e->hctr_slot ^ 1]));
-        e->copy_pending[e->hctr_slot ^ 1] = false;
+      // at most TWO runs in flight: the one before the pending one must be over before this call queues another
+      // (the host queues a small job in 15 us, the GPU takes 400: without a bound the queue would only grow).  Its KERNELS,
+      // not its counters: their copy -- a kernel of the runtime's on the other stream -- gets no room beside the pending
+      // run's grid and ends with it; waiting for it let the queue run dry after every second job (24 us between two jobs
+      // where 7 is the dispatch alone, tools/queued_jobs_probe.py)
+      const int before = (e->hctr_slot + mcx_engine::HSLOTS - 1) % mcx_engine::HSLOTS;
+      if (e->run_queued[before]) {
+        HIPCHK(hipEventSynchronize(e->run_ev[before]));
+        e->run_queued[before] = false;
       }
-      note_superseded(e);
-      e->superseded_hctr = e->pend.meet_check ? e->pend.hctr : nullptr;
+      note_superseded(e, false);
+      if (e->pend.meet_check) e->superseded_mask |= 1u << e->pend.slot;
       e->pend.active = false;
     } else {
       (void)hipGetLastError();
@@ -967,7 +981,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   // this run's counter block: a ring, zeroed as a whole when it wraps
   e->ctr_set = (e->ctr_set + 1) % CTR_RING;
   if (e->ctr_set == 0) {
-    for (int sl = 0; sl < 2; ++sl)  // (an asynchronous run's counters may still be on their way out of the ring)
+    for (int sl = 0; sl < mcx_engine::HSLOTS; ++sl)  // (an asynchronous run's counters may still be on their way out of the ring)
       if (e->copy_pending[sl]) HIPCHK(hipStreamWaitEvent(st, e->copy_ev[sl], 0));
     HIPCHK(hipMemsetAsync(e->ctr.p, 0, (size_t)CTR_WORDS * CTR_RING * sizeof(unsigned long long), st));
   }
@@ -1298,8 +1312,14 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, ctrp + 4);
     HIPCHK(hipGetLastError());
   }
-  MCXCHK(e->h_ctr.alloc(16));  // pinned: the copy queues behind the last kernel instead of staging through the runtime;
-  e->hctr_slot ^= 1;           // two slots in turn (MCX_OPT_ASYNC_RUN: the previous run's may not have been read yet)
+  MCXCHK(e->h_ctr.alloc(8 * mcx_engine::HSLOTS));  // pinned: the copy queues behind the last kernel instead of staging through the runtime;
+  e->hctr_slot = (e->hctr_slot + 1) % mcx_engine::HSLOTS;  // slots in turn (MCX_OPT_ASYNC_RUN: earlier runs' may not have been read yet)
+  if (e->copy_pending[e->hctr_slot]) {  // four runs back: long over
+    HIPCHK(hipEventSynchronize(e->copy_ev[e->hctr_slot]));
+    e->copy_pending[e->hctr_slot] = false;
+  }
+  if (e->superseded_mask & (1u << e->hctr_slot)) note_superseded(e, false);  // (its word, before the slot is written again)
+  e->run_queued[e->hctr_slot] = false;
   unsigned long long *hctr = e->h_ctr.p + 8 * e->hctr_slot;
   MCXCHK(cov_reset(e));  // (a run without any step)
   // MCX_OPT_ASYNC_RUN: everything is queued -- return.  Only runs whose end needs nothing from the host: one shard, no
@@ -1319,6 +1339,7 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     if (!e->run_ev[sl]) HIPCHK(hipEventCreateWithFlags(&e->run_ev[sl], hipEventDisableTiming));
     if (!e->copy_ev[sl]) HIPCHK(hipEventCreateWithFlags(&e->copy_ev[sl], hipEventDisableTiming));
     HIPCHK(hipEventRecord(e->run_ev[sl], st));
+    e->run_queued[sl] = true;
     HIPCHK(hipStreamWaitEvent(e->astream, e->run_ev[sl], 0));
     HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->astream));
     HIPCHK(hipEventRecord(e->copy_ev[sl], e->astream));

@@ -292,12 +292,17 @@ struct mcx_engine {
     int slot = 0;                        // its counter slot / events
   } pend;
   hipStream_t astream = nullptr;         // an asynchronous run's counters travel on it, beside the next run's kernels
-  hipEvent_t copy_ev[2] = {nullptr, nullptr};
-  bool copy_pending[2] = {false, false};
-  unsigned long long *superseded_hctr = nullptr;  // a run nobody looked at before the next was queued: its counters, for the books only
+  // Counter slots in pinned memory, one per run in turn.  FOUR: run k is queued once run k-2's kernels are over (two in flight),
+  // run k-2's counters may leave only when run k-1 ends (their copy kernel finds no room beside a grid that fills the device),
+  // and run k-3's are what the books look at meanwhile.
+  static constexpr int HSLOTS = 4;
+  hipEvent_t copy_ev[HSLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  bool copy_pending[HSLOTS] = {false, false, false, false};
+  unsigned superseded_mask = 0;  // slots of runs nobody looked at before the next was queued (and that had tuner meetings): for the books only
   DevBuf<float> pinit_async;
   int hctr_slot = 0;
-  hipEvent_t run_ev[2] = {nullptr, nullptr};  // recorded behind each asynchronous run's last command, by counter slot
+  hipEvent_t run_ev[HSLOTS] = {nullptr, nullptr, nullptr, nullptr};  // recorded behind each asynchronous run's last command, by counter slot
+  bool run_queued[HSLOTS] = {false, false, false, false};
   hipStream_t mstream = nullptr;   // Murray passes by column chunks: the sweeps' stream (mcx_murray.hip: screen_sweep_chunked)
   std::vector<hipEvent_t> mev;
   int opt_murray_overlap = 0;
