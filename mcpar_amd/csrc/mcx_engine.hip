@@ -341,7 +341,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   A(e->musigall.alloc(2 * (size_t)e->tchains * np)); A(e->winvall.alloc(2 * (size_t)e->tchains * np));
   A(e->lylast.alloc(n)); A(e->lytrial.alloc(n)); A(e->cfac.alloc(n)); A(e->cmax.alloc(n));
   A(e->cov.alloc((size_t)e->ncov)); A(e->cov0.alloc((size_t)e->ncov)); A(e->trace.alloc(256)); A(e->acc_cnt.alloc(n));
-  A(e->ctr.alloc((size_t)CTR_WORDS * CTR_RING));
+  A(e->ctr.alloc((size_t)CTR_WORDS * CTR_RING + 2));  // (+ RunArgs::report_done, behind the ring)
   e->nslots = (int)(((size_t)nc * e->lpc + 63) / 64);
   A(e->acc_slots.alloc((size_t)e->nslots));
   A(e->tun_cells.alloc(TUN_CELLS + 1));
@@ -366,7 +366,7 @@ extern "C" int mcx_create(mcx_engine **out, int np, int nc, int nshards, int sha
   (void)hipMemcpyAsync(e->cov.p, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice, e->stream);
   (void)hipMemcpyAsync(e->cov0.p, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice, e->stream);
   e->h_cov_dev = eye;
-  (void)hipMemsetAsync(e->ctr.p, 0, (size_t)CTR_WORDS * CTR_RING * sizeof(unsigned long long), e->stream);
+  (void)hipMemsetAsync(e->ctr.p, 0, ((size_t)CTR_WORDS * CTR_RING + 2) * sizeof(unsigned long long), e->stream);
   if (hipStreamSynchronize(e->stream) != hipSuccess) {
     mcx_destroy(e);
     return fail(MCX_ERR_HIP, "engine initialisation failed");
@@ -476,6 +476,7 @@ extern "C" int mcx_set_option(mcx_engine *e, int opt, int64_t value)
     break;
   case MCX_OPT_ASYNC_RUN: e->opt_async_run = value ? 1 : 0; break;
   case MCX_OPT_REFERENCE_CALLS: e->opt_reference_calls = value ? 1 : 0; break;
+  case MCX_OPT_SELF_REPORT: e->opt_self_report = value ? 1 : 0; break;
   case MCX_OPT_MURRAY_OVERLAP:
     if (value < 0 || value > 64) return fail(MCX_ERR_INVALID, "MURRAY_OVERLAP: 0 (off) or the number of column chunks, <= 64");
     e->opt_murray_overlap = (int)value;
@@ -778,6 +779,20 @@ static void never_leave_the_lock_behind(mcx_engine *e, int rc)
   e->meet_check = false;
 }
 
+// A run whose last launch reports to its counter slot itself (RunArgs::report): has the serial number arrived?  Spins for
+// at most `spin_us` -- jobs this is about take 0.3-0.5 ms; whoever waits for a longer one loses nothing by sleeping in
+// hipStreamSynchronize instead -- and says whether it saw it.
+static bool report_arrived(const unsigned long long *slot, unsigned long long serial, int spin_us)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int it = 0;; ++it) {
+    if (__atomic_load_n(slot + 7, __ATOMIC_ACQUIRE) == serial) return true;
+    if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) return false;
+    __builtin_ia32_pause();
+  }
+}
+constexpr int REPORT_SPIN_US = 1500;
+
 // the books of runs that were queued asynchronously and never looked at (the next run was queued behind them): was one of
 // their meetings abandoned?  Nobody saw their results -- nothing to repeat -- but the engine keeps to the per-segment kernels.
 // all = every such run's counters have arrived (the caller waited for a later copy on the same stream); otherwise only those
@@ -786,7 +801,9 @@ static void note_superseded(mcx_engine *e, bool all)
 {
   for (int sl = 0; sl < mcx_engine::HSLOTS && e->superseded_mask; ++sl) {
     if (!(e->superseded_mask & (1u << sl))) continue;
-    if (!all && e->copy_pending[sl]) {
+    if (!all && e->slot_serial[sl]) {  // (it reports itself)
+      if (__atomic_load_n(e->h_ctr.p + 8 * sl + 7, __ATOMIC_ACQUIRE) != e->slot_serial[sl]) continue;
+    } else if (!all && e->copy_pending[sl]) {
       if (hipEventQuery(e->copy_ev[sl]) != hipSuccess) { (void)hipGetLastError(); continue; }
       e->copy_pending[sl] = false;
     }
@@ -806,7 +823,10 @@ int finish_pending(mcx_engine *e)
   if (!e->pend.active) return MCX_OK;
   const mcx_engine::PendingRun p = e->pend;
   e->pend.active = false;
-  hipError_t se = hipStreamSynchronize(e->stream);
+  hipError_t se = hipSuccess;
+  if (!(p.serial && report_arrived(p.hctr, p.serial, REPORT_SPIN_US))) se = hipStreamSynchronize(e->stream);
+  if (se == hipSuccess && p.serial && __atomic_load_n(p.hctr + 7, __ATOMIC_ACQUIRE) != p.serial)
+    return fail(MCX_ERR_HIP, "internal: the run's last launch is over and has not reported");
   if (se == hipSuccess && e->copy_pending[p.slot]) se = hipEventSynchronize(e->copy_ev[p.slot]);  // (its counters: a stream of their own)
   if (se == hipSuccess)  // (the copies leave in order: every earlier run's counters are in as well)
     for (bool &cp : e->copy_pending) cp = false;
@@ -847,7 +867,14 @@ extern "C" int mcx_run(mcx_engine *e, int nsamp, int nburn, const float *pinit, 
       // where 7 is the dispatch alone, tools/queued_jobs_probe.py)
       const int before = (e->hctr_slot + mcx_engine::HSLOTS - 1) % mcx_engine::HSLOTS;
       if (e->run_queued[before]) {
-        HIPCHK(hipEventSynchronize(e->run_ev[before]));
+        if (e->slot_serial[before]) {  // (it reports itself: no event behind it)
+          if (!report_arrived(e->h_ctr.p + 8 * before, e->slot_serial[before], REPORT_SPIN_US)) {
+            HIPCHK(hipStreamSynchronize(e->stream));  // a long job: no hurry then
+            (void)hipGetLastError();
+          }
+        } else {
+          HIPCHK(hipEventSynchronize(e->run_ev[before]));
+        }
         e->run_queued[before] = false;
       }
       note_superseded(e, false);
@@ -986,6 +1013,23 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     HIPCHK(hipMemsetAsync(e->ctr.p, 0, (size_t)CTR_WORDS * CTR_RING * sizeof(unsigned long long), st));
   }
   unsigned long long *const ctrp = e->ctr.p + (size_t)e->ctr_set * CTR_WORDS;
+  // ... and its slot of the pinned ring the counters end in (slots in turn: with MCX_OPT_ASYNC_RUN earlier runs' may not
+  // have been read yet)
+  if (!e->h_ctr.p) {
+    MCXCHK(e->h_ctr.alloc(8 * mcx_engine::HSLOTS));  // pinned: the copy queues behind the last kernel instead of staging through the runtime
+    memset(e->h_ctr.p, 0, 8 * mcx_engine::HSLOTS * sizeof(unsigned long long));
+  }
+  e->hctr_slot = (e->hctr_slot + 1) % mcx_engine::HSLOTS;
+  if (e->copy_pending[e->hctr_slot]) {  // four runs back: long over
+    HIPCHK(hipEventSynchronize(e->copy_ev[e->hctr_slot]));
+    e->copy_pending[e->hctr_slot] = false;
+  }
+  if (e->superseded_mask & (1u << e->hctr_slot)) note_superseded(e, false);  // (its word, before the slot is written again)
+  e->superseded_mask &= ~(1u << e->hctr_slot);
+  e->run_queued[e->hctr_slot] = false;
+  e->slot_serial[e->hctr_slot] = 0;
+  unsigned long long *const hctr = e->h_ctr.p + 8 * e->hctr_slot;
+  unsigned long long reported = 0;  // serial of the launch that reports the run's end itself (RunArgs::report), if one does
   // pinit is pageable caller memory: the runtime stages it before hipMemcpyAsync returns
   if (pinit) HIPCHK(hipMemcpyAsync(e->pvals.p, pinit, (size_t)e->ntot * sizeof(float), hipMemcpyHostToDevice, st));  // :47-50
   if (!lead) {
@@ -1124,6 +1168,18 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
         }
         ra.meet_timeout = (unsigned long long)e->opt_meet_timeout_ms * 100000ull;  // s_memrealtime: 100 MHz
         ra.meet_expect_extra = e->opt_debug_meet;
+        // the launch that ends the run -- nothing of the plan left, variances and slot written by itself, accept counts its
+        // own -- also tells the host: no counters' copy behind it
+        ra.report = nullptr; ra.report_done = nullptr; ra.report_serial = 0;
+        bool plan_over = true;  // (what is left of the plan: the slot's final publish, which the launch does itself / of no step)
+        for (size_t pk = pj; pk < plan.size(); ++pk) plan_over = plan_over && plan[pk].kind == MCX_PLAN_PUBLISH && plan[pk].first == nsamp;
+        if (e->opt_self_report && plan_over && (ra.final_publish || nsamp == 0) && !slots_used && !sink && !e->ofn &&
+            !e->opt_profile && e->size == 1) {
+          reported = ++e->report_serial;
+          ra.report = hctr;
+          ra.report_done = reinterpret_cast<unsigned *>(e->ctr.p + (size_t)CTR_WORDS * CTR_RING);
+          ra.report_serial = reported;
+        }
         if (snap >= 0) {  // the kernel rewrites this shard's slot: no gather may still be reading it
           MCXCHK(exchange_wait(e));
           e->published_steps = is0 + snap + 1;
@@ -1312,15 +1368,6 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     hipLaunchKernelGGL(k_reduce_slots, dim3(1), dim3(BLOCK), 0, st, e->acc_slots.p, e->nslots, ctrp + 4);
     HIPCHK(hipGetLastError());
   }
-  MCXCHK(e->h_ctr.alloc(8 * mcx_engine::HSLOTS));  // pinned: the copy queues behind the last kernel instead of staging through the runtime;
-  e->hctr_slot = (e->hctr_slot + 1) % mcx_engine::HSLOTS;  // slots in turn (MCX_OPT_ASYNC_RUN: earlier runs' may not have been read yet)
-  if (e->copy_pending[e->hctr_slot]) {  // four runs back: long over
-    HIPCHK(hipEventSynchronize(e->copy_ev[e->hctr_slot]));
-    e->copy_pending[e->hctr_slot] = false;
-  }
-  if (e->superseded_mask & (1u << e->hctr_slot)) note_superseded(e, false);  // (its word, before the slot is written again)
-  e->run_queued[e->hctr_slot] = false;
-  unsigned long long *hctr = e->h_ctr.p + 8 * e->hctr_slot;
   MCXCHK(cov_reset(e));  // (a run without any step)
   // MCX_OPT_ASYNC_RUN: everything is queued -- return.  Only runs whose end needs nothing from the host: one shard, no
   // sink / output hook / host likelihood, no Murray step (a pass waits for its survivors' count), no profiling.
@@ -1335,30 +1382,42 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
     // the counters' way to the host on a stream of its own, behind an event: on the step stream the copy would sit between
     // this run's last kernel and the next run's first one (5-8 us of every queued job)
     const int sl = e->hctr_slot;
-    if (!e->astream) HIPCHK(hipStreamCreateWithFlags(&e->astream, hipStreamNonBlocking));
-    if (!e->run_ev[sl]) HIPCHK(hipEventCreateWithFlags(&e->run_ev[sl], hipEventDisableTiming));
-    if (!e->copy_ev[sl]) HIPCHK(hipEventCreateWithFlags(&e->copy_ev[sl], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(e->run_ev[sl], st));
-    e->run_queued[sl] = true;
-    HIPCHK(hipStreamWaitEvent(e->astream, e->run_ev[sl], 0));
-    HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->astream));
-    HIPCHK(hipEventRecord(e->copy_ev[sl], e->astream));
-    e->copy_pending[sl] = true;
+    if (reported && !pinit) {  // (the run's last launch is the last thing on the stream and reports itself: nothing to add)
+      e->slot_serial[sl] = reported;
+      e->run_queued[sl] = true;
+    } else {
+      reported = 0;
+      if (!e->astream) HIPCHK(hipStreamCreateWithFlags(&e->astream, hipStreamNonBlocking));
+      if (!e->run_ev[sl]) HIPCHK(hipEventCreateWithFlags(&e->run_ev[sl], hipEventDisableTiming));
+      if (!e->copy_ev[sl]) HIPCHK(hipEventCreateWithFlags(&e->copy_ev[sl], hipEventDisableTiming));
+      HIPCHK(hipEventRecord(e->run_ev[sl], st));
+      e->run_queued[sl] = true;
+      HIPCHK(hipStreamWaitEvent(e->astream, e->run_ev[sl], 0));
+      HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->astream));
+      HIPCHK(hipEventRecord(e->copy_ev[sl], e->astream));
+      e->copy_pending[sl] = true;
+    }
     e->ht_mark[1] = std::chrono::steady_clock::now();
     e->pend.active = true;
     e->pend.slot = sl;
     e->pend.nsamp = nsamp; e->pend.nburn = nburn; e->pend.tbase0 = e->tbase;
     e->pend.meet_check = e->meet_check; e->pend.hctr = hctr; e->pend.host_pinit = pinit != nullptr;
+    e->pend.serial = reported;
     e->meet_check = false;  // (finish_pending looks at the word itself)
     e->samp_steps = e->opt_samples ? nkeep : 0;
     e->last_nsamp = nsamp; e->last_nburn = nburn; e->have_run = true;
     e->tbase += (uint32_t)(nburn + nsamp);
     return MCX_OK;
   }
-  HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  if (!reported) HIPCHK(hipMemcpyAsync(hctr, ctrp, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   e->ht_mark[1] = std::chrono::steady_clock::now();
   {
-    const hipError_t se = hipStreamSynchronize(st);
+    hipError_t se = hipSuccess;
+    if (!(reported && report_arrived(hctr, reported, REPORT_SPIN_US))) se = hipStreamSynchronize(st);
+    if (se == hipSuccess && reported && __atomic_load_n(hctr + 7, __ATOMIC_ACQUIRE) != reported) {
+      (void)meet_release(e, true);
+      return fail(MCX_ERR_HIP, "internal: the run's last launch is over and has not reported");
+    }
     e->ht_mark[2] = std::chrono::steady_clock::now();
     const bool abandoned = e->meet_check && se == hipSuccess && hctr[5] != 0;  // (the word came with the counters)
     e->meet_check = false;

@@ -290,6 +290,7 @@ struct mcx_engine {
     unsigned long long *hctr = nullptr;  // its slot of the pinned counter ring
     bool host_pinit = false;             // it started from caller memory (kept in pinit_async for a repeat), not from the staged state
     int slot = 0;                        // its counter slot / events
+    unsigned long long serial = 0;       // != 0: its last launch reports to the slot itself (RunArgs::report) and stores this last
   } pend;
   hipStream_t astream = nullptr;         // an asynchronous run's counters travel on it, beside the next run's kernels
   // Counter slots in pinned memory, one per run in turn.  FOUR: run k is queued once run k-2's kernels are over (two in flight),
@@ -303,6 +304,11 @@ struct mcx_engine {
   int hctr_slot = 0;
   hipEvent_t run_ev[HSLOTS] = {nullptr, nullptr, nullptr, nullptr};  // recorded behind each asynchronous run's last command, by counter slot
   bool run_queued[HSLOTS] = {false, false, false, false};
+  // MCX_OPT_SELF_REPORT: a run that ends with a launch of the one-launch kernel has that launch write the counters to the slot
+  // and its serial number behind them (RunArgs::report): nothing is queued behind the kernel, the host spins on the word
+  int opt_self_report = 1;
+  unsigned long long report_serial = 0;                    // serial numbers handed out so far
+  unsigned long long slot_serial[HSLOTS] = {0, 0, 0, 0};   // the serial the slot's run will store (0: its counters come by copy)
   hipStream_t mstream = nullptr;   // Murray passes by column chunks: the sweeps' stream (mcx_murray.hip: screen_sweep_chunked)
   std::vector<hipEvent_t> mev;
   int opt_murray_overlap = 0;

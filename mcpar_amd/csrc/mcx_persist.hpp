@@ -104,6 +104,14 @@ struct RunArgs {
   unsigned long long *trace_clk;
   unsigned long long meet_timeout;  // 100 MHz ticks a tuner meeting may take before the launch is abandoned
   int meet_expect_extra;    // debug (MCX_OPT_DEBUG_MEET): workgroups the meetings wait for beyond the grid's own
+  // The launch that ends a run tells the host itself: its last workgroup copies ctr[0..6] to `report` (pinned, mapped host
+  // memory) and then stores `report_serial` to report[7], which the host spins on -- no copy kernel behind the launch, no
+  // interrupt (host wall - kernel time of a lone kernel: 16 us with the copy + hipStreamSynchronize, 4-6 this way,
+  // tools/sync_latency_probe.hip).  `report_done` counts the workgroups that are through and is left zero.  An abandoned
+  // launch reports like any other (ctr[5] says what happened).  report null: nothing of the kind.
+  unsigned long long *report;
+  unsigned *report_done;
+  unsigned long long report_serial;
 };
 
 static_assert(PLEAVES == 16, "a meeting's leaves are polled by the 16 lanes of one DPP row");
@@ -735,7 +743,8 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // (every iteration ends with a barrier: a flag raised during the last phase is visible here)
   if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) aborted = true;
-  if (aborted) return;  // abandoned launch: no state is written back, the host repeats the run (ctr[5] is set)
+  // abandoned launch: no state is written back, the host repeats the run (ctr[5] is set)
+  if (!aborted) {
   if (owner) {
     if (live) {
 #pragma unroll
@@ -773,10 +782,35 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    a.ctr[1] = tun_na;
-    a.ctr[2] = tun_nt;
+    __hip_atomic_store(a.ctr + 1, tun_na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (atomics: a.report)
+    __hip_atomic_store(a.ctr + 2, tun_nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (burn_acc) atomicAdd(a.ctr + 3, burn_acc);  // (what the meetings counted; the waves add the rest; the run's block starts at zero)
     *a.ntrace = (a.fresh ? 0 : *a.ntrace) + ntrace_local;
+  }
+  }
+  if (a.report) {  // (see RunArgs)
+    // No fence on this path: a release at agent or system scope writes the L2's dirty lines back first -- 10 us and more
+    // behind a launch that streamed sample rows -- which is what the host would then be waiting for (measured: nothing gained
+    // over the copy).  Only the seven words matter here, and every access to them is an atomic at agent scope, performed at
+    // the memory side: each wavefront waits for its own (s_waitcnt) before the workgroup's barrier, the ticket follows the
+    // barrier, the last workgroup's loads follow its ticket.  Everything else the launch wrote is read through the stream,
+    // behind the launch's own end-of-kernel release.
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (__hip_atomic_fetch_add(a.report_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {  // the grid's last workgroup
+        __hip_atomic_store(a.report_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = __hip_atomic_load(a.ctr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) __hip_atomic_store(a.report + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0);  // the words have arrived (host memory is written through) ...
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __hip_atomic_store(a.report + 7, a.report_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ... now the serial number
+      }
+    }
   }
 }
 

@@ -23,6 +23,7 @@ OPT_MEET_UNDER_GATHER = 17
 OPT_MURRAY_OVERLAP = 18
 OPT_ASYNC_RUN = 19
 OPT_REFERENCE_CALLS = 20
+OPT_SELF_REPORT = 21
 XCHG_BEGIN, XCHG_WAIT = 0, 1
 
 

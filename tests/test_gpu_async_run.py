@@ -27,7 +27,8 @@ def check(eg, eo, what):
 
 @pytest.mark.parametrize("d,n,host_pinit", [(16, 8192, False), (8, 4096, True), (16, 65536, False), (16, 700, True)],
                          ids=["one-launch-8192", "one-launch-4096-host-pinit", "segments-65536", "tiny-host-pinit"])
-def test_async_runs_equal_synchronous_ones(d, n, host_pinit):
+@pytest.mark.parametrize("self_report", [1, 0], ids=["kernel-reports", "counters-by-copy"])
+def test_async_runs_equal_synchronous_ones(d, n, host_pinit, self_report):
     import mcpar_amd as M
     from mcpar_amd import engine as E
     nburn, nsamp = (500, 300) if n > 10000 else (160, 90)
@@ -37,6 +38,7 @@ def test_async_runs_equal_synchronous_ones(d, n, host_pinit):
     vg, _k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eg = M.Engine(d, n, pl=1.0)
     eg.set_option(E.OPT_ASYNC_RUN, 1)
+    eg.set_option(E.OPT_SELF_REPORT, self_report)
     if not host_pinit:
         eg.stage_pinit(p)
     for r in range(3):  # every run looked at
@@ -55,7 +57,8 @@ def test_async_runs_equal_synchronous_ones(d, n, host_pinit):
     eg.close(); eo.close()
 
 
-def test_an_abandoned_meeting_in_an_async_run_is_repeated_when_somebody_looks(capfd):
+@pytest.mark.parametrize("self_report", [1, 0], ids=["kernel-reports", "counters-by-copy"])
+def test_an_abandoned_meeting_in_an_async_run_is_repeated_when_somebody_looks(capfd, self_report):
     """MCX_OPT_DEBUG_MEET makes every meeting wait for a workgroup that does not exist: the one-launch kernel gives up after
     MCX_OPT_MEET_TIMEOUT_MS, the host learns of it when the run is finished -- and repeats it on the per-segment kernels,
     from the state the run started from (caller memory that has long been changed), same bits, counters say so"""
@@ -68,6 +71,7 @@ def test_an_abandoned_meeting_in_an_async_run_is_repeated_when_somebody_looks(ca
     vg, _k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
     eg = M.Engine(d, n, pl=1.0)
     eg.set_option(E.OPT_ASYNC_RUN, 1)
+    eg.set_option(E.OPT_SELF_REPORT, self_report)
     eg.set_option(E.OPT_MEET_TIMEOUT_MS, 5)
     eo.run(nsamp, nburn, p, vo)
     eg.run(nsamp, nburn, p, vg)
@@ -91,3 +95,34 @@ def test_an_abandoned_meeting_in_an_async_run_is_repeated_when_somebody_looks(ca
     check(eg, eo, "overtaken")
     assert eg.counters["meet_timeouts_total"] >= 2
     eg.close(); eo.close()
+
+
+@pytest.mark.parametrize("d,n,nburn,nsamp", [(16, 8192, 160, 90), (8, 4096, 0, 50), (8, 1000, 120, 0), (32, 2048, 100, 40)])
+def test_the_last_launch_reports_the_end_of_a_synchronous_run_itself(d, n, nburn, nsamp):
+    """MCX_OPT_SELF_REPORT (default on): the one-launch kernel that ends a run writes the counters and a serial number to
+    pinned host memory and mcx_run spins on it instead of queueing a copy and sleeping -- the same run with the option off
+    and the oracle's: same bits, same counters, run after run (the serial numbers move on, the slots turn)."""
+    import mcpar_amd as M
+    from mcpar_amd import engine as E
+    p = O.default_pinit(d, n)
+    vo, _k = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=1.0, threads=16)
+    vg, _k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    engines = []
+    for sr in (1, 0):
+        eg = M.Engine(d, n, pl=1.0)
+        eg.set_option(E.OPT_SELF_REPORT, sr)
+        engines.append(eg)
+    for r in range(6):
+        eo.run(nsamp, nburn, p, vo)
+        for sr, eg in zip((1, 0), engines):
+            eg.run(nsamp, nburn, p, vg)
+            c = eg.counters
+            assert (c["naccept_burn"], c["naccept_main"]) == (eo.naccept_burn, eo.naccept_main), (sr, r)
+            assert c["small_n_launches"] == 1 and c["meet_timeouts"] == 0, (sr, r, c)
+            assert same_bits(eg.state, eo.state) and same_bits(eg.tuner_trace, eo.tuner_trace), (sr, r)
+            if nsamp:
+                assert same_bits(eg.var, eo.var) and same_bits(eg.musigall, eo.musigall), (sr, r)
+    for eg in engines:
+        eg.close()
+    eo.close()

@@ -56,11 +56,12 @@ def one_case(rng, idx):
     rng5 = np.random.default_rng(1000003 * (idx + 1) + int(os.environ.get("MCX_FUZZ_SEED", "0")))
     async_run = int(rng5.random() < 0.3)         # mcx_run returns once the run is queued (runs that qualify; the getters finish it)
     overlap = int(rng5.choice([0, 0, 2, 4]))     # Murray passes over many chains by column chunks on two streams
+    self_report = int(rng5.random() < 0.7)       # the run's last small-n launch tells the host itself / counters by copy
     if os.environ.get("MCX_FUZZ_CULL"):         # a soak of one screen: every case with it
         cull = int(os.environ["MCX_FUZZ_CULL"])
     desc = dict(idx=idx, kind=kind, d=d, n=n, nburn=nburn, nsamp=nsamp, pl=pl, sync=sync, K=K, fullcov=incov is not None,
                 fuse=fuse, mask=mask, maxseg=maxseg, stride=stride, persist=persist, split=split, sink=sink, cull=cull, bpl=bpl,
-                async_run=async_run, overlap=overlap)
+                async_run=async_run, overlap=overlap, self_report=self_report)
     p = (rng.normal(0, 0.7, (n, d))).astype(np.float32)
     vo, k1 = O.make_vlfunc(kind, d, params, K)
     eo = O.Engine(d, n, pl=pl, sync=sync, threads=8 if n >= 200 else 1)
@@ -77,6 +78,7 @@ def one_case(rng, idx):
     eg.set_option(E.OPT_BLOCKS_PER_LANE, bpl)
     eg.set_option(E.OPT_ASYNC_RUN, async_run)
     eg.set_option(E.OPT_MURRAY_OVERLAP, overlap)
+    eg.set_option(E.OPT_SELF_REPORT, self_report)
     streamed, texts = [], []
     as_text = bool(sink) and rng.random() < 0.2 and n * nsamp * (d + 1) < 200000  # the blocks as text (mcx_set_text_sink)
     if as_text:

@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=200)
     ap.add_argument("--sync", action="store_true")
+    ap.add_argument("--by-copy", action="store_true", help="MCX_OPT_SELF_REPORT = 0: the counters by a copy behind the kernel")
     ap.add_argument("--read")
     a = ap.parse_args()
     if a.read:
@@ -43,6 +44,7 @@ def main():
     eng = M.Engine(d, n, pl=1.0)
     eng.stage_pinit(p)
     eng.set_option(E.OPT_ASYNC_RUN, 0 if a.sync else 1)
+    eng.set_option(E.OPT_SELF_REPORT, 0 if a.by_copy else 1)
     for _ in range(6):
         eng.run(nsamp, nburn, None, vl)
     eng.synchronize()
@@ -51,7 +53,7 @@ def main():
         for _ in range(a.jobs):
             eng.run(nsamp, nburn, None, vl)
         eng.synchronize()
-        print("%s: %.1f us per job over %d jobs" % ("one by one" if a.sync else "queued", (time.perf_counter() - t0) / a.jobs * 1e6, a.jobs))
+        print("%s%s: %.1f us per job over %d jobs" % ("one by one" if a.sync else "queued", ", counters by copy" if a.by_copy else "", (time.perf_counter() - t0) / a.jobs * 1e6, a.jobs))
     print("meet_timeouts_total", eng.counters["meet_timeouts_total"])
     eng.close()
 
