@@ -270,8 +270,8 @@ enum {
   MCX_OPT_SELF_REPORT = 21, /* a run that ends with a launch of the one-launch small-n kernel (few chains, one shard, no sink or
                               output hook): 1: that launch's last workgroup writes the run's counters and a serial number to
                               pinned host memory and mcx_run spins on the word (for at most 1.5 ms, then sleeps in
-                              hipStreamSynchronize as ever) -- nothing is queued behind the kernel: 12 us less per job of
-                              0.3-0.5 ms.  0: the counters come by a copy behind the kernel.  Same results.  [default 1] */
+                              hipStreamSynchronize as ever) -- nothing is queued behind the kernel: 6 us less per job of
+                              0.3-0.5 ms waited for.  0: the counters come by a copy behind the kernel.  Same results.  [default 1] */
   MCX_OPT_MURRAY_OVERLAP = 18, /* Murray passes over many chains (np = 16 or 32, the per-pair screen): cut the Gaussians into this
                               many column chunks and screen chunk c + 1 (matrix cores, step stream) while chunk c is swept
                               (vector units, a side stream).  Same bits.  0 / 1: one screen, then one sweep */

@@ -11,6 +11,7 @@
 static inline bool coin_is_remote(const PlanCfg &c, int isamp)
 {
   if (isamp < c.sync) return false;  // :143-144
+  if (c.pl >= 1.0f) return false;    // (rndlocal < 1 always: no coin to look at -- 5 us of host time per 1000 steps of a 0.4 ms job)
   const uint32_t t = c.tbase + (uint32_t)c.nburn + (uint32_t)isamp;
   const float rndlocal = u24(philox4x32_10(t, 0u, 0u, 0u, c.seed, ST_COIN).x);
   return !(rndlocal <= c.pl);  // :152
@@ -19,6 +20,7 @@ static inline bool coin_is_remote(const PlanCfg &c, int isamp)
 std::vector<mcx_plan_item> build_plan(const PlanCfg &c)
 {
   std::vector<mcx_plan_item> p;
+  p.reserve(64);
   auto add = [&](int kind, int first, int nsteps, int aux) { p.push_back(mcx_plan_item{kind, first, nsteps, aux}); };
   // burn-in (src/mcpar.cc:55-97): the tuner looks at the counters when isamp > irate, irate = 50, 100, ...
   int irate = 50;
