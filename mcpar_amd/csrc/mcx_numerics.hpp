@@ -37,6 +37,17 @@ struct u32x4 {
 MCX_HD float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 MCX_HD uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+// a ^ b ^ c: gfx950 has a three-input bit operation (v_bitop3_b32, truth table 0x96) that the compiler does not pick for
+// two xors by itself -- a Philox round is two multiplies and two of these instead of two multiplies and four xors
+MCX_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 MCX_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                            uint32_t k1)
 {
@@ -44,8 +55,8 @@ MCX_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+    const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
     c1 = (uint32_t)p1;
     c3 = (uint32_t)p0;
     c0 = n0;
