@@ -70,14 +70,24 @@ MCX_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 MCX_HD float u24(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
 MCX_HD float uopen(uint32_t w) { return __builtin_fmaf((float)w, 0x1p-32f, 0x1p-33f); }
 
+// Range reduction x = 2^e (1 + m), 1 + m in [sqrt(1/2), sqrt(2)): as the oracle writes it (oracle/mcx_oracle.c: mantissa to
+// [0.5, 1), compare with 0.70710678f = 0x3f3504f3, double it and lower e if below), and as it is computed here for
+// 0 <= x < inf -- the integer form of the same thing, no compare and no select (v_cndmask and v_cmp cost 4.4 and 3 cycles,
+// an integer add 2.6: tools/ubench.hip).  With b = E << 23 | M: ix = b - 0x3f3504f3 has floor(ix / 2^23) = E - 127 when
+// M < 0x3504f3 and E - 126 otherwise, and its low 23 bits + 0x3f3504f3 are 0x3f800000 | M resp. 0x3f000000 | M: the bits of
+// 2m resp. m of the text-book form.  Same e, same mantissa, and the subtraction of 1 is exact in both: same bits.
+MCX_HD void log_reduce(float x, int &e, float &m)
+{
+  const uint32_t ix = as_u32(x) - 0x3f3504f3u;
+  e = (int)ix >> 23;  // (arithmetic shift)
+  m = as_f32((ix & 0x007fffffu) + 0x3f3504f3u) - 1.0f;
+}
+
 MCX_HD float logf_v1(float x)
 {
-  const uint32_t b = as_u32(x);
-  int e = (int)((b >> 23) & 0xffu) - 126;
-  float m = as_f32((b & 0x007fffffu) | 0x3f000000u);
-  const bool lo = m < 0.70710678f;
-  e = lo ? e - 1 : e;
-  m = lo ? (m + m) - 1.0f : m - 1.0f;
+  int e;
+  float m;
+  log_reduce(x, e, m);
   const float fe = (float)e;
   const float z = m * m;
   float p = 7.0376836292e-2f;
@@ -180,14 +190,10 @@ __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 
 __device__ __forceinline__ f32x2 logf_v1x2(f32x2 x)
 {
-  const uint32_t bx = as_u32(x.x), by = as_u32(x.y);
-  int ex = (int)((bx >> 23) & 0xffu) - 126, ey = (int)((by >> 23) & 0xffu) - 126;
-  f32x2 m = {as_f32((bx & 0x007fffffu) | 0x3f000000u), as_f32((by & 0x007fffffu) | 0x3f000000u)};
-  const bool lx = m.x < 0.70710678f, ly = m.y < 0.70710678f;
-  ex = lx ? ex - 1 : ex;
-  ey = ly ? ey - 1 : ey;
-  const f32x2 t = {lx ? m.x + m.x : m.x, ly ? m.y + m.y : m.y};
-  m = t - splat2(1.0f);
+  const uint32_t ix = as_u32(x.x) - 0x3f3504f3u, iy = as_u32(x.y) - 0x3f3504f3u;  // (log_reduce, twice)
+  const int ex = (int)ix >> 23, ey = (int)iy >> 23;
+  const f32x2 t = {as_f32((ix & 0x007fffffu) + 0x3f3504f3u), as_f32((iy & 0x007fffffu) + 0x3f3504f3u)};
+  const f32x2 m = t - splat2(1.0f);
   const f32x2 fe = {(float)ex, (float)ey};
   const f32x2 z = m * m;
   f32x2 p = splat2(7.0376836292e-2f);
