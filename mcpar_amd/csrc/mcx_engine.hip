@@ -788,7 +788,9 @@ static bool report_arrived(const unsigned long long *slot, unsigned long long se
   for (int it = 0;; ++it) {
     if (__atomic_load_n(slot + 7, __ATOMIC_ACQUIRE) == serial) return true;
     if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) return false;
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#endif
   }
 }
 constexpr int REPORT_SPIN_US = 1500;
