@@ -174,8 +174,9 @@ static int launch_fused_plain(int lpc, int lik, bool main, const SegArgs &a, hip
   else if (fast) err = mcxk_launch_fast(lpc, lik, main, a, st);  // hot path
   else if (lpc <= 8 && fast_lik && !a.diag && a.vec4 && !a.mask) {
     // full covariance: one block per lane, or two mirrored ones (mcx_fastb.hpp) -- bpl as MCX_OPT_BLOCKS_PER_LANE says,
-    // else what tools/fullcov_ab.sh measured best per size
-    const bool mirrored = (lpc == 4 || lpc == 8) && (full_bpl == 2 || (full_bpl == 0 && lpc == 8));
+    // else what tools/fullcov_ab.sh measured best per size (16-D: since the generator got cheaper the mirrored kernel wins
+    // at 65 536 chains, 2.49 against 2.55 ms; it has half the wavefronts, so not below that)
+    const bool mirrored = (lpc == 4 || lpc == 8) && (full_bpl == 2 || (full_bpl == 0 && (lpc == 8 || a.n >= 65536)));
     err = mirrored ? mcxk_launch_fastb_full(lpc, lik, main, a, st) : mcxk_launch_fast_full(lpc, lik, main, a, st);
   }
   else err = main ? mcxk_launch_generic_main(lpc, lik, a, st) : mcxk_launch_generic_burn(lpc, lik, a, st);

@@ -15,8 +15,8 @@ def main():
     pat = sys.argv[1]
     os.makedirs(TMP, exist_ok=True)
     s = ""
-    for tu in ("mcx_k_fast", "mcx_k_fast_full", "mcx_k_fastb", "mcx_k_pregen", "mcx_k_generic_main", "mcx_k_generic_burn", "mcx_engine"):
-        if pat.startswith("k_fused_fast") and tu not in ("mcx_k_fast", "mcx_k_fast_full", "mcx_k_fastb", "mcx_k_pregen"):
+    for tu in ("mcx_k_fast", "mcx_k_fast_full", "mcx_k_fastb", "mcx_k_fastb_full", "mcx_k_pregen", "mcx_k_generic_main", "mcx_k_generic_burn", "mcx_engine"):
+        if pat.startswith("k_fused_fast") and tu not in ("mcx_k_fast", "mcx_k_fast_full", "mcx_k_fastb", "mcx_k_fastb_full", "mcx_k_pregen"):
             continue
         subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
                                "-fno-fast-math", "-fno-gpu-flush-denormals-to-zero", "-I" + ROOT + "/include", "-c",
