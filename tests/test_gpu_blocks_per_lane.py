@@ -217,3 +217,25 @@ def test_full_covariance_kernels_same_bits_as_oracle(kind, d, n, pl, bpl):
     so_ = eo.samples
     assert same_bits(eg.samples, so_[so_.shape[0] - eg.samples.shape[0]:])
     eg.close()
+
+
+def test_full_covariance_engine_choice_at_the_headline_size():
+    """16-D full covariance at 65 536 chains: the engine's own choice of kernel (the mirrored one from that size on since
+    round 5, one block per lane below) -- a short job, all bits against the oracle."""
+    import mcpar_amd as M
+    d, n, nburn, nsamp = 16, 65536, 60, 25
+    a = np.random.default_rng(77).normal(size=(d, d))
+    cov = (0.02 * (np.eye(d) + 0.5 * a @ a.T / d)).astype(np.float32)
+    p = O.default_pinit(d, n)
+    vo, _k1 = O.make_vlfunc(O.VL_ROSENBROCK1, d)
+    eo = O.Engine(d, n, pl=1.0, threads=16)
+    eo.run(nsamp, nburn, p, vo, cov)
+    vg, _k2 = M.make_vlfunc(M.VL_ROSENBROCK1, d)
+    eg = M.Engine(d, n, pl=1.0)
+    eg.run(nsamp, nburn, p, vg, cov)
+    c = eg.counters
+    assert (c["naccept_burn"], c["naccept_main"]) == (eo.naccept_burn, eo.naccept_main)
+    assert np.array_equal(eg.tuner_trace, eo.tuner_trace)
+    for name in ("state", "loglike", "mean", "var", "musigall", "samples", "chol"):
+        assert same_bits(getattr(eg, name), getattr(eo, name)), name
+    eg.close(); eo.close()
