@@ -213,10 +213,22 @@ __device__ __forceinline__ f32x2 logf_v1x2(f32x2 x)
   return r;
 }
 
+// a ^ (b & c) in one instruction (v_bitop3_b32, truth table 0x78): flips the sign of a where bit 31 of b is set, for c = 1 << 31
+__device__ __forceinline__ float flip_sign_by(float a, uint32_t b)
+{
+  return as_f32((uint32_t)__builtin_amdgcn_bitop3_b32(as_u32(a), b, 0x80000000u, 0x78));
+}
+
+// sincos2pi_v1 (further up, = the oracle's) on two angles.  The quadrant k = (w + 2^29) >> 30 is never formed: with
+// t = w + 2^29, the reduced angle is w - (t & 0xc0000000), "sine and cosine change places" is bit 30 of t, "the sine is
+// negated" (k >= 2) is bit 31 of t, "the cosine is negated" (k = 1 or 2) is bit 31 ^ bit 30 = bit 31 of t ^ (t << 1), and a
+// negation is an xor of the sign bit: 9 cheap integer operations, one compare and two selects per angle where the text-book
+// form has 8, four compares and four selects (a select costs 4.4 cycles per wavefront, an integer operation 2.6:
+// tools/ubench.hip).  Same values, same bits.
 __device__ __forceinline__ void sincos2pi_v1x2(uint32_t wa, uint32_t wb, f32x2 &s, f32x2 &c)
 {
-  const uint32_t ka = ((wa + 0x20000000u) >> 30) & 3u, kb = ((wb + 0x20000000u) >> 30) & 3u;
-  const int32_t ra = (int32_t)(wa - (ka << 30)), rb = (int32_t)(wb - (kb << 30));
+  const uint32_t ta = wa + 0x20000000u, tb = wb + 0x20000000u;
+  const int32_t ra = (int32_t)(wa - (ta & 0xc0000000u)), rb = (int32_t)(wb - (tb & 0xc0000000u));
   const f32x2 phi = f32x2{(float)ra, (float)rb} * splat2(1.4629180792671596e-9f);
   const f32x2 z = phi * phi;
   f32x2 ps = splat2(-1.9515295891e-4f);
@@ -227,11 +239,12 @@ __device__ __forceinline__ void sincos2pi_v1x2(uint32_t wa, uint32_t wb, f32x2 &
   pc = fma2(pc, z, splat2(-1.388731625493765e-3f));
   pc = fma2(pc, z, splat2(4.166664568298827e-2f));
   const f32x2 cp = fma2(z * z, pc, fma2(splat2(-0.5f), z, splat2(1.0f)));
-  const bool swa = (ka & 1u) != 0u, swb = (kb & 1u) != 0u;
+  const uint32_t ua = ta << 1, ub = tb << 1;
+  const bool swa = (int32_t)ua < 0, swb = (int32_t)ub < 0;  // bit 30 of t
   const f32x2 sv = {swa ? cp.x : sp.x, swb ? cp.y : sp.y};
   const f32x2 cv = {swa ? sp.x : cp.x, swb ? sp.y : cp.y};
-  s = f32x2{ka >= 2u ? -sv.x : sv.x, kb >= 2u ? -sv.y : sv.y};
-  c = f32x2{(ka == 1u || ka == 2u) ? -cv.x : cv.x, (kb == 1u || kb == 2u) ? -cv.y : cv.y};
+  s = f32x2{flip_sign_by(sv.x, ta), flip_sign_by(sv.y, tb)};
+  c = f32x2{flip_sign_by(cv.x, ta ^ ua), flip_sign_by(cv.y, tb ^ ub)};
 }
 
 // expf_v2 on two values: same operations in the same order
@@ -258,6 +271,32 @@ __device__ __forceinline__ f32x2 expf_v2x2(f32x2 x)
   o.y = fn.y < -125.0f ? 0.0f : o.y;
   o.x = fn.x > 127.0f ? __builtin_inff() : o.x;
   o.y = fn.y > 127.0f ? __builtin_inff() : o.y;
+  return o;
+}
+
+// expf_v2x2 for arguments that are never positive (the Murray sweeps' -arg/2: arg is a sum of squares times 1/sigma^2): n <= 0,
+// so the overflow select can never fire -- left out, same bits (a NaN argument compares false there as well)
+__device__ __forceinline__ f32x2 expf_v2x2_nonpos(f32x2 x)
+{
+  const f32x2 fn = {__builtin_floorf(__builtin_fmaf(x.x, 1.44269504f, 0.5f)),
+                    __builtin_floorf(__builtin_fmaf(x.y, 1.44269504f, 0.5f))};
+  f32x2 r = fma2(fn, splat2(-0.693359375f), x);
+  r = fma2(fn, splat2(2.12194440e-4f), r);
+  f32x2 p = splat2(1.9875691500e-4f);
+  p = fma2(p, r, splat2(1.3981999507e-3f));
+  p = fma2(p, r, splat2(8.3334519073e-3f));
+  p = fma2(p, r, splat2(4.1665795894e-2f));
+  p = fma2(p, r, splat2(1.6666665459e-1f));
+  p = fma2(p, r, splat2(5.0000001201e-1f));
+  const f32x2 z = r * r;
+  f32x2 y = fma2(p, z, r);
+  y = y + splat2(1.0f);
+  const int na = (int)fn.x, nb = (int)fn.y;
+  f32x2 o;
+  o.x = as_f32(as_u32(y.x) + ((uint32_t)na << 23));
+  o.y = as_f32(as_u32(y.y) + ((uint32_t)nb << 23));
+  o.x = fn.x < -125.0f ? 0.0f : o.x;
+  o.y = fn.y < -125.0f ? 0.0f : o.y;
   return o;
 }
 

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NT, (DMAX == 32 && CPL == 2) ? 4 : 1) void k_remote
       }
       if (SUMS) {
         sweep_rows2<DMAX>(qlds, todo, xx, valid[0], valid[CPL - 1], [] { return splat2(ZERO_ARG); }, [&](f32x2 av) {
-          const f32x2 gv = expf_v2x2(splat2(-0.5f) * av);
+          const f32x2 gv = expf_v2x2_nonpos(splat2(-0.5f) * av);
           part = part + gv;
           m.x = gv.x > m.x ? gv.x : m.x;
           m.y = gv.y > m.y ? gv.y : m.y;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(BLOCK) void k_remote_sweep_srow(const float *__rest
   };
   auto consume = [&](const f32x2 arg) {
     if (SUMS) {
-      const f32x2 gv = expf_v2x2(splat2(-0.5f) * arg);
+      const f32x2 gv = expf_v2x2_nonpos(splat2(-0.5f) * arg);
       part = part + gv;
       m.x = gv.x > m.x ? gv.x : m.x;
       m.y = gv.y > m.y ? gv.y : m.y;
