@@ -43,6 +43,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define OP_CMPCND(k) asm volatile("v_cmp_lt_u32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##k) : "v"(seed) : "vcc");
 #define OP_MED3(k) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(a##k) : "v"(sf));
 #define OP_MAXF(k) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a##k) : "v"(sf));
+#define OP_ADDC(k) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a##k) : : "vcc");
+#define OP_CMPADDC(k) asm volatile("v_cmp_lt_u32 vcc, %1, %0\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a##k) : "v"(seed) : "vcc");
 #define OP_ADD(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a##k) : "v"(seed));
 #define OP_BITOP3(k) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a##k) : "v"(seed));
 #define OP_BITOP3S(k) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a##k) : "v"(seed), "s"(sseed));
@@ -138,6 +140,13 @@ __global__ void k_cmp_cnd(unsigned *out, unsigned seed)
 }
 KERNEL(k_med3, float sf = seed * 1e-9f; R8(DF), R8(OP_MED3), FINF)
 KERNEL(k_max_f32, float sf = seed * 1e-9f; R8(DF), R8(OP_MAXF), FINF)
+KERNEL(k_addc, R8(DU), R8(OP_ADDC), FINU)
+__global__ void k_cmp_addc(unsigned *out, unsigned seed)
+{
+  R8(DU)
+  for (int i = 0; i < ITER / 2; ++i) { R8(OP_CMPADDC) }
+  FINU; out[blockIdx.x * blockDim.x + threadIdx.x] = fin;
+}
 KERNEL(k_add_u32, R8(DU), R8(OP_ADD), FINU)
 KERNEL(k_add_f32_dpp, R8(DF), R8(OP_DPP), FINF)
 KERNEL(k_bitop3, R8(DU), R8(OP_BITOP3), FINU)
@@ -152,7 +161,7 @@ typedef void (*kfn)(unsigned *, unsigned);
 struct K { const char *name; kfn f; };
 int main()
 {
-  K ks[] = {{"fma", k_fma},{"xor", k_xor},{"mul_lo_u32", k_mul_lo_u32},{"mul_hi_u32", k_mul_hi_u32},{"mad_u64_u32", k_mad_u64_u32},{"mul_u32_u24", k_mul_u32_u24},{"sqrt", k_sqrt},{"rcp", k_rcp},{"cvt_f32_u32", k_cvt_f32_u32},{"cndmask", k_cndmask},{"cndmask sgpr", k_cndmask_s},{"cmp+cndmask", k_cmp_cnd},{"med3_f32", k_med3},{"max_f32", k_max_f32},{"add_u32", k_add_u32},{"add_f32_dpp", k_add_f32_dpp},{"bitop3_b32", k_bitop3},{"bitop3 v,v,s", k_bitop3_s},{"frexp_mant_f32", k_frexp_mant},{"ldexp_f32", k_ldexp},{"and_or_b32", k_and_or},{"pk_fma", k_pk_fma},{"pk_mul", k_pk_mul},{"sweep mov3", k_mov3},{"sweep fma2", k_fma2},{"mov_b64 s->v", k_mov64},{"fmac_f32_dpp", k_fmac_dpp},{"8fma+lds_b128", k_fma_lds},{"sweep pk2", k_pk2}};
+  K ks[] = {{"fma", k_fma},{"xor", k_xor},{"mul_lo_u32", k_mul_lo_u32},{"mul_hi_u32", k_mul_hi_u32},{"mad_u64_u32", k_mad_u64_u32},{"mul_u32_u24", k_mul_u32_u24},{"sqrt", k_sqrt},{"rcp", k_rcp},{"cvt_f32_u32", k_cvt_f32_u32},{"cndmask", k_cndmask},{"cndmask sgpr", k_cndmask_s},{"cmp+cndmask", k_cmp_cnd},{"med3_f32", k_med3},{"max_f32", k_max_f32},{"addc_co_u32", k_addc},{"cmp+addc", k_cmp_addc},{"add_u32", k_add_u32},{"add_f32_dpp", k_add_f32_dpp},{"bitop3_b32", k_bitop3},{"bitop3 v,v,s", k_bitop3_s},{"frexp_mant_f32", k_frexp_mant},{"ldexp_f32", k_ldexp},{"and_or_b32", k_and_or},{"pk_fma", k_pk_fma},{"pk_mul", k_pk_mul},{"sweep mov3", k_mov3},{"sweep fma2", k_fma2},{"mov_b64 s->v", k_mov64},{"fmac_f32_dpp", k_fmac_dpp},{"8fma+lds_b128", k_fma_lds},{"sweep pk2", k_pk2}};
   hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
   const int cus = p.multiProcessorCount;
   unsigned *out; CHK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * 4));
