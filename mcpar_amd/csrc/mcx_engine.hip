@@ -1416,7 +1416,10 @@ static int run_once(mcx_engine *e, int nsamp, int nburn, const float *pinit, con
   e->ht_mark[1] = std::chrono::steady_clock::now();
   {
     hipError_t se = hipSuccess;
-    if (!(reported && report_arrived(hctr, reported, REPORT_SPIN_US))) se = hipStreamSynchronize(st);
+    // (spinning only for runs of the length the last one had: whoever runs 10 ms jobs sleeps as ever)
+    const auto w0 = std::chrono::steady_clock::now();
+    if (!(reported && e->report_wait_us < (double)REPORT_SPIN_US && report_arrived(hctr, reported, REPORT_SPIN_US))) se = hipStreamSynchronize(st);
+    if (reported) e->report_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
     if (se == hipSuccess && reported && __atomic_load_n(hctr + 7, __ATOMIC_ACQUIRE) != reported) {
       (void)meet_release(e, true);
       return fail(MCX_ERR_HIP, "internal: the run's last launch is over and has not reported");

@@ -308,6 +308,8 @@ struct mcx_engine {
   // and its serial number behind them (RunArgs::report): nothing is queued behind the kernel, the host spins on the word
   int opt_self_report = 1;
   unsigned long long report_serial = 0;                    // serial numbers handed out so far
+  double report_wait_us = 0.0;  // how long the last self-reporting run kept the host waiting: a run that takes longer than the
+                                // spin allows is not spun for at all the next time (a core's 1.5 ms are somebody else's)
   unsigned long long slot_serial[HSLOTS] = {0, 0, 0, 0};   // the serial the slot's run will store (0: its counters come by copy)
   hipStream_t mstream = nullptr;   // Murray passes by column chunks: the sweeps' stream (mcx_murray.hip: screen_sweep_chunked)
   std::vector<hipEvent_t> mev;
