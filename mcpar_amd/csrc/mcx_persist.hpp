@@ -241,7 +241,10 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
   const int OWN = a.own, K = a.ksteps;  // steps per phase: a multiple of the generator count
   const int T = a.nburn + a.nmain;
   const int nphase = (T + K - 1) / K;
-  const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  // (the wavefront's index as a SCALAR: what it decides -- owner, recorder, generator, working -- is then uniform control
+  // flow to the compiler too: loop counters in SGPRs and s_cbranch instead of exec masks and VGPR counters in the owner's
+  // step loop, which a single wavefront issues at one instruction per 5.7 cycles: tools/ubench.hip)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
   const bool owner = wv < OWN, recorder = REC && !owner && wv < 2 * OWN;
   // LDS double buffers, by phase parity: zbuf / xbuf [2][K][OWN][BPL][64] float4, ubuf / lbuf [2][K][OWN][64/LPC2] float
   constexpr int CPW = 64 / LPC2;  // chains per owner wavefront
