@@ -454,6 +454,9 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
         const f32x2 t1 = splat2(1.0f) - pe[b];
         const f32x2 t2 = fma2(-pe[b], pe[b], po[b]);
         const f32x2 term = fma2(splat2(100.0f) * t2, t2, t1 * t1);
+        // (the select stays: a lane without parameters is never dealt normals, its slots of zbuf hold whatever LDS held, and
+        // 0 x inf is a NaN.  Parking such lanes at x = 1, T = 0 -- term +0 by itself -- needs the slots zeroed once per launch,
+        // which costs 6 us of a 0.36 ms job: more than the select)
         if (live) acc[b] = term.x + term.y;
       } else if (LIK == LIK_GAUSS) {
         const f32x2 ae = pe[b] - gme[b], ao = po[b] - gmo[b];
@@ -565,18 +568,7 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
         float lun = *up;
         // proposal, likelihood, acceptance (src/mcpar.cc:302-312, 62-75); returns the chains of the wave that accepted.
         // The next step's numbers are fetched first: they are on their way while this step computes.
-        auto metropolis = [&](int s) {
-          float4 z[BPL];
-#pragma unroll
-          for (int b = 0; b < BPL; ++b) z[b] = zn[b];
-          const float lu = lun;
-          if (s + 1 < ns) {
-            zp += (size_t)OB * 64;
-            up += (size_t)OWN * CPW;
-#pragma unroll
-            for (int b = 0; b < BPL; ++b) zn[b] = zp[b * 64];
-            lun = *up;
-          }
+        auto core = [&](const float4 (&z)[BPL], const float lu) {
           f32x2 pe[BPL], po[BPL];
 #pragma unroll
           for (int b = 0; b < BPL; ++b) {
@@ -591,16 +583,44 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
             xo[b] = take ? po[b] : xo[b];
           }
           ly = take ? lyt : ly;
-          cnt += take ? 1u : 0u;  // (every lane of a chain counts its chain's accepted proposals)
+          cnt += (uint32_t)take;  // (every lane of a chain counts its chain's accepted proposals; an add with carry-in)
         };
-
+        auto fetch_next = [&](float4 (&z)[BPL], float &lu) {
+          zp += (size_t)OB * 64;
+          up += (size_t)OWN * CPW;
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) z[b] = zp[b * 64];
+          lu = *up;
+        };
+        auto metropolis = [&](int s) {
+          float4 z[BPL];
+#pragma unroll
+          for (int b = 0; b < BPL; ++b) z[b] = zn[b];
+          const float lu = lun;
+          if (s + 1 < ns) fetch_next(zn, lun);
+          core(z, lu);
+        };
+        // Steps s and s + 1 (s + 1 < ns): the second step's numbers go to registers of their own, the third's back to (zn, lun)
+        // -- nothing is moved from "next" to "this" between two steps (3 of a step's 30 instructions, and this wavefront
+        // issues one per 5.7 cycles whatever it is).  `between` is what follows each step (the main loop's hand-over).
+        auto two_steps = [&](int s, auto &&between) {
+          float4 z1[BPL];
+          float lu1;
+          fetch_next(z1, lu1);
+          core(zn, lun);
+          between();
+          if (s + 2 < ns) fetch_next(zn, lun);
+          core(z1, lu1);
+          between();
+        };
         // Two loops, not one with a branch: the main-loop steps write to LDS, and a wait shared by both kinds of
         // step would have to cover those writes (LDS operations retire in order) on every step.
         int s = 0;
         while (s < nb) {  // ---- burn-in steps (src/mcpar.cc:58-75), up to and including the next tuner event's step
           const int ev = next_event - tau0;  // (>= nb: the event lies in a later phase)
           const int send = ev < nb ? ev + 1 : nb;
-          for (; s < send; ++s) metropolis(s);  // the step loop proper: nothing in it but the steps
+          for (; s + 1 < send; s += 2) two_steps(s, [] {});  // the step loop proper: nothing in it but the steps
+          for (; s < send; ++s) metropolis(s);
           if (ev < nb) {  // tuner event (src/mcpar.cc:77-96): the accept count of every chain of the shard
             const int last = next_event;
             const int steps = last - seg_start + 1, check = last > irate ? 1 : 0;
@@ -664,14 +684,20 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
         if (nb > 0 && tau0 + nb == a.nburn) cnt_mark = cnt;  // the burn-in ends here: the main loop's accepts count from now
         xq += (size_t)nb * OB * 64;
         lq += (size_t)nb * OWN * CPW;
-        for (; s < ns; ++s) {  // ---- main-loop steps (src/mcpar.cc:152-209)
-          metropolis(s);
-          if (REC) {  // hand the state to the recorder (every lane of a chain writes the same ly)
+        // ---- main-loop steps (src/mcpar.cc:152-209)
+        auto hand_over = [&] {  // the state to the recorder (every lane of a chain writes the same ly)
 #pragma unroll
-            for (int b = 0; b < BPL; ++b) xq[b * 64] = make_float4(xe[b].x, xe[b].y, xo[b].x, xo[b].y);
-            *lq = ly;
-            xq += (size_t)OB * 64;
-            lq += (size_t)OWN * CPW;
+          for (int b = 0; b < BPL; ++b) xq[b * 64] = make_float4(xe[b].x, xe[b].y, xo[b].x, xo[b].y);
+          *lq = ly;
+          xq += (size_t)OB * 64;
+          lq += (size_t)OWN * CPW;
+        };
+        if (REC)
+          for (; s + 1 < ns; s += 2) two_steps(s, hand_over);
+        for (; s < ns; ++s) {
+          metropolis(s);
+          if (REC) {
+            hand_over();
           } else {  // no recorders (the run is bound by the generators' throughput, not by this wave's latency)
             if (s == nb && tau0 + s == a.nburn && a.init_moments) {  // src/mcpar.cc:99-104
 #pragma unroll
