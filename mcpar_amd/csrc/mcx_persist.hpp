@@ -238,6 +238,7 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
   }
   if (threadIdx.x == 0) { lds_sum = 0; lds_cnt = 0; lds_abort = 0; }
   if (threadIdx.x < PEVENTS) lds_out[threadIdx.x] = ~0ull;
+  constexpr bool NEGSUM = LIK == LIK_ROSEN1 || LIK == LIK_GAUSS;  // (see loglike)
   const int OWN = a.own, K = a.ksteps;  // steps per phase: a multiple of the generator count
   const int T = a.nburn + a.nmain;
   const int nphase = (T + K - 1) / K;
@@ -469,13 +470,18 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
         }
       }
     }
+    // Rosenbrock1 / Gaussian (NEGSUM): the sum S itself, L = 0 - S.  The owners keep S_cur = -ly instead of ly: the test
+    // log u < ly' - ly is log u < S_cur - S' -- the same difference, rounded once either way -- and the negation leaves
+    // the step loop, where every instruction costs this lone wavefront 5.7 cycles: ly = 0 - S_cur where it is wanted
+    if (NEGSUM) return blocks_sum(acc);
     return 0.0f - blocks_sum(acc);
   };
 
   __syncthreads();  // the mixture's means and log-weights are staged
+  if (NEGSUM && owner) ly = 0.0f - ly;  // (a state handed over from an earlier launch: S_cur = -ly; -inf where no chain is)
   if (owner && a.x0) {  // L(pinit) (src/mcpar.cc:53); every lane of a chain gets the chain's value
     const float l0 = loglike(xe, xo);
-    ly = mine ? l0 : __builtin_inff();
+    ly = mine ? l0 : (NEGSUM ? -__builtin_inff() : __builtin_inff());
   }
   // tuner state (src/mcpar.cc:77-96), identical in every owner wave
   unsigned long long tun_na = a.fresh ? 0ull : a.ctr[1], tun_nt = a.fresh ? 0ull : a.ctr[2], burn_acc = 0;
@@ -576,14 +582,19 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
             po[b] = fma2(to[b], f32x2{z[b].z, z[b].w}, xo[b]);
           }
           const float lyt = loglike(pe, po);
-          const bool take = accept_local(lyt, ly, lu);
+          const bool take = NEGSUM ? lu < ly - lyt : accept_local(lyt, ly, lu);  // (NEGSUM: ly is S_cur, lyt is S')
 #pragma unroll
           for (int b = 0; b < BPL; ++b) {
             xe[b] = take ? pe[b] : xe[b];
             xo[b] = take ? po[b] : xo[b];
           }
           ly = take ? lyt : ly;
-          cnt += (uint32_t)take;  // (every lane of a chain counts its chain's accepted proposals; an add with carry-in)
+          {  // cnt += take: every lane of a chain counts its chain's accepted proposals -- ONE instruction, an add whose carry-in
+             // is the comparison's mask (the compiler makes a select and an add of it)
+            const unsigned long long tm = __builtin_amdgcn_ballot_w64(take);
+            unsigned long long carry_out;
+            asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(cnt), "=s"(carry_out) : "s"(tm));
+          }
         };
         auto fetch_next = [&](float4 (&z)[BPL], float &lu) {
           zp += (size_t)OB * 64;
@@ -706,7 +717,7 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
                 se[b] = so[b] = splat2(FPEPS);
               }
             }
-            record(xe, xo, ly, wbuf[(p & 3) * PKMAX + s], tau0 + s - a.nburn == a.snap_after);
+            record(xe, xo, NEGSUM ? 0.0f - ly : ly, wbuf[(p & 3) * PKMAX + s], tau0 + s - a.nburn == a.snap_after);
           }
         }
       }
@@ -734,7 +745,7 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
               ce[b] = f32x2{xv.x, xv.y};
               co[b] = f32x2{xv.z, xv.w};
             }
-            const float lyv = *lq;
+            const float lyv = NEGSUM ? 0.0f - *lq : *lq;  // (the owner hands over S_cur)
             const float w = wq[s];
             xq += (size_t)OB * 64;
             lq += (size_t)OWN * CPW;
@@ -787,7 +798,7 @@ __device__ __forceinline__ void run_small_body(const RunArgs &a)
       }
     }
     if (mine && q == 0) {
-      a.ly[chain] = ly;
+      a.ly[chain] = NEGSUM ? 0.0f - ly : ly;
       a.acc_cnt[chain] = a.fresh ? cnt : a.acc_cnt[chain] + cnt;
     }
     const unsigned long long macc = wave_accepts(cnt_mark);  // accepted main-loop proposals of this wave
