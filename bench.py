@@ -325,15 +325,17 @@ def claims_under_the_clock(M, E, headline_ms, headline_n, nburn, nsamp):
         for _ in range(4):
             eng.run(nsamp, nburn, None, vl)
         eng.synchronize()
-        kq = 60
-        t0 = time.perf_counter()
-        for _ in range(kq):
-            eng.run(nsamp, nburn, None, vl)
-        eng.synchronize()
-        t_piped = (time.perf_counter() - t0) / kq
+        kq, batches = 60, []
+        for _ in range(3):  # (the median of three batches: one stall of the box -- 13 ms were seen once -- is not the figure)
+            t0 = time.perf_counter()
+            for _ in range(kq):
+                eng.run(nsamp, nburn, None, vl)
+            eng.synchronize()
+            batches.append((time.perf_counter() - t0) / kq)
+        t_piped = sorted(batches)[1]
         eng.set_option(E.OPT_ASYNC_RUN, 0)
-        piped = dict(ms_per_job=t_piped * 1e3, jobs=kq, speedup_vs_headline_job=headline_ms / (t_piped * 1e3),
-                     meet_timeouts_total=eng.counters["meet_timeouts_total"])
+        piped = dict(ms_per_job=t_piped * 1e3, jobs=kq, batches_ms=[round(b * 1e3, 4) for b in batches],
+                     speedup_vs_headline_job=headline_ms / (t_piped * 1e3), meet_timeouts_total=eng.counters["meet_timeouts_total"])
     except Exception as ex:  # noqa: BLE001
         piped = dict(error=repr(ex))
     eng.close()

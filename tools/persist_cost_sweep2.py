@@ -10,9 +10,11 @@ from persist_bpl_probe import one  # noqa: E402
 
 d, n = int(sys.argv[1]), int(sys.argv[2])
 res = []
-for cn in (185, 165, 150, 135, 120):
+CN = tuple(int(v) for v in os.environ.get("SWEEP_CN", "185,165,150,135,120").split(","))
+COCR = tuple(tuple(int(x) for x in v.split("/")) for v in os.environ.get("SWEEP_COCR", "34/24,45/32,60/40").split(","))
+for cn in CN:
     for ca in (110, 85):
-        for co, cr in ((34, 24), (45, 32), (60, 40)):
+        for co, cr in COCR:
             c = "%d,%d,%d,%d" % (cn, ca, co, cr)
             os.environ["MCX_PERSIST_COST"] = c
             r = one(d, n, 0)
