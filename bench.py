@@ -258,15 +258,20 @@ def spd_covariance(d):
 
 
 def time_job(eng, vl, p, nsamp, nburn, incov=None, reps=5):
-    """median wall time of `reps` runs after two warm runs (run() returns when the stream has drained; the first
-    run of a kernel family also loads its code object)"""
+    """median wall time of `reps` runs after warm runs -- at least two (run() returns when the stream has drained; the first
+    run of a kernel family also loads its code object) and 20 ms' worth: the first jobs after a pause of the GPU run at the
+    clock it idled at (a 0.36 ms job measures 0.39 there)"""
     eng.stage_pinit(p)
+    t_warm, k = time.perf_counter(), 0
+    while k < 2 or (time.perf_counter() - t_warm < 0.02 and k < 200):
+        eng.run(nsamp, nburn, None, vl, incov)
+        k += 1
     ts = []
-    for r in range(reps + 2):
+    for r in range(reps):
         t0 = time.perf_counter()
         eng.run(nsamp, nburn, None, vl, incov)
         ts.append(time.perf_counter() - t0)
-    ts = sorted(ts[2:])
+    ts = sorted(ts)
     return ts[len(ts) // 2]
 
 
