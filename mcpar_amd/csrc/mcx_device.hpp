@@ -734,6 +734,9 @@ __device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a)
 #ifndef MCX_FULL_T_REGS
 #define MCX_FULL_T_REGS 1
 #endif
+#ifndef MCX_FAST_UNROLL4
+#define MCX_FAST_UNROLL4 1
+#endif
   constexpr bool TREGS = FULL && LPC <= 4 && (MCX_FULL_T_REGS != 0);
   __shared__ __attribute__((aligned(16))) float4 lds_T[FULL && !TREGS ? 4 * LPC * LPC : 1];
   __shared__ __attribute__((aligned(16))) float4 lds_z[FULL && LPC == 8 ? (BLOCK / 8) * 9 : 1];
@@ -985,26 +988,54 @@ __device__ __forceinline__ uint32_t fused_fast_body(const SegArgs &a)
   const __attribute__((address_space(4))) float *wtab = (const __attribute__((address_space(4))) float *)a.winv;
   if (!PREGEN) {
     float wnext = MAIN ? wtab[a.isamp0] : 1.0f;  // requested one step ahead (the table is padded past nsamp)
-    for (int s = 0; s < a.nsteps; ++s) {
-      const uint32_t t = a.t0 + (uint32_t)s;
-      const float wthis = wnext;
-      if (MAIN) wnext = wtab[a.isamp0 + s + 1];
-      f32x2 ze, zo;
-      normal4_packed(philox4x32_10(t, g, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
-      // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
-      // lanes of a chain split the work: lane q draws block b for b % LPC == q, once per 4*LPC steps.
-      const uint32_t blk = t >> 2;
+    // accept threshold: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3.  The LPC
+    // lanes of a chain split the work: lane q draws block b for b % LPC == q, once per 4*LPC steps.
+    auto refresh = [&](uint32_t blk) {
       if ((blk & ~(uint32_t)(LPC - 1)) != ablk) {  // the four logs are taken here, once per 4*LPC steps per lane
         ablk = blk & ~(uint32_t)(LPC - 1);
         const u32x4 aw = philox4x32_10(ablk + (uint32_t)q, g, 0u, 0u, a.seed, ST_ACCEPT);
         al01 = accept_lu_x2(aw.x, aw.y);
         al23 = accept_lu_x2(aw.z, aw.w);
       }
+    };
+    auto one_step = [&](int s) {
+      const uint32_t t = a.t0 + (uint32_t)s;
+      const float wthis = wnext;
+      if (MAIN) wnext = wtab[a.isamp0 + s + 1];
+      f32x2 ze, zo;
+      normal4_packed(philox4x32_10(t, g, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
+      const uint32_t blk = t >> 2;
+      refresh(blk);
       const uint32_t wi = t & 3u;
       const float mine = wi == 0u ? al01.x : (wi == 1u ? al01.y : (wi == 2u ? al23.x : al23.y));
       const float lu = as_f32(group_bcast<LPC>(as_u32(mine), blk & (uint32_t)(LPC - 1), q));
       step(s, ze, zo, lu, wthis);
+    };
+    int s = 0;
+#if MCX_FAST_UNROLL4
+    // Four steps at a time from a step index that is a multiple of 4 on: which of the block's four logs a step takes is then
+    // known at compile time, and the lane that holds them is looked up once per block instead of once per step (two
+    // wave-uniform switches per step otherwise: some ten scalar branches and two moves)
+    if (!FULL) {
+      for (; s < a.nsteps && ((a.t0 + (uint32_t)s) & 3u); ++s) one_step(s);
+      for (; s + 4 <= a.nsteps; s += 4) {
+        const uint32_t t = a.t0 + (uint32_t)s, blk = t >> 2;
+        refresh(blk);
+        const uint32_t holder = blk & (uint32_t)(LPC - 1);
+        const float lu4[4] = {as_f32(group_bcast<LPC>(as_u32(al01.x), holder, q)), as_f32(group_bcast<LPC>(as_u32(al01.y), holder, q)),
+                              as_f32(group_bcast<LPC>(as_u32(al23.x), holder, q)), as_f32(group_bcast<LPC>(as_u32(al23.y), holder, q))};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float wthis = wnext;
+          if (MAIN) wnext = wtab[a.isamp0 + s + u + 1];
+          f32x2 ze, zo;
+          normal4_packed(philox4x32_10(t + (uint32_t)u, g, (uint32_t)q, 0u, a.seed, ST_LOCAL), ze, zo);
+          step(s + u, ze, zo, lu4[u], wthis);
+        }
+      }
     }
+#endif
+    for (; s < a.nsteps; ++s) one_step(s);
   } else {
     // Batches of P steps, double buffered: at the top of a batch every load of it (issued one whole
     // batch earlier) is awaited at once and moved to `cur`, then the loads of the next batch are issued,
