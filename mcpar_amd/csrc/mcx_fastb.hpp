@@ -143,7 +143,17 @@ __device__ __forceinline__ uint32_t fused_fastb_body(const SegArgs &a)
   asm volatile("" ::"v"(ly));
   // 1/pwgt by scalar loads (constant address space): a plain global load would queue behind the sample stores
   const __attribute__((address_space(4))) float *wtab = (const __attribute__((address_space(4))) float *)a.winv;
-  for (int s = 0; s < a.nsteps; ++s) {
+  // acceptance draw: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3; lane q2 draws block b for
+  // b % LPC2 == q2, once per 4 * LPC2 steps
+  auto refresh = [&](uint32_t blk) {
+    if ((blk & ~(uint32_t)(LPC2 - 1)) != ablk) {
+      ablk = blk & ~(uint32_t)(LPC2 - 1);
+      const u32x4 aw = philox4x32_10(ablk + (uint32_t)q2, g, 0u, 0u, a.seed, ST_ACCEPT);
+      al01 = accept_lu_x2(aw.x, aw.y);
+      al23 = accept_lu_x2(aw.z, aw.w);
+    }
+  };
+  auto step = [&](const int s, const float lu) {
     const uint32_t t = a.t0 + (uint32_t)s;
     f32x2 pe[BPL], po[BPL];
     if (!FULL) {
@@ -189,19 +199,6 @@ __device__ __forceinline__ uint32_t fused_fastb_body(const SegArgs &a)
         asm volatile("" : "+v"(pe[0]), "+v"(po[0]), "+v"(pe[1]), "+v"(po[1]));
       }
     }
-    // acceptance draw: Philox block (t >> 2) of the ACCEPT stream serves steps 4b..4b+3; lane q2 draws block b for
-    // b % LPC2 == q2, once per 4 * LPC2 steps
-    const uint32_t blk = t >> 2;
-    if ((blk & ~(uint32_t)(LPC2 - 1)) != ablk) {
-      ablk = blk & ~(uint32_t)(LPC2 - 1);
-      const u32x4 aw = philox4x32_10(ablk + (uint32_t)q2, g, 0u, 0u, a.seed, ST_ACCEPT);
-      al01 = accept_lu_x2(aw.x, aw.y);
-      al23 = accept_lu_x2(aw.z, aw.w);
-    }
-    const uint32_t wi = t & 3u;
-    const float mine = wi == 0u ? al01.x : (wi == 1u ? al01.y : (wi == 2u ? al23.x : al23.y));
-    const float lu = as_f32(group_bcast<LPC2>(as_u32(mine), blk & (uint32_t)(LPC2 - 1), q2));
-
     float lyt;
 #ifdef MCX_USER_LIK
     if (LIK == LIK_USER) {  // a user's source (mcx_user.hip): this lane's BPL blocks of the proposal
@@ -344,7 +341,29 @@ __device__ __forceinline__ uint32_t fused_fastb_body(const SegArgs &a)
         }
       }
     }
+  };
+  auto one_step = [&](const int s) {
+    const uint32_t t = a.t0 + (uint32_t)s, blk = t >> 2;
+    refresh(blk);
+    const uint32_t wi = t & 3u;
+    const float mine = wi == 0u ? al01.x : (wi == 1u ? al01.y : (wi == 2u ? al23.x : al23.y));
+    step(s, as_f32(group_bcast<LPC2>(as_u32(mine), blk & (uint32_t)(LPC2 - 1), q2)));
+  };
+  int s = 0;
+#if MCX_FAST_UNROLL4
+  // (four steps per iteration from an aligned step on: k_fused_fast's driver loop, mcx_device.hpp)
+  for (; s < a.nsteps && ((a.t0 + (uint32_t)s) & 3u); ++s) one_step(s);
+  for (; s + 4 <= a.nsteps; s += 4) {
+    const uint32_t blk = (a.t0 + (uint32_t)s) >> 2;
+    refresh(blk);
+    const uint32_t holder = blk & (uint32_t)(LPC2 - 1);
+    const float lu4[4] = {as_f32(group_bcast<LPC2>(as_u32(al01.x), holder, q2)), as_f32(group_bcast<LPC2>(as_u32(al01.y), holder, q2)),
+                          as_f32(group_bcast<LPC2>(as_u32(al23.x), holder, q2)), as_f32(group_bcast<LPC2>(as_u32(al23.y), holder, q2))};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) step(s + u, lu4[u]);
   }
+#endif
+  for (; s < a.nsteps; ++s) one_step(s);
 
 #pragma unroll
   for (int b = 0; b < BPL; ++b)
