@@ -8,9 +8,11 @@
 //
 //   * OWN (1..4) "owner" wavefronts per workgroup hold the chains (x, ly) in registers, in the lane layout of
 //     k_fused_fast, and do only what the NEXT step depends on: proposal = x + T z, likelihood,
-//     log u < ly' - ly.  A lone wave pays 4-8 cycles per instruction, so the owner's loop is kept to the bare
-//     dependent chain (measured: ~85 instructions and 690 cycles per step with the moments and the sample
-//     emission in it);
+//     log u < ly' - ly.  A lone wave issues one instruction per 5.7 cycles whatever the instruction (tools/ubench.hip), so
+//     the owner's loop is kept to the bare dependent chain -- 21 vector instructions per burn-in step since round 5 (the
+//     wavefront's index a scalar: uniform control flow; two steps per iteration: no register moves between "next" and
+//     "this" step's numbers; S = -ly kept instead of ly); with the moments and the sample emission in it a step took
+//     ~85 instructions and 690 cycles;
 //   * OWN "recorder" wavefronts, one per owner, follow one phase behind: they read the owner's post-step
 //     (x, ly) from LDS and do the Welford moments (src/mcpar.cc:184-209), the exchange snapshot and the sample
 //     emission (:176-182) -- everything that consumes the state without feeding the next step;
